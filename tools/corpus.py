@@ -1,0 +1,181 @@
+"""Deterministic synthetic inputs shared by the oracle diff tests, the golden-vector generator,
+the GPU parity tests and bench.py.  Pure numpy; nothing here reads
+/root/reference or any file outside the repo, so it runs unchanged on the GPU box.
+
+PRNG: xoshiro256** seeded by splitmix64(0x7371756973685253 ^ config_id ^ index); bytes are the
+little-endian u64 stream."""
+import numpy as np
+
+_M64 = (1 << 64) - 1
+BASE_SEED = 0x7371756973685253
+
+
+def splitmix64(x):
+    x = (x + 0x9E3779B97F4A7C15) & _M64
+    z = x
+    z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & _M64
+    z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & _M64
+    return z ^ (z >> 31), x
+
+
+def _rotl(x, k):
+    return ((x << np.uint64(k)) | (x >> np.uint64(64 - k)))
+
+
+def xoshiro_bytes(seed: int, nbytes: int) -> bytes:
+    """nbytes of xoshiro256** output.  Vectorised over 64 interleaved streams (stream j is seeded
+    from splitmix64 chain element 4j..4j+3), so it is fast in numpy and trivially reproducible
+    on a GPU with one stream per lane."""
+    lanes = 64
+    s = np.zeros((4, lanes), dtype=np.uint64)
+    x = seed & _M64
+    for j in range(lanes):
+        for i in range(4):
+            v, x = splitmix64(x)
+            s[i, j] = v
+    nwords = (nbytes + 7) // 8
+    rounds = (nwords + lanes - 1) // lanes
+    out = np.empty((rounds, lanes), dtype=np.uint64)
+    with np.errstate(over="ignore"):
+        for r in range(rounds):
+            out[r] = _rotl(s[1] * np.uint64(5), 7) * np.uint64(9)
+            t = s[1] << np.uint64(17)
+            s[2] ^= s[0]
+            s[3] ^= s[1]
+            s[1] ^= s[2]
+            s[0] ^= s[3]
+            s[2] ^= t
+            s[3] = _rotl(s[3], 45)
+    return out.reshape(-1).tobytes()[:nbytes]
+
+
+def random_bytes(config_id: int, index: int, nbytes: int) -> bytes:
+    return xoshiro_bytes(BASE_SEED ^ (config_id << 32) ^ index, nbytes)
+
+
+_WORDS = None
+
+
+def _wordlist():
+    """A fixed pseudo-vocabulary (no external corpus): 4096 'words' built from syllables."""
+    global _WORDS
+    if _WORDS is None:
+        syl = ["ka", "to", "ri", "mo", "se", "lu", "an", "de", "pi", "vo", "ne", "sha", "qu", "ex",
+               "ing", "er", "ti", "on", "al", "st", "re", "un", "co", "mp", "th", "ou", "gh", "ea"]
+        rng = np.random.default_rng(12345)
+        words = []
+        for _ in range(4096):
+            k = int(rng.integers(1, 5))
+            words.append("".join(syl[int(i)] for i in rng.integers(0, len(syl), size=k)))
+        _WORDS = words
+    return _WORDS
+
+
+def text_like(seed: int, nbytes: int) -> bytes:
+    """Zipf-distributed words with punctuation/newlines/indentation: compresses to roughly
+    25-35 % at zstd level 12, with a realistic mix of short and long matches."""
+    rng = np.random.default_rng(seed)
+    words = _wordlist()
+    out = bytearray()
+    ranks = rng.zipf(1.3, size=nbytes // 3 + 16)
+    ranks = np.minimum(ranks - 1, len(words) - 1)
+    puncts = rng.integers(0, 40, size=len(ranks))
+    i = 0
+    while len(out) < nbytes:
+        w = words[int(ranks[i])]
+        p = int(puncts[i])
+        i += 1
+        out += w.encode()
+        if p == 0:
+            out += b".\n"
+        elif p == 1:
+            out += b",\n    "
+        elif p == 2:
+            out += b" = "
+        elif p == 3:
+            out += b"(" + str(int(ranks[i % len(ranks)])).encode() + b")"
+        else:
+            out += b" "
+    return bytes(out[:nbytes])
+
+
+def records(seed: int, nbytes: int) -> bytes:
+    """Structured binary records: 32-byte rows with slowly varying fields."""
+    rng = np.random.default_rng(seed)
+    n = nbytes // 32 + 1
+    rec = np.zeros((n, 32), dtype=np.uint8)
+    ids = np.arange(n, dtype=np.uint32) + np.uint32(rng.integers(0, 1 << 20))
+    rec[:, 0:4] = ids.view(np.uint8).reshape(n, 4)
+    ts = (np.cumsum(rng.integers(0, 50, size=n)).astype(np.uint64) + np.uint64(1_700_000_000))
+    rec[:, 4:12] = ts.view(np.uint8).reshape(n, 8)
+    rec[:, 12] = rng.integers(0, 4, size=n)
+    rec[:, 13] = rng.integers(0, 16, size=n)
+    val = rng.normal(1000, 30, size=n).astype(np.float32)
+    rec[:, 16:20] = val.view(np.uint8).reshape(n, 4)
+    rec[:, 20:24] = rng.integers(0, 256, size=(n, 4))
+    return rec.reshape(-1).tobytes()[:nbytes]
+
+
+def runs(seed: int, nbytes: int) -> bytes:
+    """Long zero / RLE runs with occasional noise."""
+    rng = np.random.default_rng(seed)
+    out = bytearray()
+    while len(out) < nbytes:
+        kind = int(rng.integers(0, 4))
+        ln = int(rng.integers(64, 40000))
+        if kind == 0:
+            out += bytes(ln)
+        elif kind == 1:
+            out += bytes([int(rng.integers(0, 256))]) * ln
+        elif kind == 2:
+            pat = bytes(rng.integers(0, 256, size=int(rng.integers(2, 9)), dtype=np.uint8))
+            out += (pat * (ln // len(pat) + 1))[:ln]
+        else:
+            out += bytes(rng.integers(0, 256, size=min(ln, 512), dtype=np.uint8))
+    return bytes(out[:nbytes])
+
+
+def skewed(seed: int, nbytes: int, alpha: float = 1.5) -> bytes:
+    """i.i.d. bytes from a skewed distribution: few LZ matches, Huffman-compressible."""
+    rng = np.random.default_rng(seed)
+    v = np.minimum(rng.zipf(alpha, size=nbytes) - 1, 255).astype(np.uint8)
+    perm = np.random.default_rng(seed ^ 0x55).permutation(256).astype(np.uint8)
+    return perm[v].tobytes()
+
+
+def mixed(seed: int, nbytes: int, region: int = 65536) -> bytes:
+    """Silesia-style mixed entropy: regions of text / records / runs / random."""
+    rng = np.random.default_rng(seed)
+    out = bytearray()
+    k = 0
+    while len(out) < nbytes:
+        kind = int(rng.integers(0, 5))
+        ln = min(int(rng.integers(region // 4, region * 2)), nbytes - len(out))
+        s = seed * 1000003 + k
+        if kind == 0:
+            out += text_like(s, ln)
+        elif kind == 1:
+            out += records(s, ln)
+        elif kind == 2:
+            out += runs(s, ln)
+        elif kind == 3:
+            out += random_bytes(99, s & 0xFFFFFFFF, ln)
+        else:
+            out += skewed(s, ln)
+        k += 1
+    return bytes(out[:nbytes])
+
+
+GENERATORS = {
+    "random": lambda seed, n: random_bytes(7, seed, n),
+    "text": text_like,
+    "records": records,
+    "runs": runs,
+    "skewed": skewed,
+    "mixed": mixed,
+    "zeros": lambda seed, n: bytes(n),
+}
+
+
+def make(kind: str, seed: int, nbytes: int) -> bytes:
+    return GENERATORS[kind](seed, nbytes)
