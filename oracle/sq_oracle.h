@@ -75,6 +75,15 @@ int sqo_store_insert(sqo_store*, const uint8_t* chunk, size_t len, uint8_t hash[
                      size_t cap, size_t* out_len);
 uint64_t sqo_store_len(const sqo_store*);
 
+/* Whole-archive restatement: files in walk order -> malloc'd .squish image (timestamp given). */
+typedef struct {
+    const char* rel_path;
+    const uint8_t* data;
+    uint64_t size;
+} sqo_file;
+size_t sqo_pack_archive(const sqo_file* files, uint32_t nfiles, uint64_t timestamp, uint8_t** out);
+void sqo_free(void* p);
+
 #ifdef __cplusplus
 }
 #endif

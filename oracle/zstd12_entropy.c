@@ -957,9 +957,9 @@ static size_t compressLiterals(u8* dst, size_t dstCap, const u8* src, size_t src
 }
 
 /* ------------------------------------------------------------------ sequences section */
-static const u8 LL_bits[36] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0,  0,  0,  0,  1,  1,
+const u8 zs_LL_bits[36] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0,  0,  0,  0,  1,  1,
                                1, 1, 2, 2, 3, 3, 4, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16};
-static const u8 ML_bits[53] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0,  0,  0,  0,
+const u8 zs_ML_bits[53] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0,  0,  0,  0,
                                0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 1,  1,  1,  1,
                                2, 2, 3, 3, 4, 4, 5, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16};
 static const s16 LL_defaultNorm[36] = {4, 3, 2, 2, 2, 2, 2, 2, 2, 2, 2, 2, 2, 1, 1, 1, 2, 2,
@@ -977,14 +977,14 @@ static const s16 OF_defaultNorm[29] = {1, 1, 1, 1, 1, 1, 2, 2, 2, 1, 1, 1, 1, 1,
 #define MLFSELog 9
 #define OffFSELog 8
 
-static u32 LLcode(u32 litLength) { /* ZSTD_LLcode */
+u32 zs_LLcode(u32 litLength) { /* ZSTD_LLcode */
     static const u8 LL_Code[64] = {0,  1,  2,  3,  4,  5,  6,  7,  8,  9,  10, 11, 12, 13, 14, 15,
                                    16, 16, 17, 17, 18, 18, 19, 19, 20, 20, 20, 20, 21, 21, 21, 21,
                                    22, 22, 22, 22, 22, 22, 22, 22, 23, 23, 23, 23, 23, 23, 23, 23,
                                    24, 24, 24, 24, 24, 24, 24, 24, 24, 24, 24, 24, 24, 24, 24, 24};
     return (litLength > 63) ? highbit32(litLength) + 19 : LL_Code[litLength];
 }
-static u32 MLcode(u32 mlBase) { /* ZSTD_MLcode */
+u32 zs_MLcode(u32 mlBase) { /* ZSTD_MLcode */
     static const u8 ML_Code[128] = {
         0,  1,  2,  3,  4,  5,  6,  7,  8,  9,  10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21,
         22, 23, 24, 25, 26, 27, 28, 29, 30, 31, 32, 32, 33, 33, 34, 34, 35, 35, 36, 36, 36, 36,
@@ -1137,8 +1137,8 @@ static size_t encodeSequences(u8* dst, size_t dstCap, const fse_ct* ctML, const 
     fse_initCState2(&stML, ctML, mlCodeTable[nbSeq - 1]);
     fse_initCState2(&stOF, ctOF, ofCodeTable[nbSeq - 1]);
     fse_initCState2(&stLL, ctLL, llCodeTable[nbSeq - 1]);
-    bw_add(&b, sequences[nbSeq - 1].litLength, LL_bits[llCodeTable[nbSeq - 1]]);
-    bw_add(&b, sequences[nbSeq - 1].mlBase, ML_bits[mlCodeTable[nbSeq - 1]]);
+    bw_add(&b, sequences[nbSeq - 1].litLength, zs_LL_bits[llCodeTable[nbSeq - 1]]);
+    bw_add(&b, sequences[nbSeq - 1].mlBase, zs_ML_bits[mlCodeTable[nbSeq - 1]]);
     bw_add(&b, sequences[nbSeq - 1].offBase, ofCodeTable[nbSeq - 1]);
     {
         size_t n;
@@ -1149,8 +1149,8 @@ static size_t encodeSequences(u8* dst, size_t dstCap, const fse_ct* ctML, const 
             fse_encodeSymbol(&b, &stOF, ofCode);
             fse_encodeSymbol(&b, &stML, mlCode);
             fse_encodeSymbol(&b, &stLL, llCode);
-            bw_add(&b, sequences[n].litLength, LL_bits[llCode]);
-            bw_add(&b, sequences[n].mlBase, ML_bits[mlCode]);
+            bw_add(&b, sequences[n].litLength, zs_LL_bits[llCode]);
+            bw_add(&b, sequences[n].mlBase, zs_ML_bits[mlCode]);
             bw_add(&b, sequences[n].offBase, ofCode);
         }
     }
@@ -1220,9 +1220,9 @@ size_t entropy_compress_seqstore(const seqstore* ss, const entropy_t* prev, entr
         u32 LLtype, Offtype, MLtype;
         /* ZSTD_seqToCodes */
         for (size_t u = 0; u < nbSeq; u++) {
-            ss->llCode[u] = (u8)LLcode(ss->seqs[u].litLength);
+            ss->llCode[u] = (u8)zs_LLcode(ss->seqs[u].litLength);
             ss->ofCode[u] = (u8)highbit32(ss->seqs[u].offBase);
-            ss->mlCode[u] = (u8)MLcode(ss->seqs[u].mlBase);
+            ss->mlCode[u] = (u8)zs_MLcode(ss->seqs[u].mlBase);
         }
         if (ss->longLengthType == 1) ss->llCode[ss->longLengthPos] = MaxLL;
         if (ss->longLengthType == 2) ss->mlCode[ss->longLengthPos] = MaxML;

@@ -72,6 +72,11 @@ typedef struct {
     u8 *llCode, *ofCode, *mlCode; /* capacity >= max nseq */
 } seqstore;
 
+extern const u8 zs_LL_bits[36];
+extern const u8 zs_ML_bits[53];
+u32 zs_LLcode(u32 litLength); /* ZSTD_LLcode */
+u32 zs_MLcode(u32 mlBase);    /* ZSTD_MLcode */
+
 void entropy_reset(entropy_t* e); /* ZSTD_reset_compressedBlockState (tables part) */
 
 /* ZSTD_entropyCompressSeqStore: returns compressed block body size, 0 = "emit raw block",

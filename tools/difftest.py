@@ -20,7 +20,7 @@ class Seq(ctypes.Structure):
 
 
 def load_oracle():
-    o = ctypes.CDLL(os.path.join(ROOT, "oracle", "_build", "libsq_oracle.so"))
+    o = ctypes.CDLL(os.environ.get("SQO_SO", os.path.join(ROOT, "oracle", "_build", "libsq_oracle.so")))
     o.sqo_compress_chunk.restype = ctypes.c_size_t
     o.sqo_compress_chunk.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_size_t]
     o.sqo_compress_bound.restype = ctypes.c_size_t
