@@ -1,0 +1,127 @@
+/*
+ * squish_gpu.h -- C ABI of libsquish_gpu.so: the MI355X (gfx950) implementation of squishRS's
+ * pack-side hot path (per-chunk XXH3-128 content hash, global dedup set, zstd level-12 frame
+ * compressor).  Plain pointers and sizes only; no C++/torch types; never throws or aborts across
+ * the boundary.  Every entry point returns 0 (SQ_OK) or a negative sq_err.
+ *
+ * The reference (SamB032/squishRS v1.2.0) has no FFI for this path; the seam these symbols replace
+ * is the Rust API of /root/reference/src/util/chunk.rs, called from
+ * /root/reference/src/archive/writer.rs:249 on Rayon workers.  INTEGRATION.md shows the
+ * `extern "C"` block a maintainer would add to src/util/chunk.rs to bind them.
+ *
+ * Pointer arguments documented "host or device" are classified with hipPointerGetAttributes:
+ * device pointers are used in place (nothing crosses PCIe); host pointers are staged through the
+ * context's device buffers.
+ */
+#ifndef SQUISH_GPU_H
+#define SQUISH_GPU_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SQ_ABI_VERSION 1
+#define SQ_CHUNK_SIZE (2048u * 1024u) /* CHUNK_SIZE, src/util/chunk.rs:11 */
+#define SQ_LEVEL 12                   /* COMPRESSION_LEVEL, src/util/chunk.rs:12 */
+#define SQ_HASH_BYTES 16              /* ChunkHash = [u8; 16], src/util/chunk.rs:9 */
+
+typedef enum sq_err {
+    SQ_OK = 0,
+    SQ_E_INVAL = -1,    /* bad argument */
+    SQ_E_NOMEM = -2,    /* host or device allocation failed */
+    SQ_E_CAP = -3,      /* output capacity too small */
+    SQ_E_DEVICE = -4,   /* HIP runtime error / no gfx950 device / kernel fault */
+    SQ_E_COMPRESS = -5, /* == AppError::Compression (src/util/chunk.rs:90, errors.rs:25-26) */
+    SQ_E_NODEVICE = -6  /* library built without a usable GPU at run time: fails loudly, no CPU path */
+} sq_err;
+
+typedef struct sq_ctx sq_ctx;
+
+typedef struct sq_config {
+    uint32_t abi_version;      /* SQ_ABI_VERSION */
+    int32_t device;            /* HIP device ordinal */
+    uint32_t max_chunk;        /* largest chunk length in bytes (<= SQ_CHUNK_SIZE; 0 = SQ_CHUNK_SIZE) */
+    uint32_t max_batch_chunks; /* chunks per sq_pack_batch call (0 = 4096) */
+    uint64_t max_batch_bytes;  /* input bytes per call when staged from host (0 = 1 GiB) */
+    uint64_t dedup_capacity;   /* distinct chunks the dedup set can hold (0 = 1<<22) */
+    uint32_t compress_waves;   /* persistent compressor wavefronts (0 = auto) */
+    uint32_t reserved;
+} sq_config;
+
+/* Lifecycle.  One ctx per driver thread (a ctx is not re-entrant); the dedup set inside is the
+ * counterpart of ChunkStore.primary_store (src/util/chunk.rs:20-24,52-56). */
+int sq_ctx_create(const sq_config* cfg, sq_ctx** out);
+void sq_ctx_destroy(sq_ctx* ctx);
+/* Run all subsequent work of this ctx on an existing hipStream_t (e.g. torch's current stream). */
+int sq_ctx_set_stream(sq_ctx* ctx, void* hip_stream);
+int sq_ctx_synchronize(sq_ctx* ctx);
+
+/* == hash_chunk (src/util/chunk.rs:46-49): out = xxh3_128(chunk).to_le_bytes().
+ * Stateless convenience form (host pointers, runs one tiny launch on device 0). */
+int sq_hash_chunk(const uint8_t* chunk, size_t len, uint8_t out[SQ_HASH_BYTES]);
+
+/* == ZSTD_compressBound: capacity that always suffices for one frame of n input bytes. */
+size_t sq_compress_bound(size_t n);
+
+/* == zstd::bulk::compress(chunk, 12) (src/util/chunk.rs:89-90): one complete zstd frame.
+ * Stateless convenience form (host pointers). */
+int sq_compress_chunk(const uint8_t* chunk, size_t len, uint8_t* dst, size_t cap, size_t* out_len);
+
+/* == n x ChunkStore::insert applied in index order (src/util/chunk.rs:80-100): chunk i is
+ * data[off[i] .. off[i]+len[i]) (chunks may be padded apart; 16-byte aligned starts are fastest).
+ * For every chunk hashes[16*i..] receives its hash; is_new[i] = 1 iff
+ * this is the first occurrence of that hash in index order across all batches of this ctx
+ * (Entry::Vacant), and only those chunks are compressed: frame i occupies
+ * comp[comp_off[i] .. comp_off[i+1]) (empty for duplicates).  comp_cap bytes must be available at
+ * comp; SQ_E_CAP if the frames do not fit (nothing is committed to the dedup set in that case).
+ * data / hashes / is_new / comp: host or device (all on the same side).
+ * off, len (n entries each) and comp_off (n+1 entries): host. */
+int sq_pack_batch(sq_ctx* ctx, const uint8_t* data, const uint64_t* off, const uint32_t* len,
+                  uint32_t n, uint8_t* hashes, uint8_t* is_new, uint8_t* comp, uint64_t comp_cap,
+                  uint64_t* comp_off);
+
+/* == ChunkStore::len (src/util/chunk.rs:116-118). */
+uint64_t sq_unique_count(const sq_ctx* ctx);
+
+/* ---- stage-level entry points (same kernels sq_pack_batch chains; used by the multi-GPU
+ * driver, the parity tests and bench.py).  d_* are DEVICE pointers, h_* HOST pointers. */
+
+/* hash stage: d_hashes[16*i..] = hash_chunk(chunk i). */
+int sq_hash_batch(sq_ctx* ctx, const uint8_t* d_data, const uint64_t* h_off, const uint32_t* h_len,
+                  uint32_t n, uint8_t* d_hashes);
+
+/* dedup stage over an already gathered, globally ordered hash list of n_total entries (multi-GPU:
+ * the RCCL all-gather result; single GPU: the batch itself).  Entries [my_first, my_first+my_n)
+ * belong to this rank; d_is_new[my_n] receives 1 where the entry is the first occurrence of its
+ * hash in global index order and was not seen in any earlier call.  All n_total hashes are
+ * committed to the ctx's set, so every rank ends with the same set and unique count. */
+int sq_dedup_global(sq_ctx* ctx, const uint8_t* d_all_hashes, uint64_t n_total, uint64_t my_first,
+                    uint32_t my_n, uint8_t* d_is_new);
+
+/* compress stage: frames for chunks with d_select[i] != 0 (NULL = all), compacted into d_comp in
+ * index order; h_comp_off (host, n+1 entries) receives the offsets.  Returns SQ_E_CAP if
+ * comp_cap is too small. */
+int sq_compress_batch(sq_ctx* ctx, const uint8_t* d_data, const uint64_t* h_off,
+                      const uint32_t* h_len, uint32_t n, const uint8_t* d_select, uint8_t* d_comp,
+                      uint64_t comp_cap, uint64_t* h_comp_off);
+
+/* HBM read-bandwidth calibration (a trivial 16 B/lane streaming read over d_buf): returns the
+ * kernel time in ms through *ms.  bench.py reports it beside the 8 TB/s nominal peak. */
+int sq_calibrate_read_bw(sq_ctx* ctx, const uint8_t* d_buf, uint64_t nbytes, float* ms);
+
+/* Timing of the most recent stage launches of this ctx, in milliseconds, measured with HIP
+ * events on the ctx stream (0 if the stage did not run). */
+typedef struct sq_timings {
+    float hash_ms, dedup_ms, compress_ms, compact_ms;
+} sq_timings;
+int sq_last_timings(sq_ctx* ctx, sq_timings* out);
+
+const char* sq_strerror(int err);
+uint32_t sq_abi_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,81 @@
+"""ctypes binding of libsquish_gpu.so (the C ABI in include/squish_gpu.h).
+
+The library is the product: there is no Python or CPU implementation behind it.  If it is missing
+or no gfx950 device is usable, every call raises -- nothing falls back to the CPU."""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libsquish_gpu.so")
+
+SQ_OK = 0
+SQ_E_INVAL, SQ_E_NOMEM, SQ_E_CAP, SQ_E_DEVICE, SQ_E_COMPRESS, SQ_E_NODEVICE = -1, -2, -3, -4, -5, -6
+SQ_ABI_VERSION = 1
+SQ_CHUNK_SIZE = 2048 * 1024
+
+EXPORTS = [
+    "sq_abi_version", "sq_strerror", "sq_compress_bound", "sq_ctx_create", "sq_ctx_destroy",
+    "sq_ctx_set_stream", "sq_ctx_synchronize", "sq_hash_chunk", "sq_compress_chunk",
+    "sq_pack_batch", "sq_unique_count", "sq_hash_batch", "sq_dedup_global", "sq_compress_batch",
+    "sq_calibrate_read_bw", "sq_last_timings",
+]
+
+
+class SqConfig(ctypes.Structure):
+    _fields_ = [("abi_version", ctypes.c_uint32), ("device", ctypes.c_int32),
+                ("max_chunk", ctypes.c_uint32), ("max_batch_chunks", ctypes.c_uint32),
+                ("max_batch_bytes", ctypes.c_uint64), ("dedup_capacity", ctypes.c_uint64),
+                ("compress_waves", ctypes.c_uint32), ("reserved", ctypes.c_uint32)]
+
+
+class SqTimings(ctypes.Structure):
+    _fields_ = [("hash_ms", ctypes.c_float), ("dedup_ms", ctypes.c_float),
+                ("compress_ms", ctypes.c_float), ("compact_ms", ctypes.c_float)]
+
+
+class SquishError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"libsquish_gpu: {msg} ({code})")
+        self.code = code
+
+
+_lib = None
+
+
+def load():
+    """Load libsquish_gpu.so (built in-tree by __graft_entry__.build()).  Raises if absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise SquishError(SQ_E_NODEVICE, f"{LIB_PATH} not built; run __graft_entry__.build()")
+    L = ctypes.CDLL(LIB_PATH)
+    vp, u8p = ctypes.c_void_p, ctypes.c_void_p
+    L.sq_abi_version.restype = ctypes.c_uint32
+    L.sq_strerror.restype = ctypes.c_char_p
+    L.sq_strerror.argtypes = [ctypes.c_int]
+    L.sq_compress_bound.restype = ctypes.c_size_t
+    L.sq_compress_bound.argtypes = [ctypes.c_size_t]
+    L.sq_ctx_create.argtypes = [ctypes.POINTER(SqConfig), ctypes.POINTER(vp)]
+    L.sq_ctx_destroy.argtypes = [vp]
+    L.sq_ctx_destroy.restype = None
+    L.sq_ctx_set_stream.argtypes = [vp, vp]
+    L.sq_ctx_synchronize.argtypes = [vp]
+    L.sq_hash_chunk.argtypes = [u8p, ctypes.c_size_t, u8p]
+    L.sq_compress_chunk.argtypes = [u8p, ctypes.c_size_t, u8p, ctypes.c_size_t,
+                                    ctypes.POINTER(ctypes.c_size_t)]
+    L.sq_pack_batch.argtypes = [vp, u8p, vp, vp, ctypes.c_uint32, u8p, u8p, u8p, ctypes.c_uint64, vp]
+    L.sq_unique_count.restype = ctypes.c_uint64
+    L.sq_unique_count.argtypes = [vp]
+    L.sq_hash_batch.argtypes = [vp, u8p, vp, vp, ctypes.c_uint32, u8p]
+    L.sq_dedup_global.argtypes = [vp, u8p, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_uint32, u8p]
+    L.sq_compress_batch.argtypes = [vp, u8p, vp, vp, ctypes.c_uint32, u8p, u8p, ctypes.c_uint64, vp]
+    L.sq_calibrate_read_bw.argtypes = [vp, u8p, ctypes.c_uint64, ctypes.POINTER(ctypes.c_float)]
+    L.sq_last_timings.argtypes = [vp, ctypes.POINTER(SqTimings)]
+    _lib = L
+    return L
+
+
+def check(code):
+    if code != SQ_OK:
+        raise SquishError(code, load().sq_strerror(code).decode())

@@ -1,0 +1,155 @@
+"""Host-side mirror of the reference's chunk API (src/util/chunk.rs) over the C ABI.
+
+Same names and argument meaning as the reference: `hash_chunk`, `ChunkStore.insert/len/is_empty`,
+`CHUNK_SIZE`, `InsertReturn{hash, compressed_data}`; errors surface as SquishError whose text for
+compressor failures is the reference's "Compression error" (src/util/errors.rs:25-26).
+Batch forms (`insert_batch`, device-resident `pack_device`) are additive.
+
+torch is used only for device memory, streams and (in parallel.py) torch.distributed."""
+import ctypes
+from dataclasses import dataclass
+from typing import List, Optional, Sequence
+
+import numpy as np
+
+from . import _lib
+from ._lib import SqConfig, SqTimings, SquishError, check
+
+CHUNK_SIZE = 2048 * 1024   # src/util/chunk.rs:11
+COMPRESSION_LEVEL = 12     # src/util/chunk.rs:12
+
+
+@dataclass
+class InsertReturn:        # src/util/chunk.rs:14-17
+    hash: bytes
+    compressed_data: Optional[bytes]
+
+
+def compress_bound(n: int) -> int:
+    return int(_lib.load().sq_compress_bound(n))
+
+
+def hash_chunk(chunk: bytes) -> bytes:
+    """== hash_chunk (src/util/chunk.rs:46-49), computed by the HIP kernel."""
+    L = _lib.load()
+    out = ctypes.create_string_buffer(16)
+    buf = (ctypes.c_char * max(len(chunk), 1)).from_buffer_copy(chunk or b"\0")
+    check(L.sq_hash_chunk(ctypes.addressof(buf), len(chunk), ctypes.addressof(out)))
+    return out.raw
+
+
+def compress_chunk(chunk: bytes) -> bytes:
+    """== zstd::bulk::compress(chunk, 12) (src/util/chunk.rs:89-90), computed by the HIP kernel."""
+    L = _lib.load()
+    cap = compress_bound(len(chunk)) + 64
+    dst = ctypes.create_string_buffer(cap)
+    n = ctypes.c_size_t(0)
+    buf = (ctypes.c_char * max(len(chunk), 1)).from_buffer_copy(chunk or b"\0")
+    check(L.sq_compress_chunk(ctypes.addressof(buf), len(chunk), ctypes.addressof(dst), cap,
+                              ctypes.byref(n)))
+    return dst.raw[:n.value]
+
+
+class ChunkStore:
+    """== ChunkStore (src/util/chunk.rs:19-24,52-56,80-136); the dedup set lives in HBM."""
+
+    def __init__(self, device: int = 0, max_chunk: int = CHUNK_SIZE, dedup_capacity: int = 1 << 22,
+                 compress_waves: int = 0):
+        L = _lib.load()
+        cfg = SqConfig(_lib.SQ_ABI_VERSION, device, max_chunk, 0, 0, dedup_capacity, compress_waves, 0)
+        h = ctypes.c_void_p()
+        check(L.sq_ctx_create(ctypes.byref(cfg), ctypes.byref(h)))
+        self._h = h
+        self._L = L
+        self.device = device
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.sq_ctx_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:  # noqa: BLE001
+            pass
+
+    # -- reference API ---------------------------------------------------------------------
+    def insert(self, chunk: bytes) -> InsertReturn:
+        return self.insert_batch([chunk])[0]
+
+    def len(self) -> int:
+        return int(self._L.sq_unique_count(self._h))
+
+    def __len__(self):
+        return self.len()
+
+    def is_empty(self) -> bool:
+        return self.len() == 0
+
+    # -- batch forms -----------------------------------------------------------------------
+    def insert_batch(self, chunks: Sequence[bytes]) -> List[InsertReturn]:
+        """n x insert in index order through sq_pack_batch with host buffers."""
+        n = len(chunks)
+        if n == 0:
+            return []
+        lens = np.array([len(c) for c in chunks], dtype=np.uint32)
+        offs = np.zeros(n, dtype=np.uint64)
+        offs[1:] = np.cumsum(lens.astype(np.uint64))[:-1]
+        data = np.frombuffer(b"".join(chunks) or b"\0", dtype=np.uint8)
+        hashes = np.zeros(n * 16, dtype=np.uint8)
+        is_new = np.zeros(n, dtype=np.uint8)
+        cap = int(sum(compress_bound(int(x)) + 64 for x in lens))
+        comp = np.zeros(cap, dtype=np.uint8)
+        comp_off = np.zeros(n + 1, dtype=np.uint64)
+        check(self._L.sq_pack_batch(self._h, data.ctypes.data, offs.ctypes.data, lens.ctypes.data, n,
+                                    hashes.ctypes.data, is_new.ctypes.data, comp.ctypes.data, cap,
+                                    comp_off.ctypes.data))
+        out = []
+        for i in range(n):
+            h = hashes[16 * i:16 * i + 16].tobytes()
+            if is_new[i]:
+                out.append(InsertReturn(h, comp[int(comp_off[i]):int(comp_off[i + 1])].tobytes()))
+            else:
+                out.append(InsertReturn(h, None))
+        return out
+
+    # -- device-resident stage API (torch tensors on this store's device) ---------------------
+    def set_stream(self, stream_ptr: int):
+        check(self._L.sq_ctx_set_stream(self._h, ctypes.c_void_p(stream_ptr)))
+
+    def synchronize(self):
+        check(self._L.sq_ctx_synchronize(self._h))
+
+    def hash_device(self, data, offs: np.ndarray, lens: np.ndarray, hashes):
+        check(self._L.sq_hash_batch(self._h, data.data_ptr(), offs.ctypes.data, lens.ctypes.data,
+                                    len(lens), hashes.data_ptr()))
+
+    def dedup_device(self, all_hashes, n_total: int, my_first: int, my_n: int, is_new):
+        check(self._L.sq_dedup_global(self._h, all_hashes.data_ptr(), n_total, my_first, my_n,
+                                      is_new.data_ptr() if my_n else None))
+
+    def compress_device(self, data, offs: np.ndarray, lens: np.ndarray, select, comp) -> np.ndarray:
+        comp_off = np.zeros(len(lens) + 1, dtype=np.uint64)
+        check(self._L.sq_compress_batch(self._h, data.data_ptr(), offs.ctypes.data, lens.ctypes.data,
+                                        len(lens), select.data_ptr() if select is not None else None,
+                                        comp.data_ptr(), comp.numel(), comp_off.ctypes.data))
+        return comp_off
+
+    def pack_device(self, data, offs: np.ndarray, lens: np.ndarray, hashes, is_new, comp) -> np.ndarray:
+        """sq_pack_batch with every buffer resident in HBM (nothing crosses PCIe but offsets)."""
+        comp_off = np.zeros(len(lens) + 1, dtype=np.uint64)
+        check(self._L.sq_pack_batch(self._h, data.data_ptr(), offs.ctypes.data, lens.ctypes.data,
+                                    len(lens), hashes.data_ptr(), is_new.data_ptr(), comp.data_ptr(),
+                                    comp.numel(), comp_off.ctypes.data))
+        return comp_off
+
+    def read_bw_ms(self, buf) -> float:
+        ms = ctypes.c_float(0)
+        check(self._L.sq_calibrate_read_bw(self._h, buf.data_ptr(), buf.numel(), ctypes.byref(ms)))
+        return ms.value
+
+    def timings(self) -> SqTimings:
+        t = SqTimings()
+        check(self._L.sq_last_timings(self._h, ctypes.byref(t)))
+        return t

@@ -1,0 +1,526 @@
+// sq_api.hip -- host side of libsquish_gpu.so: implements include/squish_gpu.h on top of the HIP
+// kernels in this directory.  There is deliberately NO CPU implementation behind these entry
+// points: without a usable gfx950 device every call fails with SQ_E_NODEVICE / SQ_E_DEVICE.
+#include "../../include/squish_gpu.h"
+#include "sq_common.h"
+#include "sq_dedup.h"
+#include "sq_xxh3.h"
+#ifndef SQ_NO_COMPRESS
+#include "sq_zstd_kernel.h"
+#endif
+#include <hip/hip_runtime.h>
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <vector>
+
+#define HIPCHK(x)                                                                                  \
+    do {                                                                                           \
+        hipError_t e_ = (x);                                                                       \
+        if (e_ != hipSuccess) {                                                                    \
+            if (getenv("SQ_DEBUG"))                                                                \
+                fprintf(stderr, "[squish_gpu] %s:%d %s -> %s\n", __FILE__, __LINE__, #x,           \
+                        hipGetErrorString(e_));                                                    \
+            return (e_ == hipErrorOutOfMemory) ? SQ_E_NOMEM : SQ_E_DEVICE;                         \
+        }                                                                                          \
+    } while (0)
+
+namespace {
+
+struct DevBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+    int ensure(size_t n) {
+        if (n <= cap) return SQ_OK;
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+        size_t want = n + (n >> 3) + 4096; // grow with slack so steady state does not reallocate
+        hipError_t e = hipMalloc(&p, want);
+        if (e != hipSuccess) {
+            p = nullptr;
+            e = hipMalloc(&p, n);
+            if (e != hipSuccess) {
+                p = nullptr;
+                return SQ_E_NOMEM;
+            }
+            want = n;
+        }
+        cap = want;
+        return SQ_OK;
+    }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+    }
+};
+
+} // namespace
+
+struct sq_ctx {
+    sq_config cfg;
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    hipEvent_t ev[8];
+    int num_cu = 256;
+
+    // dedup state (persistent)
+    u64* d_keys = nullptr; // 2 x u64 per chunk ever seen
+    u32* d_table = nullptr;
+    unsigned long long* d_unique = nullptr;
+    u64 table_mask = 0;
+    u64 key_capacity = 0;
+    u64 n_seen = 0; // global chunk index of the next chunk
+
+    // per-batch scratch
+    DevBuf b_off, b_len, b_slot_off, b_frame_len, b_out_off, b_isnew, b_hashes, b_stage_in,
+        b_stage_out, b_slots, b_ws, b_misc;
+    void* h_pinned = nullptr; // small pinned host mirror (total sizes etc.)
+
+    sq_timings last = {0, 0, 0, 0};
+};
+
+static bool is_device_ptr(const void* p) {
+    if (!p) return false;
+    hipPointerAttribute_t a;
+    hipError_t e = hipPointerGetAttributes(&a, p);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        return false;
+    }
+    return a.type == hipMemoryTypeDevice || a.type == hipMemoryTypeManaged;
+}
+
+extern "C" {
+
+uint32_t sq_abi_version(void) { return SQ_ABI_VERSION; }
+
+const char* sq_strerror(int err) {
+    switch (err) {
+    case SQ_OK: return "ok";
+    case SQ_E_INVAL: return "invalid argument";
+    case SQ_E_NOMEM: return "out of memory";
+    case SQ_E_CAP: return "output capacity too small";
+    case SQ_E_DEVICE: return "HIP device error";
+    case SQ_E_COMPRESS: return "Compression error";
+    case SQ_E_NODEVICE: return "no gfx950 device available (libsquish_gpu has no CPU path)";
+    default: return "unknown error";
+    }
+}
+
+size_t sq_compress_bound(size_t n) {
+    return n + (n >> 8) + ((n < (128u << 10)) ? (((128u << 10) - n) >> 11) : 0);
+}
+
+int sq_ctx_create(const sq_config* cfg_in, sq_ctx** out) {
+    if (!out) return SQ_E_INVAL;
+    *out = nullptr;
+    sq_config cfg;
+    memset(&cfg, 0, sizeof(cfg));
+    if (cfg_in) cfg = *cfg_in;
+    if (cfg_in && cfg.abi_version != SQ_ABI_VERSION) return SQ_E_INVAL;
+    if (cfg.max_chunk == 0 || cfg.max_chunk > SQ_CHUNK_SIZE) cfg.max_chunk = SQ_CHUNK_SIZE;
+    if (cfg.max_batch_chunks == 0) cfg.max_batch_chunks = 4096;
+    if (cfg.max_batch_bytes == 0) cfg.max_batch_bytes = 1ull << 30;
+    if (cfg.dedup_capacity == 0) cfg.dedup_capacity = 1ull << 22;
+
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+        (void)hipGetLastError();
+        return SQ_E_NODEVICE;
+    }
+    if (cfg.device < 0 || cfg.device >= ndev) return SQ_E_INVAL;
+    HIPCHK(hipSetDevice(cfg.device));
+    hipDeviceProp_t prop;
+    HIPCHK(hipGetDeviceProperties(&prop, cfg.device));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0 && !getenv("SQ_ALLOW_ANY_ARCH")) return SQ_E_NODEVICE;
+
+    sq_ctx* c = new (std::nothrow) sq_ctx();
+    if (!c) return SQ_E_NOMEM;
+    c->cfg = cfg;
+    c->device = cfg.device;
+    c->num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
+        delete c;
+        return SQ_E_DEVICE;
+    }
+    c->own_stream = true;
+    for (auto& e : c->ev)
+        if (hipEventCreate(&e) != hipSuccess) {
+            delete c;
+            return SQ_E_DEVICE;
+        }
+    // dedup set: table of 2x capacity (power of two), keys for `capacity` chunks
+    u64 slots = 1024;
+    while (slots < cfg.dedup_capacity * 2) slots <<= 1;
+    c->table_mask = slots - 1;
+    c->key_capacity = cfg.dedup_capacity;
+    if (hipMalloc((void**)&c->d_table, slots * sizeof(u32)) != hipSuccess ||
+        hipMalloc((void**)&c->d_keys, c->key_capacity * 16) != hipSuccess ||
+        hipMalloc((void**)&c->d_unique, 64) != hipSuccess ||
+        hipHostMalloc(&c->h_pinned, 4096, hipHostMallocDefault) != hipSuccess) {
+        sq_ctx_destroy(c);
+        return SQ_E_NOMEM;
+    }
+    if (hipMemsetAsync(c->d_table, 0, slots * sizeof(u32), c->stream) != hipSuccess ||
+        hipMemsetAsync(c->d_unique, 0, 64, c->stream) != hipSuccess ||
+        hipStreamSynchronize(c->stream) != hipSuccess) {
+        sq_ctx_destroy(c);
+        return SQ_E_DEVICE;
+    }
+    *out = c;
+    return SQ_OK;
+}
+
+void sq_ctx_destroy(sq_ctx* c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    for (DevBuf* b : {&c->b_off, &c->b_len, &c->b_slot_off, &c->b_frame_len, &c->b_out_off, &c->b_isnew,
+                      &c->b_hashes, &c->b_stage_in, &c->b_stage_out, &c->b_slots, &c->b_ws, &c->b_misc})
+        b->release();
+    if (c->d_table) (void)hipFree(c->d_table);
+    if (c->d_keys) (void)hipFree(c->d_keys);
+    if (c->d_unique) (void)hipFree(c->d_unique);
+    if (c->h_pinned) (void)hipHostFree(c->h_pinned);
+    for (auto& e : c->ev)
+        if (e) (void)hipEventDestroy(e);
+    if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+int sq_ctx_set_stream(sq_ctx* c, void* s) {
+    if (!c) return SQ_E_INVAL;
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    if (c->own_stream) (void)hipStreamDestroy(c->stream);
+    c->stream = (hipStream_t)s;
+    c->own_stream = false;
+    return SQ_OK;
+}
+
+int sq_ctx_synchronize(sq_ctx* c) {
+    if (!c) return SQ_E_INVAL;
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return SQ_OK;
+}
+
+uint64_t sq_unique_count(const sq_ctx* c) {
+    if (!c) return 0;
+    unsigned long long v = 0;
+    (void)hipSetDevice(c->device);
+    if (hipStreamSynchronize(c->stream) != hipSuccess) return 0;
+    if (hipMemcpy(&v, c->d_unique, sizeof(v), hipMemcpyDeviceToHost) != hipSuccess) return 0;
+    return (uint64_t)v;
+}
+
+int sq_last_timings(sq_ctx* c, sq_timings* out) {
+    if (!c || !out) return SQ_E_INVAL;
+    *out = c->last;
+    return SQ_OK;
+}
+
+// ---- helpers --------------------------------------------------------------------------------
+static int upload_off_len(sq_ctx* c, const u64* h_off, const u32* h_len, u32 n) {
+    int r;
+    if ((r = c->b_off.ensure((size_t)n * 8))) return r;
+    if ((r = c->b_len.ensure((size_t)n * 4))) return r;
+    HIPCHK(hipMemcpyAsync(c->b_off.p, h_off, (size_t)n * 8, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(hipMemcpyAsync(c->b_len.p, h_len, (size_t)n * 4, hipMemcpyHostToDevice, c->stream));
+    return SQ_OK;
+}
+
+static int launch_hash(sq_ctx* c, const u8* d_data, u32 n, u8* d_hashes) {
+    if (n == 0) return SQ_OK;
+    const u32 wpb = 4;
+    dim3 grid((n + wpb - 1) / wpb), block(64 * wpb);
+    HIPCHK(hipEventRecord(c->ev[0], c->stream));
+    hipLaunchKernelGGL(sqx::k_xxh3_128_batch, grid, block, 0, c->stream, d_data, (const u64*)c->b_off.p,
+                       (const u32*)c->b_len.p, n, d_hashes);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipEventRecord(c->ev[1], c->stream));
+    return SQ_OK;
+}
+
+int sq_hash_batch(sq_ctx* c, const uint8_t* d_data, const uint64_t* h_off, const uint32_t* h_len,
+                  uint32_t n, uint8_t* d_hashes) {
+    if (!c || (n && (!d_data || !h_off || !h_len || !d_hashes))) return SQ_E_INVAL;
+    HIPCHK(hipSetDevice(c->device));
+    int r;
+    if ((r = upload_off_len(c, h_off, h_len, n))) return r;
+    if ((r = launch_hash(c, d_data, n, d_hashes))) return r;
+    HIPCHK(hipStreamSynchronize(c->stream));
+    if (n) HIPCHK(hipEventElapsedTime(&c->last.hash_ms, c->ev[0], c->ev[1]));
+    return SQ_OK;
+}
+
+static int dedup_async(sq_ctx* c, const u8* d_all_hashes, u64 n_total, u64 my_first, u32 my_n,
+                       u8* d_is_new) {
+    if (c->n_seen + n_total > c->key_capacity) return SQ_E_CAP;
+    if (c->n_seen + n_total >= 0xFFFFFFFFull) return SQ_E_CAP;
+    if (n_total == 0) return SQ_OK;
+    const u64 g0 = c->n_seen;
+    HIPCHK(hipEventRecord(c->ev[2], c->stream));
+    HIPCHK(hipMemcpyAsync(c->d_keys + 2 * g0, d_all_hashes, n_total * 16, hipMemcpyDeviceToDevice,
+                          c->stream));
+    {
+        dim3 block(256), grid((unsigned)((n_total + 255) / 256));
+        hipLaunchKernelGGL(sqd::k_dedup_insert, grid, block, 0, c->stream, (const u64*)c->d_keys, g0,
+                           n_total, c->d_table, c->table_mask, c->d_unique);
+        HIPCHK(hipGetLastError());
+    }
+    if (my_n) {
+        dim3 block(256), grid((my_n + 255) / 256);
+        hipLaunchKernelGGL(sqd::k_dedup_resolve, grid, block, 0, c->stream, (const u64*)c->d_keys,
+                           g0 + my_first, my_n, (const u32*)c->d_table, c->table_mask, d_is_new);
+        HIPCHK(hipGetLastError());
+    }
+    HIPCHK(hipEventRecord(c->ev[3], c->stream));
+    c->n_seen += n_total;
+    return SQ_OK;
+}
+
+int sq_dedup_global(sq_ctx* c, const uint8_t* d_all_hashes, uint64_t n_total, uint64_t my_first,
+                    uint32_t my_n, uint8_t* d_is_new) {
+    if (!c || (n_total && !d_all_hashes) || (my_n && !d_is_new) || my_first + my_n > n_total)
+        return SQ_E_INVAL;
+    HIPCHK(hipSetDevice(c->device));
+    int r = dedup_async(c, d_all_hashes, n_total, my_first, my_n, d_is_new);
+    if (r) return r;
+    HIPCHK(hipStreamSynchronize(c->stream));
+    if (n_total) HIPCHK(hipEventElapsedTime(&c->last.dedup_ms, c->ev[2], c->ev[3]));
+    return SQ_OK;
+}
+
+int sq_calibrate_read_bw(sq_ctx* c, const uint8_t* d_buf, uint64_t nbytes, float* ms) {
+    if (!c || !d_buf || !ms || ((uintptr_t)d_buf & 15)) return SQ_E_INVAL;
+    HIPCHK(hipSetDevice(c->device));
+    int r = c->b_misc.ensure(256);
+    if (r) return r;
+    dim3 block(256), grid((unsigned)(c->num_cu * 8));
+    HIPCHK(hipEventRecord(c->ev[6], c->stream));
+    hipLaunchKernelGGL(sqd::k_read_bw, grid, block, 0, c->stream, (const uint4*)d_buf, nbytes / 16,
+                       (u32*)c->b_misc.p);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipEventRecord(c->ev[7], c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    HIPCHK(hipEventElapsedTime(ms, c->ev[6], c->ev[7]));
+    return SQ_OK;
+}
+
+#ifndef SQ_NO_COMPRESS
+// Frames are produced into per-chunk slots (bound(len) bytes, 16-byte aligned), then packed.
+static int compress_async(sq_ctx* c, const u8* d_data, const u64* h_off, const u32* h_len, u32 n,
+                          const u8* d_select, u8* d_comp, u64 comp_cap, u64* h_comp_off) {
+    (void)h_off;
+    int r;
+    if (n == 0) {
+        h_comp_off[0] = 0;
+        return SQ_OK;
+    }
+    // slot offsets on the host (prefix sum of bounds)
+    std::vector<u64> slot_off((size_t)n + 1);
+    u64 acc = 0;
+    u32 max_len = 0;
+    for (u32 i = 0; i < n; i++) {
+        slot_off[i] = acc;
+        acc += (sq_compress_bound(h_len[i]) + 32 + 15) & ~(u64)15;
+        max_len = std::max(max_len, h_len[i]);
+    }
+    slot_off[n] = acc;
+    if (max_len > c->cfg.max_chunk) return SQ_E_INVAL;
+    if ((r = c->b_slot_off.ensure(((size_t)n + 1) * 8))) return r;
+    if ((r = c->b_frame_len.ensure((size_t)n * 4))) return r;
+    if ((r = c->b_out_off.ensure(((size_t)n + 1) * 8))) return r;
+    if ((r = c->b_slots.ensure(acc))) return r;
+    HIPCHK(hipMemcpyAsync(c->b_slot_off.p, slot_off.data(), ((size_t)n + 1) * 8, hipMemcpyHostToDevice,
+                          c->stream));
+    HIPCHK(hipMemsetAsync(c->b_frame_len.p, 0, (size_t)n * 4, c->stream));
+
+    // persistent compressor waves, one private workspace each
+    u32 waves = c->cfg.compress_waves ? c->cfg.compress_waves : (u32)c->num_cu * 8;
+    waves = std::min(waves, n);
+    const size_t ws_each = sqz::workspace_bytes(max_len);
+    // keep the workspace pool within ~96 GiB
+    while (waves > 64 && (u64)waves * ws_each > (96ull << 30)) waves /= 2;
+    if ((r = c->b_ws.ensure((size_t)waves * ws_each + 256))) return r;
+    if ((r = c->b_misc.ensure(256))) return r;
+    HIPCHK(hipMemsetAsync(c->b_misc.p, 0, 256, c->stream));
+
+    HIPCHK(hipEventRecord(c->ev[4], c->stream));
+    {
+        dim3 block(64), grid(waves);
+        hipLaunchKernelGGL(sqz::k_compress_batch, grid, block, 0, c->stream, d_data, (const u64*)c->b_off.p,
+                           (const u32*)c->b_len.p, d_select, n, (u8*)c->b_slots.p,
+                           (const u64*)c->b_slot_off.p, (u32*)c->b_frame_len.p, (u8*)c->b_ws.p,
+                           (u64)ws_each, (u32*)c->b_misc.p /*queue*/, (u32*)c->b_misc.p + 16 /*err*/);
+        HIPCHK(hipGetLastError());
+    }
+    HIPCHK(hipEventRecord(c->ev[5], c->stream));
+    hipLaunchKernelGGL(sqd::k_scan_lengths, dim3(1), dim3(1024), 0, c->stream, (const u32*)c->b_frame_len.p,
+                       n, (u64*)c->b_out_off.p);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(h_comp_off, c->b_out_off.p, ((size_t)n + 1) * 8, hipMemcpyDeviceToHost,
+                          c->stream));
+    u32* h_err = (u32*)c->h_pinned;
+    HIPCHK(hipMemcpyAsync(h_err, (u32*)c->b_misc.p + 16, 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    HIPCHK(hipEventElapsedTime(&c->last.compress_ms, c->ev[4], c->ev[5]));
+    if (*h_err) return SQ_E_COMPRESS;
+    if (h_comp_off[n] > comp_cap) return SQ_E_CAP;
+    HIPCHK(hipEventRecord(c->ev[6], c->stream));
+    {
+        const u32 wpb = 4;
+        dim3 grid((n + wpb - 1) / wpb), block(64 * wpb);
+        hipLaunchKernelGGL(sqd::k_compact_frames, grid, block, 0, c->stream, (const u8*)c->b_slots.p,
+                           (const u64*)c->b_slot_off.p, (const u32*)c->b_frame_len.p,
+                           (const u64*)c->b_out_off.p, n, d_comp);
+        HIPCHK(hipGetLastError());
+    }
+    HIPCHK(hipEventRecord(c->ev[7], c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    HIPCHK(hipEventElapsedTime(&c->last.compact_ms, c->ev[6], c->ev[7]));
+    return SQ_OK;
+}
+#endif
+
+int sq_compress_batch(sq_ctx* c, const uint8_t* d_data, const uint64_t* h_off, const uint32_t* h_len,
+                      uint32_t n, const uint8_t* d_select, uint8_t* d_comp, uint64_t comp_cap,
+                      uint64_t* h_comp_off) {
+#ifdef SQ_NO_COMPRESS
+    (void)c; (void)d_data; (void)h_off; (void)h_len; (void)n; (void)d_select; (void)d_comp;
+    (void)comp_cap; (void)h_comp_off;
+    return SQ_E_COMPRESS;
+#else
+    if (!c || !h_comp_off || (n && (!d_data || !h_off || !h_len || !d_comp))) return SQ_E_INVAL;
+    HIPCHK(hipSetDevice(c->device));
+    int r;
+    if ((r = upload_off_len(c, h_off, h_len, n))) return r;
+    return compress_async(c, d_data, h_off, h_len, n, d_select, d_comp, comp_cap, h_comp_off);
+#endif
+}
+
+int sq_pack_batch(sq_ctx* c, const uint8_t* data, const uint64_t* off, const uint32_t* len, uint32_t n,
+                  uint8_t* hashes, uint8_t* is_new, uint8_t* comp, uint64_t comp_cap,
+                  uint64_t* comp_off) {
+#ifdef SQ_NO_COMPRESS
+    (void)c; (void)data; (void)off; (void)len; (void)n; (void)hashes; (void)is_new; (void)comp;
+    (void)comp_cap; (void)comp_off;
+    return SQ_E_COMPRESS;
+#else
+    if (!c || !comp_off || (n && (!data || !off || !len || !hashes || !is_new || !comp))) return SQ_E_INVAL;
+    HIPCHK(hipSetDevice(c->device));
+    if (n == 0) {
+        comp_off[0] = 0;
+        return SQ_OK;
+    }
+    const bool dev = is_device_ptr(data);
+    int r;
+    const u8* d_data = data;
+    u8 *d_hashes = hashes, *d_isnew = is_new, *d_comp = comp;
+    std::vector<u64> off2;
+    const u64* use_off = off;
+    if (!dev) {
+        // stage: pack chunks at 256-byte aligned offsets into the ctx's input buffer
+        off2.resize(n);
+        u64 acc = 0;
+        for (u32 i = 0; i < n; i++) {
+            off2[i] = acc;
+            acc += ((u64)len[i] + 255) & ~(u64)255;
+        }
+        if ((r = c->b_stage_in.ensure(acc + 256))) return r;
+        if ((r = c->b_hashes.ensure((size_t)n * 16))) return r;
+        if ((r = c->b_isnew.ensure(n))) return r;
+        if ((r = c->b_stage_out.ensure(comp_cap))) return r;
+        for (u32 i = 0; i < n; i++)
+            HIPCHK(hipMemcpyAsync((u8*)c->b_stage_in.p + off2[i], data + off[i], len[i],
+                                  hipMemcpyHostToDevice, c->stream));
+        d_data = (const u8*)c->b_stage_in.p;
+        d_hashes = (u8*)c->b_hashes.p;
+        d_isnew = (u8*)c->b_isnew.p;
+        d_comp = (u8*)c->b_stage_out.p;
+        use_off = off2.data();
+    }
+    if ((r = upload_off_len(c, use_off, len, n))) return r;
+    if ((r = launch_hash(c, d_data, n, d_hashes))) return r;
+    const u64 seen_before = c->n_seen;
+    if ((r = dedup_async(c, d_hashes, n, 0, n, d_isnew))) return r;
+    r = compress_async(c, d_data, use_off, len, n, d_isnew, d_comp, comp_cap, comp_off);
+    (void)seen_before;
+    if (r) return r;
+    HIPCHK(hipEventElapsedTime(&c->last.hash_ms, c->ev[0], c->ev[1]));
+    HIPCHK(hipEventElapsedTime(&c->last.dedup_ms, c->ev[2], c->ev[3]));
+    if (!dev) {
+        HIPCHK(hipMemcpyAsync(hashes, d_hashes, (size_t)n * 16, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipMemcpyAsync(is_new, d_isnew, n, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipMemcpyAsync(comp, d_comp, comp_off[n], hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(hipStreamSynchronize(c->stream));
+    }
+    return SQ_OK;
+#endif
+}
+
+// ---- stateless convenience forms --------------------------------------------------------------
+static sq_ctx* g_default_ctx = nullptr;
+static int default_ctx(sq_ctx** out) {
+    if (!g_default_ctx) {
+        sq_config cfg;
+        memset(&cfg, 0, sizeof(cfg));
+        cfg.abi_version = SQ_ABI_VERSION;
+        cfg.dedup_capacity = 1024;
+        cfg.compress_waves = 1;
+        int r = sq_ctx_create(&cfg, &g_default_ctx);
+        if (r) return r;
+    }
+    *out = g_default_ctx;
+    return SQ_OK;
+}
+
+int sq_hash_chunk(const uint8_t* chunk, size_t len, uint8_t out[SQ_HASH_BYTES]) {
+    if ((!chunk && len) || !out || len > SQ_CHUNK_SIZE) return SQ_E_INVAL;
+    sq_ctx* c;
+    int r = default_ctx(&c);
+    if (r) return r;
+    HIPCHK(hipSetDevice(c->device));
+    if ((r = c->b_stage_in.ensure(len + 256))) return r;
+    if ((r = c->b_hashes.ensure(16))) return r;
+    if (len) HIPCHK(hipMemcpyAsync(c->b_stage_in.p, chunk, len, hipMemcpyHostToDevice, c->stream));
+    u64 off = 0;
+    u32 l32 = (u32)len;
+    if ((r = sq_hash_batch(c, (const u8*)c->b_stage_in.p, &off, &l32, 1, (u8*)c->b_hashes.p))) return r;
+    HIPCHK(hipMemcpy(out, c->b_hashes.p, 16, hipMemcpyDeviceToHost));
+    return SQ_OK;
+}
+
+int sq_compress_chunk(const uint8_t* chunk, size_t len, uint8_t* dst, size_t cap, size_t* out_len) {
+#ifdef SQ_NO_COMPRESS
+    (void)chunk; (void)len; (void)dst; (void)cap; (void)out_len;
+    return SQ_E_COMPRESS;
+#else
+    if ((!chunk && len) || !dst || !out_len || len > SQ_CHUNK_SIZE) return SQ_E_INVAL;
+    sq_ctx* c;
+    int r = default_ctx(&c);
+    if (r) return r;
+    HIPCHK(hipSetDevice(c->device));
+    const size_t bound = sq_compress_bound(len) + 64;
+    if ((r = c->b_stage_in.ensure(len + 256))) return r;
+    if ((r = c->b_stage_out.ensure(bound))) return r;
+    if (len) HIPCHK(hipMemcpyAsync(c->b_stage_in.p, chunk, len, hipMemcpyHostToDevice, c->stream));
+    u64 off = 0, coff[2] = {0, 0};
+    u32 l32 = (u32)len;
+    if ((r = sq_compress_batch(c, (const u8*)c->b_stage_in.p, &off, &l32, 1, nullptr,
+                               (u8*)c->b_stage_out.p, bound, coff)))
+        return r;
+    if (coff[1] > cap) return SQ_E_CAP;
+    HIPCHK(hipMemcpy(dst, c->b_stage_out.p, coff[1], hipMemcpyDeviceToHost));
+    *out_len = (size_t)coff[1];
+    return SQ_OK;
+#endif
+}
+
+} // extern "C"
