@@ -1,0 +1,290 @@
+// sq_wave.h -- wavefront-level primitives for the one-wavefront-per-chunk zstd compressor.
+//
+// Execution model: a workgroup is ONE wave of 64 lanes and owns one chunk.  Control flow is
+// wave-uniform: every lane executes the same "scalar" program on the same values (uniform loads
+// broadcast one address; single-lane stores publish), and the 64 lanes are used as a vector unit
+// by the primitives in this file: match-length extension, 64-entry tag-row compare, batched hash
+// insertion with in-wave conflict ranking, LDS histograms, coalesced copies/fills, bit-stream
+// packing with wavefront prefix scans.
+//
+// The same source also builds with -DSQ_SIM for the host: every primitive then has a plain
+// scalar body with identical semantics.  That build exists ONLY for tests/ (a CPU-side simulator
+// to debug the uniform control logic where there is no GPU); it is never linked into
+// libsquish_gpu.so and is not a fallback.
+#pragma once
+#include "sq_common.h"
+
+#if SQ_ON_DEVICE
+#define SQ_LDS __shared__
+#define SQ_NOINLINE __device__ __noinline__
+SQ_DEV u32 wv_lane() { return __lane_id(); }
+SQ_DEV u32 wv_uni(u32 v) { return (u32)__builtin_amdgcn_readfirstlane((int)v); }
+SQ_DEV u64 wv_uni64(u64 v) {
+    u32 lo = wv_uni((u32)v), hi = wv_uni((u32)(v >> 32));
+    return ((u64)hi << 32) | lo;
+}
+SQ_DEV u64 wv_ballot(bool p) { return __ballot(p); }
+SQ_DEV u32 wv_readlane(u32 v, u32 l) { return (u32)__builtin_amdgcn_readlane((int)v, (int)l); }
+SQ_DEV u64 wv_readlane64(u64 v, u32 l) {
+    return ((u64)wv_readlane((u32)(v >> 32), l) << 32) | wv_readlane((u32)v, l);
+}
+// order LDS / global accesses made by different lanes of this wave (compiler-level only: one
+// wave executes its memory instructions in program order)
+SQ_DEV void wv_fence() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); }
+#else
+#define SQ_LDS static thread_local
+#define SQ_NOINLINE static __attribute__((noinline))
+SQ_DEV u32 wv_uni(u32 v) { return v; }
+SQ_DEV u64 wv_uni64(u64 v) { return v; }
+SQ_DEV void wv_fence() {}
+#endif
+
+// A serial region: plain scalar code run by lane 0 only while the other lanes idle at the
+// reconvergence point.  No wave primitive may be called inside.  Results leave through LDS /
+// global memory (followed by wv_fence()) or through wv_uni() of a lane-0 register.
+#if SQ_ON_DEVICE
+#define WV_SERIAL if (wv_lane() == 0)
+#else
+#define WV_SERIAL if (1)
+#endif
+
+// ---- uniform global memory access: all lanes read one address; lane 0 alone writes ------------
+SQ_DEV u32 gld32(const u32* p) {
+#if SQ_ON_DEVICE
+    return wv_uni(*p);
+#else
+    return *p;
+#endif
+}
+SQ_DEV u32 gld8(const u8* p) {
+#if SQ_ON_DEVICE
+    return wv_uni(*p);
+#else
+    return *p;
+#endif
+}
+SQ_DEV u32 gld16(const u16* p) {
+#if SQ_ON_DEVICE
+    return wv_uni(*p);
+#else
+    return *p;
+#endif
+}
+SQ_DEV void gst32(u32* p, u32 v) {
+#if SQ_ON_DEVICE
+    if (wv_lane() == 0) *p = v;
+#else
+    *p = v;
+#endif
+}
+SQ_DEV void gst16(u16* p, u32 v) {
+#if SQ_ON_DEVICE
+    if (wv_lane() == 0) *p = (u16)v;
+#else
+    *p = (u16)v;
+#endif
+}
+SQ_DEV void gst8(u8* p, u32 v) {
+#if SQ_ON_DEVICE
+    if (wv_lane() == 0) *p = (u8)v;
+#else
+    *p = (u8)v;
+#endif
+}
+// uniform unaligned source reads (chunk bytes are never written by the kernel)
+SQ_DEV u32 srd32(const u8* p) { return wv_uni(sq_rd32(p)); }
+SQ_DEV u64 srd64(const u8* p) { return wv_uni64(sq_rd64(p)); }
+SQ_DEV u32 srd16(const u8* p) { return wv_uni(sq_rd16(p)); }
+SQ_DEV u32 srd8(const u8* p) { return wv_uni(*p); }
+
+// ---- wv_count: length of the common prefix of a[0..maxLen) and b[..] (ZSTD_count) -------------
+SQ_DEV u32 wv_count(const u8* a, const u8* b, u32 maxLen) {
+#if SQ_ON_DEVICE
+    const u32 lane = wv_lane();
+    // fast uniform probe of the first 8 bytes: most candidates die here
+    if (maxLen >= 8) {
+        u64 x = srd64(a) ^ srd64(b);
+        if (x) return (u32)(__builtin_ctzll(x) >> 3);
+    }
+    for (u32 base = 0; base < maxLen; base += 512) {
+        const u32 o = base + lane * 8;
+        u64 x;
+        if (o + 8 <= maxLen) {
+            x = sq_rd64(a + o) ^ sq_rd64(b + o);
+        } else if (o < maxLen) {
+            const u32 valid = maxLen - o; // 1..7
+            x = 0;
+            for (u32 k = 0; k < valid; k++) x |= (u64)(u8)(a[o + k] ^ b[o + k]) << (8 * k);
+            x |= 1ull << (8 * valid); // stop at the limit
+        } else {
+            x = 1; // beyond the limit
+        }
+        const u64 m = wv_ballot(x != 0);
+        if (m) {
+            const u32 first = (u32)__builtin_ctzll(m);
+            const u64 xv = wv_readlane64(x, first);
+            u32 r = base + first * 8 + (u32)(__builtin_ctzll(xv) >> 3);
+            return r < maxLen ? r : maxLen;
+        }
+    }
+    return maxLen;
+#else
+    u32 n = 0;
+    while (n < maxLen && a[n] == b[n]) n++;
+    return n;
+#endif
+}
+
+// ---- coalesced fill / copy / compare ---------------------------------------------------------
+SQ_DEV void wv_fill32(u32* dst, u32 v, size_t nwords) { // dst 16-byte aligned, nwords % 4 == 0
+#if SQ_ON_DEVICE
+    uint4 q = make_uint4(v, v, v, v);
+    uint4* d = (uint4*)dst;
+    const size_t n16 = nwords / 4;
+    for (size_t i = wv_lane(); i < n16; i += 64) d[i] = q;
+#else
+    for (size_t i = 0; i < nwords; i++) dst[i] = v;
+#endif
+}
+SQ_DEV void wv_memcpy(u8* dst, const u8* src, u32 n) {
+#if SQ_ON_DEVICE
+    const u32 lane = wv_lane();
+    u32 pos = lane * 16;
+    for (; pos + 16 <= n; pos += 1024) {
+        uint4 v;
+        __builtin_memcpy(&v, src + pos, 16);
+        __builtin_memcpy(dst + pos, &v, 16);
+    }
+    if (pos < n)
+        for (u32 k = pos; k < n; k++) dst[k] = src[k]; // the single partial lane
+    wv_fence();
+#else
+    memcpy(dst, src, n);
+#endif
+}
+// 1 if all n bytes equal src[0] (ZSTD_isRLE); n >= 1
+SQ_DEV u32 wv_is_rle(const u8* src, u32 n) {
+#if SQ_ON_DEVICE
+    const u32 b0 = srd8(src);
+    const u64 pat = 0x0101010101010101ull * b0;
+    bool bad = false;
+    u32 pos = wv_lane() * 8;
+    for (; pos + 8 <= n; pos += 512) bad |= (sq_rd64(src + pos) != pat);
+    if (pos < n)
+        for (u32 k = pos; k < n; k++) bad |= (src[k] != (u8)b0);
+    return wv_ballot(bad) == 0;
+#else
+    for (u32 i = 1; i < n; i++)
+        if (src[i] != src[0]) return 0;
+    return 1;
+#endif
+}
+
+// ---- byte histogram into count[0..255] (u32, LDS) ----------------------------------------------
+// Returns nothing; count must be zeroed by the caller via wv_zero_lds.
+SQ_DEV void wv_zero_lds(u32* p, u32 nwords) {
+#if SQ_ON_DEVICE
+    for (u32 i = wv_lane(); i < nwords; i += 64) p[i] = 0;
+    wv_fence();
+#else
+    for (u32 i = 0; i < nwords; i++) p[i] = 0;
+#endif
+}
+SQ_DEV void wv_hist_bytes(u32* count /*LDS*/, const u8* src, u32 n) {
+#if SQ_ON_DEVICE
+    const u32 lane = wv_lane();
+    u32 pos = lane * 4;
+    for (; pos + 4 <= n; pos += 256) {
+        u32 w = sq_rd32(src + pos);
+        atomicAdd(&count[w & 0xFF], 1u);
+        atomicAdd(&count[(w >> 8) & 0xFF], 1u);
+        atomicAdd(&count[(w >> 16) & 0xFF], 1u);
+        atomicAdd(&count[w >> 24], 1u);
+    }
+    if (pos < n)
+        for (u32 k = pos; k < n; k++) atomicAdd(&count[src[k]], 1u);
+    wv_fence();
+#else
+    for (u32 i = 0; i < n; i++) count[src[i]]++;
+#endif
+}
+// max over p[0..n) and index of the last nonzero entry (n <= 256); uniform results
+SQ_DEV void wv_max_and_last(const u32* p /*LDS*/, u32 n, u32* maxOut, u32* lastNonZero) {
+#if SQ_ON_DEVICE
+    const u32 lane = wv_lane();
+    u32 mx = 0, last = 0;
+    for (u32 i = lane; i < n; i += 64) {
+        u32 v = p[i];
+        mx = v > mx ? v : mx;
+        if (v) last = i;
+    }
+    for (int m = 32; m >= 1; m >>= 1) {
+        u32 o = (u32)__shfl_xor((int)mx, m, 64);
+        mx = o > mx ? o : mx;
+        u32 l2 = (u32)__shfl_xor((int)last, m, 64);
+        last = l2 > last ? l2 : last;
+    }
+    *maxOut = wv_uni(mx);
+    *lastNonZero = wv_uni(last);
+#else
+    u32 mx = 0, last = 0;
+    for (u32 i = 0; i < n; i++) {
+        if (p[i] > mx) mx = p[i];
+        if (p[i]) last = i;
+    }
+    *maxOut = mx;
+    *lastNonZero = last;
+#endif
+}
+
+// ---- in-wave grouping of equal keys -------------------------------------------------------------
+// Each active lane holds `key`.  Returns for the calling lane: rank = number of lower active lanes
+// with the same key, gsize = group size, prevLane = closest lower lane of the group (or 64).
+// `scratch` = 2048-byte LDS table private to the wave.
+#if SQ_ON_DEVICE
+struct WvGroup {
+    u32 rank, gsize, prevLane;
+};
+SQ_DEV WvGroup wv_group(u32 key, bool active, u8* scratch /*LDS 2048 B*/) {
+    const u32 lane = wv_lane();
+    WvGroup g;
+    g.rank = 0;
+    g.gsize = 1;
+    g.prevLane = 64;
+    const u32 slot = (key * 2654435761u) >> 21; // 11 bits
+    if (active) scratch[slot] = (u8)lane;
+    wv_fence();
+    bool loser = active && (scratch[slot] != (u8)lane);
+    u64 todo = wv_ballot(loser);
+    const u64 act = wv_ballot(active);
+    const u64 below = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+    while (todo) {
+        const u32 l = (u32)__builtin_ctzll(todo);
+        const u32 k = wv_readlane(key, l);
+        const u64 m = wv_ballot(active && key == k) & act;
+        if (active && key == k) {
+            const u64 lower = m & below;
+            g.rank = (u32)__popcll(lower);
+            g.gsize = (u32)__popcll(m);
+            g.prevLane = lower ? (63u - (u32)__builtin_clzll(lower)) : 64u;
+        }
+        todo &= ~m;
+    }
+    wv_fence();
+    return g;
+}
+#endif
+
+// exclusive prefix sum over lanes of a u32 (device only); returns (exclusive, total)
+#if SQ_ON_DEVICE
+SQ_DEV u32 wv_excl_scan(u32 v, u32* total) {
+    u32 x = v;
+    const u32 lane = wv_lane();
+    for (int d = 1; d < 64; d <<= 1) {
+        u32 y = (u32)__shfl_up((int)x, d, 64);
+        if (lane >= (u32)d) x += y;
+    }
+    *total = wv_readlane(x, 63);
+    return x - v;
+}
+#endif

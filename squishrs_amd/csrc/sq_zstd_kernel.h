@@ -1,0 +1,413 @@
+// sq_zstd_kernel.h -- zstd level-12 frame compressor kernel for gfx950: one wavefront per chunk,
+// persistent waves pulling chunk indices from a device work queue.
+//
+// Replaces (bit-exact) the call at /root/reference/src/util/chunk.rs:89-90
+//     compress(chunk, COMPRESSION_LEVEL)        // zstd::bulk::compress(chunk, 12), libzstd 1.5.7
+// i.e. one self-contained zstd frame per chunk from a fresh context: magic, single-segment frame
+// header with content size, <=128 KiB blocks (1.5.7 pre-block splitter), no checksum.
+//
+// HBM layout: each wave owns one workspace (ws_layout): hash table, chain/tag table, 3-byte hash
+// table (btopt), sequence store (sequences, literals, code bytes), btopt tables, pre-split
+// fingerprints.  Entropy tables and statistics live in LDS (sq_zstd_entropy.h).  Frames are
+// written straight into per-chunk output slots.
+#pragma once
+#include "sq_zstd_opt.h"
+
+namespace sqz {
+
+#define SQZ_BLOCKSIZE_MAX (128u << 10)
+#define SQZ_MAX_NBSEQ (SQZ_BLOCKSIZE_MAX / 3 + 2)
+
+struct Fingerprint {
+    u32 events[1024];
+    u32 nbEvents;
+    u32 pad[3];
+};
+
+struct WsLayout {
+    size_t hashTable, table2, hashTable3, seqs, lits, llCode, ofCode, mlCode, optState, fp, dummy, total;
+};
+
+#if SQ_ON_DEVICE
+#define SQ_HD __host__ __device__ inline
+#else
+#define SQ_HD static inline
+#endif
+
+SQ_HD size_t ws_align(size_t x) { return (x + 255) & ~(size_t)255; }
+
+SQ_HD WsLayout ws_layout(u32 max_len) {
+    // table areas sized for the largest parameters of any chunk length <= max_len
+    size_t hashBytes = 0, t2Bytes = 0;
+    const u32 bps[9] = {16u << 10, 32u << 10, 64u << 10, 128u << 10, 256u << 10, 512u << 10, 1u << 20, 2u << 20, max_len};
+    for (int i = 0; i < 9; i++) {
+        u32 n = bps[i] < max_len ? bps[i] : max_len;
+        if (n == 0) n = 1;
+        // get_cparams, restated for host+device use
+        u32 hashLog, chainLog, strategy;
+        if (n <= (16u << 10)) {
+            u32 w = 0;
+            while ((1u << w) < n) w++;
+            chainLog = (w + 1 < 7) ? 7 : w + 1;
+            hashLog = chainLog > 14 ? 14 : chainLog;
+            strategy = 7;
+        } else if (n <= (256u << 10)) {
+            u32 w = 15;
+            while ((1u << w) < n) w++;
+            chainLog = w + 1;
+            hashLog = (w == 17) ? 17 : w + 1;
+            strategy = 6;
+        } else {
+            u32 w = 19;
+            while ((1u << w) < n && w < 21) w++;
+            chainLog = w;
+            hashLog = w + 1;
+            strategy = 5;
+        }
+        size_t hb = ((size_t)4) << hashLog;
+        size_t tb = (strategy == 5) ? ((size_t)1 << hashLog) : (((size_t)4) << chainLog);
+        if (hb > hashBytes) hashBytes = hb;
+        if (tb > t2Bytes) t2Bytes = tb;
+    }
+    WsLayout L;
+    size_t o = 0;
+    L.hashTable = o;
+    o += ws_align(hashBytes);
+    L.table2 = o;
+    o += ws_align(t2Bytes);
+    L.hashTable3 = o;
+    o += ws_align((size_t)4 << 14);
+    L.seqs = o;
+    o += ws_align((size_t)SQZ_MAX_NBSEQ * 8);
+    L.lits = o;
+    o += ws_align(SQZ_BLOCKSIZE_MAX + 64);
+    L.llCode = o;
+    o += ws_align(SQZ_MAX_NBSEQ);
+    L.ofCode = o;
+    o += ws_align(SQZ_MAX_NBSEQ);
+    L.mlCode = o;
+    o += ws_align(SQZ_MAX_NBSEQ);
+    L.optState = o;
+    o += ws_align(sizeof(opt::optstate));
+    L.fp = o;
+    o += ws_align(2 * sizeof(Fingerprint));
+    L.dummy = o;
+    o += 256;
+    L.total = o;
+    return L;
+}
+SQ_HD size_t workspace_bytes(u32 max_len) { return ws_layout(max_len).total; }
+
+// ---------------------------------------------------------------- pre-block splitter (1.5.7)
+SQ_DEV u32 ps_hash2_10(const u8* p) { return ((u32)sq_rd16(p) * 0x9e3779b9U) >> 22; }
+
+// recordFingerprint_generic(samplingRate 5, hashLog 10) over 8 KiB
+SQ_DEV void ps_record(Fingerprint* fp, const u8* src) {
+    const u32 limit = 8192 - 2 + 1;
+#if SQ_ON_DEVICE
+    const u32 lane = wv_lane();
+    for (u32 i = lane; i < 1024; i += 64) fp->events[i] = 0;
+    wv_fence();
+    for (u32 n = lane * 5; n < limit; n += 64 * 5) atomicAdd(&fp->events[ps_hash2_10(src + n)], 1u);
+    if (lane == 0) fp->nbEvents = limit / 5;
+    wv_fence();
+#else
+    for (u32 i = 0; i < 1024; i++) fp->events[i] = 0;
+    for (u32 n = 0; n < limit; n += 5) fp->events[ps_hash2_10(src + n)]++;
+    fp->nbEvents = limit / 5;
+#endif
+}
+// compareFingerprints: 1 when "too different"
+SQ_DEV u32 ps_compare(const Fingerprint* ref, const Fingerprint* nw, int penalty) {
+    u64 distance = 0;
+    const s64 nbA = (s64)gld32(&ref->nbEvents), nbB = (s64)gld32(&nw->nbEvents);
+#if SQ_ON_DEVICE
+    for (u32 n = wv_lane(); n < 1024; n += 64) {
+        s64 d = (s64)ref->events[n] * nbB - (s64)nw->events[n] * nbA;
+        distance += (u64)(d < 0 ? -d : d);
+    }
+    for (int m = 32; m >= 1; m >>= 1) {
+        u32 lo = (u32)__shfl_xor((int)(u32)distance, m, 64);
+        u32 hi = (u32)__shfl_xor((int)(u32)(distance >> 32), m, 64);
+        distance += ((u64)hi << 32) | lo;
+    }
+    distance = wv_uni64(distance);
+#else
+    for (u32 n = 0; n < 1024; n++) {
+        s64 d = (s64)ref->events[n] * nbB - (s64)nw->events[n] * nbA;
+        distance += (u64)(d < 0 ? -d : d);
+    }
+#endif
+    u64 const p50 = (u64)nbA * (u64)nbB;
+    u64 const threshold = p50 * (u64)(16 - 2 + penalty) / 16;
+    return distance >= threshold;
+}
+SQ_DEV void ps_merge(Fingerprint* acc, const Fingerprint* nw) {
+#if SQ_ON_DEVICE
+    const u32 lane = wv_lane();
+    for (u32 n = lane; n < 1024; n += 64) acc->events[n] += nw->events[n];
+    if (lane == 0) acc->nbEvents += nw->nbEvents;
+    wv_fence();
+#else
+    for (u32 n = 0; n < 1024; n++) acc->events[n] += nw->events[n];
+    acc->nbEvents += nw->nbEvents;
+#endif
+}
+// ZSTD_splitBlock_byChunks(level 2) on a full 128 KiB block
+SQ_DEVFN u32 splitBlock_byChunks(const u8* p, Fingerprint* fps) {
+    Fingerprint* const past = fps;
+    Fingerprint* const nw = fps + 1;
+    int penalty = 3;
+    ps_record(past, p);
+    for (u32 pos = 8192; pos <= SQZ_BLOCKSIZE_MAX - 8192; pos += 8192) {
+        ps_record(nw, p + pos);
+        if (ps_compare(past, nw, penalty)) return pos;
+        ps_merge(past, nw);
+        if (penalty > 0) penalty--;
+    }
+    return SQZ_BLOCKSIZE_MAX;
+}
+// ZSTD_optimalBlockSize for strategies lazy2 / btlazy2 (split level 3) / btopt (never >= 128 KiB)
+SQ_DEV u32 optimalBlockSize(const u8* src, u32 srcSize, s64 savings, Fingerprint* fps) {
+    if (srcSize < SQZ_BLOCKSIZE_MAX) return srcSize;
+    if (savings < 3) return SQZ_BLOCKSIZE_MAX;
+    return splitBlock_byChunks(src, fps);
+}
+
+// ---------------------------------------------------------------- one frame, one wave
+struct BlockState { // entropy tables are g_lds.ent[idx]
+    u32 rep[2][SQZ_REP_NUM];
+    u32 prevIdx;
+    u32 isFirstBlock;
+};
+
+// ZSTD_buildSeqStore + ZSTD_compressBlock_internal: returns body size; 0 => raw; 1 => RLE
+SQ_DEVFN u32 compressBlock_internal(MatchState& ms, SeqStore& ss, BlockState& bs, void* optState, u8* dst,
+                                    u32 dstCap, const u8* src, u32 srcSize) {
+    u32 const p = bs.prevIdx, nx = p ^ 1;
+    u32 cSize;
+    if (srcSize < 1 + 1 + 3 + 1 + 1) { // ZSTDbss_noCompress
+        cSize = 0;
+    } else {
+        ss.nseq = 0;
+        ss.nlits = 0;
+        ss.longLengthType = 0;
+        ss.longLengthPos = 0;
+        {
+            u32 const curr = (u32)(src - ms.base);
+            if (curr > ms.nextToUpdate + 384) {
+                u32 const d = curr - ms.nextToUpdate - 384;
+                ms.nextToUpdate = curr - (192 < d ? 192 : d);
+            }
+        }
+        for (int i = 0; i < SQZ_REP_NUM; ++i) bs.rep[nx][i] = bs.rep[p][i];
+        u32 lastLLSize;
+        if (ms.cp.strategy == STRAT_LAZY2) {
+            lastLLSize = compressBlock_lazy<1>(ms, ss, bs.rep[nx], src, srcSize);
+        } else if (ms.cp.strategy == STRAT_BTLAZY2) {
+            lastLLSize = compressBlock_lazy<0>(ms, ss, bs.rep[nx], src, srcSize);
+        } else {
+            // btopt: the whole parse is one serial region on lane 0
+            u32 r0 = bs.rep[nx][0], r1 = bs.rep[nx][1], r2 = bs.rep[nx][2];
+            WV_SERIAL {
+                opt::mstate om;
+                om.base = ms.base;
+                om.nextToUpdate = ms.nextToUpdate;
+                om.hashTable = ms.hashTable;
+                om.chainTable = ms.chainTable;
+                om.hashTable3 = ms.hashTable3;
+                om.hashLog3 = ms.hashLog3;
+                om.cp = ms.cp;
+                om.opt = optState;
+                opt::seqstore os;
+                os.seqs = ss.seqs;
+                os.lits = ss.lits;
+                os.nseq = 0;
+                os.nlits = 0;
+                os.longLengthType = 0;
+                os.longLengthPos = 0;
+                u32 rr[3] = {r0, r1, r2};
+                u32 const last = (u32)opt::compressBlock_btopt(&om, &os, rr, src, srcSize);
+                g_lds.ret[0] = last;
+                g_lds.ret[1] = os.nseq;
+                g_lds.ret[2] = os.nlits;
+                g_lds.ret[3] = os.longLengthType;
+                g_lds.ret[4] = os.longLengthPos;
+                g_lds.ret[5] = rr[0];
+                g_lds.ret[6] = rr[1];
+                g_lds.ret[7] = rr[2];
+            }
+            wv_fence();
+            lastLLSize = g_lds.ret[0];
+            ss.nseq = g_lds.ret[1];
+            ss.nlits = g_lds.ret[2];
+            ss.longLengthType = g_lds.ret[3];
+            ss.longLengthPos = g_lds.ret[4];
+            bs.rep[nx][0] = g_lds.ret[5];
+            bs.rep[nx][1] = g_lds.ret[6];
+            bs.rep[nx][2] = g_lds.ret[7];
+            wv_fence();
+        }
+        if (lastLLSize) wv_memcpy(ss.lits + ss.nlits, src + srcSize - lastLLSize, lastLLSize);
+        ss.nlits += lastLLSize;
+        cSize = entropy_compress_seqstore(ss, &g_lds.ent[p], &g_lds.ent[nx], ms.cp.strategy, dst, dstCap, srcSize);
+        if (is_err(cSize)) return cSize;
+        if (!bs.isFirstBlock && cSize < 25 && wv_is_rle(src, srcSize)) {
+            cSize = 1;
+            gst8(dst, srd8(src));
+        }
+    }
+    if (cSize > 1) bs.prevIdx ^= 1; // ZSTD_blockState_confirmRepcodesAndEntropyTables
+    // offcode_repeatMode valid -> check: REP_VALID never occurs without a dictionary
+    return cSize;
+}
+
+// Returns the frame length, 0 on error.
+SQ_DEVFN u32 compress_frame_wave(const u8* src, u32 n, u8* dst, u32 cap, u8* ws, const WsLayout& L) {
+    MatchState ms;
+    SeqStore ss;
+    BlockState bs;
+    CParams const cp = get_cparams(n);
+    u8* op = dst;
+    u8* const oend = dst + cap;
+    if (cap < 18) return 0;
+    // ---- frame header (ZSTD_writeFrameHeader)
+    u32 const fcsCode = (n >= 256) + (n >= 65536 + 256);
+    u32 hdr;
+    WV_SERIAL {
+        dst[0] = 0x28;
+        dst[1] = 0xB5;
+        dst[2] = 0x2F;
+        dst[3] = 0xFD;
+        dst[4] = (u8)((fcsCode << 6) + (1 << 5));
+        if (fcsCode == 0)
+            dst[5] = (u8)n;
+        else if (fcsCode == 1) {
+            u32 v = n - 256;
+            dst[5] = (u8)v;
+            dst[6] = (u8)(v >> 8);
+        } else {
+            dst[5] = (u8)n;
+            dst[6] = (u8)(n >> 8);
+            dst[7] = (u8)(n >> 16);
+            dst[8] = (u8)(n >> 24);
+        }
+    }
+    hdr = 5 + (fcsCode == 0 ? 1 : (fcsCode == 1 ? 2 : 4));
+    op += hdr;
+    // ---- fresh context
+    ms.cp = cp;
+    ms.base = src - SQZ_WINDOW_START;
+    ms.nextToUpdate = SQZ_WINDOW_START;
+    ms.lazySkipping = 0;
+    ms.hashTable = (u32*)(ws + L.hashTable);
+    ms.chainTable = (u32*)(ws + L.table2);
+    ms.tagTable = ws + L.table2;
+    ms.hashTable3 = (u32*)(ws + L.hashTable3);
+    ms.dummy = (u32*)(ws + L.dummy);
+    ms.hashLog3 = 0;
+    ms.rowHashLog = 0;
+    wv_fill32(ms.hashTable, 0, (size_t)1 << cp.hashLog);
+    if (cp.strategy == STRAT_LAZY2) {
+        ms.rowHashLog = cp.hashLog - 6;
+    } else if (cp.strategy == STRAT_BTOPT) {
+        ms.hashLog3 = cp.windowLog < 17 ? cp.windowLog : 17;
+        wv_fill32(ms.hashTable3, 0, (size_t)1 << ms.hashLog3);
+        // optstate: only litLengthSum == 0 matters for the first (only) block
+        WV_SERIAL { ((opt::optstate*)(ws + L.optState))->litLengthSum = 0; }
+    }
+    ss.seqs = (SeqDef*)(ws + L.seqs);
+    ss.lits = ws + L.lits;
+    ss.llCode = ws + L.llCode;
+    ss.ofCode = ws + L.ofCode;
+    ss.mlCode = ws + L.mlCode;
+    ss.nseq = ss.nlits = 0;
+    ss.longLengthType = ss.longLengthPos = 0;
+    WV_SERIAL {
+        entropy_reset(&g_lds.ent[0]);
+        entropy_reset(&g_lds.ent[1]);
+    }
+    for (int k = 0; k < 2; k++) {
+        bs.rep[k][0] = 1;
+        bs.rep[k][1] = 4;
+        bs.rep[k][2] = 8;
+    }
+    bs.prevIdx = 0;
+    bs.isFirstBlock = 1;
+    wv_fence();
+
+    if (n == 0) { // ZSTD_writeLastEmptyBlock
+        WV_SERIAL {
+            op[0] = 1;
+            op[1] = 0;
+            op[2] = 0;
+        }
+        return hdr + 3;
+    }
+    const u8* ip = src;
+    u32 remaining = n;
+    s64 savings = 0;
+    while (remaining) {
+        u32 const blockSize = optimalBlockSize(ip, remaining, savings, (Fingerprint*)(ws + L.fp));
+        u32 const lastBlock = (blockSize == remaining);
+        if ((u32)(oend - op) < 3 + 2 + 1) return 0;
+        if (ms.nextToUpdate < SQZ_WINDOW_START) ms.nextToUpdate = SQZ_WINDOW_START;
+        u32 cSize = compressBlock_internal(ms, ss, bs, ws + L.optState, op + 3, (u32)(oend - op) - 3, ip, blockSize);
+        if (is_err(cSize)) return 0;
+        if (cSize == 0) { // ZSTD_noCompressBlock
+            u32 const h = lastBlock + (0u << 1) + (blockSize << 3);
+            if (blockSize + 3 > (u32)(oend - op)) return 0;
+            WV_SERIAL {
+                op[0] = (u8)h;
+                op[1] = (u8)(h >> 8);
+                op[2] = (u8)(h >> 16);
+            }
+            wv_memcpy(op + 3, ip, blockSize);
+            cSize = 3 + blockSize;
+        } else {
+            u32 const h = (cSize == 1) ? lastBlock + (1u << 1) + (blockSize << 3) : lastBlock + (2u << 1) + (cSize << 3);
+            WV_SERIAL {
+                op[0] = (u8)h;
+                op[1] = (u8)(h >> 8);
+                op[2] = (u8)(h >> 16);
+            }
+            cSize += 3;
+        }
+        savings += (s64)blockSize - (s64)cSize;
+        ip += blockSize;
+        remaining -= blockSize;
+        op += cSize;
+        bs.isFirstBlock = 0;
+    }
+    wv_fence();
+    return (u32)(op - dst);
+}
+
+#if SQ_ON_DEVICE
+// Persistent compressor: grid = number of workspaces, block = one wave.  Each wave pulls chunk
+// indices from *queue until exhausted; every wave reaches the exit condition (idx >= n).
+__global__ void __launch_bounds__(64)
+k_compress_batch(const u8* __restrict__ data, const u64* __restrict__ off, const u32* __restrict__ len,
+                 const u8* __restrict__ select, u32 n, u8* __restrict__ slots, const u64* __restrict__ slot_off,
+                 u32* __restrict__ frame_len, u8* __restrict__ ws_pool, u64 ws_each, u32* __restrict__ queue,
+                 u32* __restrict__ err) {
+    u8* const ws = ws_pool + (u64)blockIdx.x * ws_each;
+    for (;;) {
+        u32 idx = 0;
+        if (threadIdx.x == 0) idx = atomicAdd(queue, 1u);
+        idx = wv_uni(idx);
+        if (idx >= n) break;
+        if (select && !select[idx]) continue;
+        u32 const L = len[idx];
+        WsLayout const lay = ws_layout(L); // offsets for this length are <= the pool's
+        u32 const cap = (u32)(slot_off[idx + 1] - slot_off[idx]);
+        u32 const r = compress_frame_wave(data + off[idx], L, slots + slot_off[idx], cap, ws, lay);
+        if (threadIdx.x == 0) {
+            frame_len[idx] = r;
+            if (r == 0) atomicOr(err, 1u);
+        }
+    }
+}
+#endif
+
+} // namespace sqz

@@ -1,0 +1,598 @@
+// sq_zstd_match.h -- LZ match finders and the lazy parser of zstd level 12 on gfx950, one wave
+// per chunk, bit-exact with libzstd 1.5.7 (reached from /root/reference/src/util/chunk.rs:89-90).
+//
+//   chunk > 256 KiB        : lazy2 + row-hash match finder (ZSTD_RowFindBestMatch, 64-entry rows)
+//   16 KiB < chunk <= 256K : btlazy2, DUBT binary tree (ZSTD_DUBT_findBestMatch)
+//
+// Wave mapping: the parser state machine is wave-uniform; the 64 lanes are spent on
+//   * hash insertion in batches of 64 positions (hash per lane, in-wave ranking of equal
+//     rows/hashes, coalesced bt writes)                       -> dubt_update / row_update
+//   * the 64-entry tag row: one lane per slot, ballot -> candidate mask   -> row_find
+//   * one candidate per lane match-length evaluation          -> row_find
+//   * 8 bytes per lane match extension                        -> wv_count
+// Tables (hash / chain / tag) are in the wave's HBM workspace; see sq_zstd_kernel.h.
+#pragma once
+#include "sq_zstd_entropy.h"
+
+namespace sqz {
+
+#define SQZ_WINDOW_START 2u
+#define SQZ_REP_NUM 3
+#define SQZ_MINMATCH 3
+#define OFFSET_TO_OFFBASE(o) ((o) + SQZ_REP_NUM)
+#define OFFBASE_TO_OFFSET(o) ((o)-SQZ_REP_NUM)
+#define OFFBASE_IS_OFFSET(o) ((o) > SQZ_REP_NUM)
+
+enum { STRAT_LAZY2 = 5, STRAT_BTLAZY2 = 6, STRAT_BTOPT = 7 };
+
+struct CParams {
+    u32 windowLog, chainLog, hashLog, searchLog, minMatch, targetLength, strategy;
+};
+
+// ZSTD_getCParams(12, n) after ZSTD_adjustCParams (table measured on libzstd 1.5.7)
+SQ_DEV CParams get_cparams(u32 n) {
+    CParams p;
+    if (n == 0) n = 1;
+    if (n <= (16u << 10)) {
+        u32 w = 0;
+        while ((1u << w) < n) w++;
+        p.windowLog = w < 10 ? 10 : w;
+        p.chainLog = (w + 1 < 7) ? 7 : w + 1;
+        p.hashLog = p.chainLog > 14 ? 14 : p.chainLog;
+        p.searchLog = 4;
+        p.minMatch = 3;
+        p.targetLength = 24;
+        p.strategy = STRAT_BTOPT;
+    } else if (n <= (256u << 10)) {
+        u32 w = 15;
+        while ((1u << w) < n) w++;
+        p.windowLog = w;
+        p.chainLog = w + 1;
+        p.hashLog = (w == 17) ? 17 : w + 1;
+        p.searchLog = 7;
+        p.minMatch = 4;
+        p.targetLength = 12;
+        p.strategy = STRAT_BTLAZY2;
+    } else {
+        u32 w = 19;
+        while ((1u << w) < n && w < 21) w++;
+        p.windowLog = w;
+        p.chainLog = w;
+        p.hashLog = w + 1;
+        p.searchLog = 6;
+        p.minMatch = 5;
+        p.targetLength = 32;
+        p.strategy = STRAT_LAZY2;
+    }
+    return p;
+}
+
+struct MatchState {
+    const u8* base; // base + index; first source byte has index SQZ_WINDOW_START
+    u32* hashTable;
+    u32* chainTable;
+    u8* tagTable;
+    u32* hashTable3;
+    u32* dummy; // 2 words of scratch in the workspace (the "dummy32" of libzstd)
+    u32 hashLog3;
+    u32 rowHashLog;
+    u32 nextToUpdate;
+    u32 lazySkipping;
+    CParams cp;
+};
+
+SQ_DEV u32 hash4(u32 v, u32 hBits) { return (v * 2654435761U) >> (32 - hBits); }
+SQ_DEV u32 hash5(u64 v, u32 hBits) { return (u32)(((v << 24) * 889523592379ULL) >> (64 - hBits)); }
+SQ_DEV u32 hash3(u32 v, u32 hBits) { return ((v << 8) * 506832829U) >> (32 - hBits); }
+
+// ZSTD_storeSeq: literal run copied by the wave, sequence record by lane 0
+SQ_DEV void storeSeq(SeqStore& ss, u32 litLength, const u8* literals, u32 offBase, u32 matchLength) {
+    if (litLength) wv_memcpy(ss.lits + ss.nlits, literals, litLength);
+    ss.nlits += litLength;
+    if (litLength > 0xFFFF) {
+        ss.longLengthType = 1;
+        ss.longLengthPos = ss.nseq;
+    }
+    u32 const mlBase = matchLength - SQZ_MINMATCH;
+    if (mlBase > 0xFFFF) {
+        ss.longLengthType = 2;
+        ss.longLengthPos = ss.nseq;
+    }
+#if SQ_ON_DEVICE
+    if (wv_lane() == 0) {
+        uint2 v = make_uint2(offBase, (litLength & 0xFFFF) | (mlBase << 16));
+        *(uint2*)&ss.seqs[ss.nseq] = v;
+    }
+#else
+    ss.seqs[ss.nseq].offBase = offBase;
+    ss.seqs[ss.nseq].litLength = (u16)litLength;
+    ss.seqs[ss.nseq].mlBase = (u16)mlBase;
+#endif
+    ss.nseq++;
+}
+
+// ================================================================ DUBT (btlazy2)
+#define SQZ_DUBT_UNSORTED 1u
+
+// ZSTD_updateDUBT: insert positions [nextToUpdate, target) as unsorted candidates.
+SQ_DEVFN void dubt_update(MatchState& ms, u32 target) {
+    u32* const hashTable = ms.hashTable;
+    u32 const hashLog = ms.cp.hashLog;
+    u32* const bt = ms.chainTable;
+    u32 const btMask = (1u << (ms.cp.chainLog - 1)) - 1;
+    const u8* const base = ms.base;
+#if SQ_ON_DEVICE
+    u32 const lane = wv_lane();
+    for (u32 idx0 = ms.nextToUpdate; idx0 < target; idx0 += 64) {
+        u32 const idx = idx0 + lane;
+        bool const active = idx < target;
+        u32 h = 0;
+        if (active) h = hash4(sq_rd32(base + idx), hashLog);
+        WvGroup const g = wv_group(h, active, g_lds.grp);
+        if (active) {
+            u32 prev;
+            if (g.prevLane < 64)
+                prev = idx0 + g.prevLane;
+            else
+                prev = hashTable[h];
+            uint2 v = make_uint2(prev, SQZ_DUBT_UNSORTED);
+            *(uint2*)(bt + 2 * (idx & btMask)) = v;
+            if (g.rank + 1 == g.gsize) hashTable[h] = idx;
+        }
+        wv_fence();
+    }
+#else
+    for (u32 idx = ms.nextToUpdate; idx < target; idx++) {
+        u32 const h = hash4(sq_rd32(base + idx), hashLog);
+        u32 const matchIndex = hashTable[h];
+        hashTable[h] = idx;
+        bt[2 * (idx & btMask)] = matchIndex;
+        bt[2 * (idx & btMask) + 1] = SQZ_DUBT_UNSORTED;
+    }
+#endif
+    ms.nextToUpdate = target;
+}
+
+// ZSTD_insertDUBT1 (noDict)
+SQ_DEVFN void dubt_insert1(MatchState& ms, u32 curr, const u8* inputEnd, u32 nbCompares, u32 btLow) {
+    u32* const bt = ms.chainTable;
+    u32 const btMask = (1u << (ms.cp.chainLog - 1)) - 1;
+    u32 commonLengthSmaller = 0, commonLengthLarger = 0;
+    const u8* const base = ms.base;
+    const u8* const ip = base + curr;
+    u32 const ipRoom = (u32)(inputEnd - ip);
+    u32* smallerPtr = bt + 2 * (curr & btMask);
+    u32* largerPtr = smallerPtr + 1;
+    u32 matchIndex = gld32(smallerPtr);
+    u32 const windowLow = SQZ_WINDOW_START; // window always covers the whole chunk (see get_cparams)
+    for (; nbCompares && (matchIndex > windowLow); --nbCompares) {
+        u32* const nextPtr = bt + 2 * (matchIndex & btMask);
+        u32 matchLength = commonLengthSmaller < commonLengthLarger ? commonLengthSmaller : commonLengthLarger;
+        const u8* const match = base + matchIndex;
+        matchLength += wv_count(ip + matchLength, match + matchLength, ipRoom - matchLength);
+        if (matchLength == ipRoom) break;
+        if (srd8(match + matchLength) < srd8(ip + matchLength)) {
+            gst32(smallerPtr, matchIndex);
+            commonLengthSmaller = matchLength;
+            if (matchIndex <= btLow) {
+                smallerPtr = ms.dummy;
+                break;
+            }
+            smallerPtr = nextPtr + 1;
+            matchIndex = gld32(nextPtr + 1);
+        } else {
+            gst32(largerPtr, matchIndex);
+            commonLengthLarger = matchLength;
+            if (matchIndex <= btLow) {
+                largerPtr = ms.dummy;
+                break;
+            }
+            largerPtr = nextPtr;
+            matchIndex = gld32(nextPtr);
+        }
+    }
+    gst32(smallerPtr, 0);
+    gst32(largerPtr, 0);
+    wv_fence();
+}
+
+// ZSTD_DUBT_findBestMatch (noDict, mls 4)
+SQ_DEVFN u32 dubt_find(MatchState& ms, const u8* const ip, const u8* const iend, u32* offBasePtr) {
+    u32* const hashTable = ms.hashTable;
+    u32 const hashLog = ms.cp.hashLog;
+    u32 const h = hash4(srd32(ip), hashLog);
+    u32 matchIndex = gld32(hashTable + h);
+    const u8* const base = ms.base;
+    u32 const curr = (u32)(ip - base);
+    u32 const windowLow = SQZ_WINDOW_START;
+    u32* const bt = ms.chainTable;
+    u32 const btMask = (1u << (ms.cp.chainLog - 1)) - 1;
+    u32 const btLow = (btMask >= curr) ? 0 : curr - btMask;
+    u32 const unsortLimit = btLow > windowLow ? btLow : windowLow;
+    u32* nextCandidate = bt + 2 * (matchIndex & btMask);
+    u32* unsortedMark = bt + 2 * (matchIndex & btMask) + 1;
+    u32 nbCompares = 1U << ms.cp.searchLog;
+    u32 nbCandidates = nbCompares;
+    u32 previousCandidate = 0;
+    u32 const ipRoom = (u32)(iend - ip);
+
+    while ((matchIndex > unsortLimit) && (gld32(unsortedMark) == SQZ_DUBT_UNSORTED) && (nbCandidates > 1)) {
+        gst32(unsortedMark, previousCandidate);
+        previousCandidate = matchIndex;
+        matchIndex = gld32(nextCandidate);
+        nextCandidate = bt + 2 * (matchIndex & btMask);
+        unsortedMark = bt + 2 * (matchIndex & btMask) + 1;
+        nbCandidates--;
+    }
+    if ((matchIndex > unsortLimit) && (gld32(unsortedMark) == SQZ_DUBT_UNSORTED)) {
+        gst32(nextCandidate, 0);
+        gst32(unsortedMark, 0);
+    }
+    wv_fence();
+    matchIndex = previousCandidate;
+    while (matchIndex) {
+        u32* const nextCandidateIdxPtr = bt + 2 * (matchIndex & btMask) + 1;
+        u32 const nextCandidateIdx = gld32(nextCandidateIdxPtr);
+        dubt_insert1(ms, matchIndex, iend, nbCandidates, unsortLimit);
+        matchIndex = nextCandidateIdx;
+        nbCandidates++;
+    }
+    {
+        u32 commonLengthSmaller = 0, commonLengthLarger = 0;
+        u32* smallerPtr = bt + 2 * (curr & btMask);
+        u32* largerPtr = bt + 2 * (curr & btMask) + 1;
+        u32 matchEndIdx = curr + 8 + 1;
+        u32 bestLength = 0;
+        matchIndex = gld32(hashTable + h);
+        gst32(hashTable + h, curr);
+        for (; nbCompares && (matchIndex > windowLow); --nbCompares) {
+            u32* const nextPtr = bt + 2 * (matchIndex & btMask);
+            u32 matchLength = commonLengthSmaller < commonLengthLarger ? commonLengthSmaller : commonLengthLarger;
+            const u8* const match = base + matchIndex;
+            matchLength += wv_count(ip + matchLength, match + matchLength, ipRoom - matchLength);
+            if (matchLength > bestLength) {
+                if (matchLength > matchEndIdx - matchIndex) matchEndIdx = matchIndex + matchLength;
+                if ((4 * (int)(matchLength - bestLength)) >
+                    (int)(sq_highbit32(curr - matchIndex + 1) - sq_highbit32(*offBasePtr))) {
+                    bestLength = matchLength;
+                    *offBasePtr = OFFSET_TO_OFFBASE(curr - matchIndex);
+                }
+                if (matchLength == ipRoom) break;
+            }
+            if (srd8(match + matchLength) < srd8(ip + matchLength)) {
+                gst32(smallerPtr, matchIndex);
+                commonLengthSmaller = matchLength;
+                if (matchIndex <= btLow) {
+                    smallerPtr = ms.dummy;
+                    break;
+                }
+                smallerPtr = nextPtr + 1;
+                matchIndex = gld32(nextPtr + 1);
+            } else {
+                gst32(largerPtr, matchIndex);
+                commonLengthLarger = matchLength;
+                if (matchIndex <= btLow) {
+                    largerPtr = ms.dummy;
+                    break;
+                }
+                largerPtr = nextPtr;
+                matchIndex = gld32(nextPtr);
+            }
+        }
+        gst32(smallerPtr, 0);
+        gst32(largerPtr, 0);
+        wv_fence();
+        ms.nextToUpdate = matchEndIdx - 8;
+        return bestLength;
+    }
+}
+
+SQ_DEV u32 bt_find_best(MatchState& ms, const u8* ip, const u8* iLimit, u32* offBasePtr) {
+    if (ip < ms.base + ms.nextToUpdate) return 0; // skipped area
+    dubt_update(ms, (u32)(ip - ms.base));
+    return dubt_find(ms, ip, iLimit, offBasePtr);
+}
+
+// ================================================================ row hash (lazy2)
+// position sequence of ZSTD_row_nextIndex starting from head byte hb: k-th insert (k >= 1)
+SQ_DEV u32 row_pos_after(u32 hb, u32 k) {
+    u32 const c0 = hb & 63;
+    u32 const p1 = (c0 <= 1) ? 63 : c0 - 1;
+    // positions cycle 63,62,...,1,63,...  p_k = ((p1 - 1 - (k-1)) mod 63) + 1
+    u32 const m = (k - 1) % 63;
+    u32 const q = p1 - 1; // 0..62
+    return ((q + 63 - m) % 63) + 1;
+}
+
+// insert positions [from, to) into the row tables (ZSTD_row_update_internalImpl)
+SQ_DEVFN void row_insert_range(MatchState& ms, u32 from, u32 to) {
+    const u8* const base = ms.base;
+    u32 const hBits = ms.rowHashLog + 8;
+#if SQ_ON_DEVICE
+    u32 const lane = wv_lane();
+    for (u32 idx0 = from; idx0 < to; idx0 += 64) {
+        u32 const idx = idx0 + lane;
+        bool const active = idx < to;
+        u32 hash = 0;
+        if (active) hash = hash5(sq_rd64(base + idx), hBits);
+        u32 const relRow = (hash >> 8) << 6;
+        WvGroup const g = wv_group(relRow, active, g_lds.grp);
+        if (active) {
+            u8* const tagRow = ms.tagTable + relRow;
+            u32* const row = ms.hashTable + relRow;
+            u32 const hb = tagRow[0];
+            u32 const pos = row_pos_after(hb, g.rank + 1);
+            if (g.rank + 63 >= g.gsize) { // not overwritten by a later lane of this batch
+                tagRow[pos] = (u8)hash;
+                row[pos] = idx;
+            }
+        }
+        wv_fence();
+        // heads are written after every lane has read its (old) head byte
+        if (active && g.rank + 1 == g.gsize) {
+            u8* const tagRow = ms.tagTable + relRow;
+            tagRow[0] = (u8)row_pos_after(tagRow[0], g.gsize);
+        }
+        wv_fence();
+    }
+#else
+    for (u32 idx = from; idx < to; idx++) {
+        u32 const hash = hash5(sq_rd64(base + idx), hBits);
+        u32 const relRow = (hash >> 8) << 6;
+        u8* const tagRow = ms.tagTable + relRow;
+        u32 const pos = row_pos_after(tagRow[0], 1);
+        tagRow[0] = (u8)pos;
+        tagRow[pos] = (u8)hash;
+        ms.hashTable[relRow + pos] = idx;
+    }
+#endif
+}
+
+// ZSTD_row_update_internal (the 8-entry hash cache is a prefetch device, not state)
+SQ_DEV void row_update(MatchState& ms, u32 target) {
+    u32 idx = ms.nextToUpdate;
+    if (target - idx > 384) {
+        row_insert_range(ms, idx, idx + 96);
+        idx = target - 32;
+    }
+    row_insert_range(ms, idx, target);
+    ms.nextToUpdate = target;
+}
+
+// ZSTD_RowFindBestMatch (noDict, mls 5, rowLog 6)
+SQ_DEVFN u32 row_find(MatchState& ms, const u8* const ip, const u8* const iLimit, u32* offsetPtr) {
+    const u8* const base = ms.base;
+    u32 const curr = (u32)(ip - base);
+    u32 const lowLimit = SQZ_WINDOW_START;
+    u32 ml = 4 - 1;
+    if (!ms.lazySkipping) {
+        row_update(ms, curr);
+    } else {
+        ms.nextToUpdate = curr;
+    }
+    u32 const hash = hash5(srd64(ip), ms.rowHashLog + 8);
+    u32 const relRow = (hash >> 8) << 6;
+    u32 const tag = hash & 0xFF;
+    u32* const row = ms.hashTable + relRow;
+    u8* const tagRow = ms.tagTable + relRow;
+    u32 const limitLen = (u32)(iLimit - ip);
+#if SQ_ON_DEVICE
+    u32 const lane = wv_lane();
+    u32 const hb = gld8(tagRow);
+    u32 const head = hb & 63;
+    u32 const matchPos = (head + lane) & 63;
+    u32 const t = tagRow[matchPos];
+    u32 const cand = row[matchPos];
+    bool const hit = (t == tag) && (matchPos != 0);
+    u64 const M = wv_ballot(hit);
+    u64 const B = wv_ballot(hit && cand < lowLimit);
+    u64 valid = M;
+    if (B) {
+        u32 const jb = (u32)__builtin_ctzll(B);
+        valid &= (jb == 0) ? 0ull : (~0ull >> (64 - jb));
+    }
+    wv_fence();
+    { // insert the current position (ZSTD_row_nextIndex)
+        u32 const pos = row_pos_after(hb, 1);
+        if (lane == 0) {
+            tagRow[0] = (u8)pos;
+            tagRow[pos] = (u8)tag;
+            row[pos] = ms.nextToUpdate;
+        }
+        ms.nextToUpdate++;
+    }
+    wv_fence();
+    if (valid) {
+        // one candidate per lane: full match length, then first-maximum selection
+        u32 L = 0;
+        if ((valid >> lane) & 1) {
+            const u8* const m = base + cand;
+            u32 o = 0;
+            bool done = false;
+            while (!done && o + 8 <= limitLen) {
+                u64 x = sq_rd64(ip + o) ^ sq_rd64(m + o);
+                if (x) {
+                    o += (u32)(__builtin_ctzll(x) >> 3);
+                    done = true;
+                } else
+                    o += 8;
+            }
+            while (!done && o < limitLen) {
+                if (ip[o] != m[o])
+                    done = true;
+                else
+                    o++;
+            }
+            L = o;
+        }
+        u32 mx = L;
+        for (int s = 32; s >= 1; s >>= 1) {
+            u32 y = (u32)__shfl_xor((int)mx, s, 64);
+            mx = y > mx ? y : mx;
+        }
+        mx = wv_uni(mx);
+        if (mx > ml) {
+            u64 const who = wv_ballot(L == mx && ((valid >> lane) & 1));
+            u32 const w = (u32)__builtin_ctzll(who);
+            u32 const idx = wv_readlane(cand, w);
+            ml = mx;
+            *offsetPtr = OFFSET_TO_OFFBASE(curr - idx);
+        }
+    }
+#else
+    {
+        u32 const head = tagRow[0] & 63;
+        u32 matchBuffer[64];
+        u32 numMatches = 0;
+        u32 nbAttempts = 64;
+        for (u32 j = 0; j < 64 && nbAttempts > 0; j++) {
+            u32 const matchPos = (head + j) & 63;
+            if (tagRow[matchPos] != (u8)tag) continue;
+            u32 const matchIndex = row[matchPos];
+            if (matchPos == 0) continue;
+            if (matchIndex < lowLimit) break;
+            matchBuffer[numMatches++] = matchIndex;
+            --nbAttempts;
+        }
+        {
+            u32 const pos = row_pos_after(tagRow[0], 1);
+            tagRow[0] = (u8)pos;
+            tagRow[pos] = (u8)tag;
+            row[pos] = ms.nextToUpdate++;
+        }
+        for (u32 c = 0; c < numMatches; ++c) {
+            u32 const matchIndex = matchBuffer[c];
+            u32 currentMl = 0;
+            const u8* const match = base + matchIndex;
+            if (sq_rd32(match + ml - 3) == sq_rd32(ip + ml - 3)) currentMl = wv_count(ip, match, limitLen);
+            if (currentMl > ml) {
+                ml = currentMl;
+                *offsetPtr = OFFSET_TO_OFFBASE(curr - matchIndex);
+                if (currentMl == limitLen) break;
+            }
+        }
+    }
+#endif
+    return ml;
+}
+
+// ================================================================ lazy parser (depth 2)
+template <int ROW>
+SQ_DEV u32 search_max(MatchState& ms, const u8* ip, const u8* iend, u32* offBase) {
+    if (ROW) return row_find(ms, ip, iend, offBase);
+    return bt_find_best(ms, ip, iend, offBase);
+}
+
+// ZSTD_compressBlock_lazy_generic (noDict, depth 2); returns last literals size
+template <int ROW>
+SQ_DEVFN u32 compressBlock_lazy(MatchState& ms, SeqStore& ss, u32* rep, const u8* src, u32 srcSize) {
+    const u8* const istart = src;
+    const u8* ip = istart;
+    const u8* anchor = istart;
+    const u8* const iend = istart + srcSize;
+    const u8* const ilimit = ROW ? iend - 8 - 8 : iend - 8;
+    const u8* const base = ms.base;
+    const u8* const prefixLowest = base + SQZ_WINDOW_START;
+    u32 offset_1 = rep[0], offset_2 = rep[1];
+    u32 offsetSaved1 = 0, offsetSaved2 = 0;
+
+    ip += (ip == prefixLowest);
+    {
+        u32 const curr = (u32)(ip - base);
+        u32 const maxRep = curr - SQZ_WINDOW_START;
+        if (offset_2 > maxRep) offsetSaved2 = offset_2, offset_2 = 0;
+        if (offset_1 > maxRep) offsetSaved1 = offset_1, offset_1 = 0;
+    }
+    ms.lazySkipping = 0;
+
+    while (ip < ilimit) {
+        u32 matchLength = 0;
+        u32 offBase = 1; // REPCODE1_TO_OFFBASE
+        const u8* start = ip + 1;
+
+        if ((offset_1 > 0) && (srd32(ip + 1 - offset_1) == srd32(ip + 1))) {
+            matchLength = wv_count(ip + 1 + 4, ip + 1 + 4 - offset_1, (u32)(iend - (ip + 1 + 4))) + 4;
+        }
+        {
+            u32 offbaseFound = 999999999;
+            u32 const ml2 = search_max<ROW>(ms, ip, iend, &offbaseFound);
+            if (ml2 > matchLength) matchLength = ml2, start = ip, offBase = offbaseFound;
+        }
+        if (matchLength < 4) {
+            u32 const step = ((u32)(ip - anchor) >> 8) + 1;
+            ip += step;
+            ms.lazySkipping = step > 8;
+            continue;
+        }
+        while (ip < ilimit) {
+            ip++;
+            if ((offset_1 > 0) && (srd32(ip) == srd32(ip - offset_1))) {
+                u32 const mlRep = wv_count(ip + 4, ip + 4 - offset_1, (u32)(iend - (ip + 4))) + 4;
+                int const gain2 = (int)(mlRep * 3);
+                int const gain1 = (int)(matchLength * 3 - sq_highbit32(offBase) + 1);
+                if ((mlRep >= 4) && (gain2 > gain1)) matchLength = mlRep, offBase = 1, start = ip;
+            }
+            {
+                u32 ofbCandidate = 999999999;
+                u32 const ml2 = search_max<ROW>(ms, ip, iend, &ofbCandidate);
+                int const gain2 = (int)(ml2 * 4 - sq_highbit32(ofbCandidate));
+                int const gain1 = (int)(matchLength * 4 - sq_highbit32(offBase) + 4);
+                if ((ml2 >= 4) && (gain2 > gain1)) {
+                    matchLength = ml2, offBase = ofbCandidate, start = ip;
+                    continue;
+                }
+            }
+            if (ip < ilimit) {
+                ip++;
+                if ((offset_1 > 0) && (srd32(ip) == srd32(ip - offset_1))) {
+                    u32 const mlRep = wv_count(ip + 4, ip + 4 - offset_1, (u32)(iend - (ip + 4))) + 4;
+                    int const gain2 = (int)(mlRep * 4);
+                    int const gain1 = (int)(matchLength * 4 - sq_highbit32(offBase) + 1);
+                    if ((mlRep >= 4) && (gain2 > gain1)) matchLength = mlRep, offBase = 1, start = ip;
+                }
+                {
+                    u32 ofbCandidate = 999999999;
+                    u32 const ml2 = search_max<ROW>(ms, ip, iend, &ofbCandidate);
+                    int const gain2 = (int)(ml2 * 4 - sq_highbit32(ofbCandidate));
+                    int const gain1 = (int)(matchLength * 4 - sq_highbit32(offBase) + 7);
+                    if ((ml2 >= 4) && (gain2 > gain1)) {
+                        matchLength = ml2, offBase = ofbCandidate, start = ip;
+                        continue;
+                    }
+                }
+            }
+            break;
+        }
+        if (OFFBASE_IS_OFFSET(offBase)) {
+            u32 const off = OFFBASE_TO_OFFSET(offBase);
+            while ((start > anchor) && (start - off > prefixLowest) && (srd8(start - 1) == srd8(start - off - 1))) {
+                start--;
+                matchLength++;
+            }
+            offset_2 = offset_1;
+            offset_1 = off;
+        }
+        {
+            u32 const litLength = (u32)(start - anchor);
+            storeSeq(ss, litLength, anchor, offBase, matchLength);
+            anchor = ip = start + matchLength;
+        }
+        if (ms.lazySkipping) ms.lazySkipping = 0;
+
+        while ((ip <= ilimit) && (offset_2 > 0) && (srd32(ip) == srd32(ip - offset_2))) {
+            matchLength = wv_count(ip + 4, ip + 4 - offset_2, (u32)(iend - (ip + 4))) + 4;
+            offBase = offset_2;
+            offset_2 = offset_1;
+            offset_1 = offBase;
+            storeSeq(ss, 0, anchor, 1, matchLength);
+            ip += matchLength;
+            anchor = ip;
+        }
+    }
+    offsetSaved2 = ((offsetSaved1 != 0) && (offset_1 != 0)) ? offsetSaved1 : offsetSaved2;
+    rep[0] = offset_1 ? offset_1 : offsetSaved1;
+    rep[1] = offset_2 ? offset_2 : offsetSaved2;
+    return (u32)(iend - anchor);
+}
+
+} // namespace sqz

@@ -1,0 +1,21 @@
+// tests/sim/sim_main.cpp -- TEST INFRASTRUCTURE.  Builds the product's wave-level compressor
+// source (squishrs_amd/csrc/sq_zstd_*.h) with -DSQ_SIM, where every wave primitive has a scalar
+// body, so the uniform control logic can be diffed against the oracle on a machine without a
+// GPU.  Never linked into libsquish_gpu.so; not a fallback for anything.
+#define SQ_SIM 1
+#include "../../squishrs_amd/csrc/sq_zstd_kernel.h"
+#include <stdlib.h>
+
+extern "C" size_t sim_compress_chunk(const uint8_t* src, size_t n, uint8_t* dst, size_t cap, int poison) {
+    sqz::WsLayout L = sqz::ws_layout((u32)n);
+    u8* ws = (u8*)malloc(L.total + 256);
+    // poison the workspace: the kernel must not depend on anything it did not initialise itself
+    memset(ws, poison ? 0xA5 : 0, L.total + 256);
+    memset(&sqz::g_lds, poison ? 0x5A : 0, sizeof(sqz::g_lds));
+    u8* wsa = (u8*)(((uintptr_t)ws + 255) & ~(uintptr_t)255);
+    u32 r = sqz::compress_frame_wave(src, (u32)n, dst, (u32)cap, wsa, L);
+    free(ws);
+    return r;
+}
+extern "C" size_t sim_workspace_bytes(size_t n) { return sqz::workspace_bytes((u32)n); }
+extern "C" size_t sim_lds_bytes(void) { return sizeof(sqz::LdsState); }

@@ -1,0 +1,150 @@
+"""GPU parity for the zstd level-12 frame compressor kernel, through the C ABI:
+bit-exact vs the CPU oracle and vs the golden vectors produced by real libzstd 1.5.7; plus
+size-independent properties (decode round trip, determinism) at full configuration sizes.
+Where the GPU box image still carries libzstd 1.5.7 it is used as one more, direct check."""
+import hashlib
+import json
+import os
+
+import numpy as np
+import pytest
+
+import corpus
+
+pytestmark = pytest.mark.gpu
+G = os.path.join(os.path.dirname(__file__), "golden")
+ZZ = json.load(open(os.path.join(G, "zstd12_frames.json")))
+
+
+def _batch_compress(store, chunks):
+    """sq_compress_batch over device-resident chunks; returns list of frames."""
+    import torch
+    lens = np.array([len(c) for c in chunks], dtype=np.uint32)
+    offs = np.zeros(len(chunks), dtype=np.uint64)
+    pos = 0
+    for i, c in enumerate(chunks):
+        offs[i] = pos
+        pos += (len(c) + 255) // 256 * 256
+    buf = np.zeros(pos + 256, dtype=np.uint8)
+    for i, c in enumerate(chunks):
+        buf[int(offs[i]):int(offs[i]) + len(c)] = np.frombuffer(c, dtype=np.uint8)
+    d = torch.from_numpy(buf).cuda()
+    import squishrs_amd
+    cap = int(sum(squishrs_amd.compress_bound(len(c)) + 64 for c in chunks))
+    comp = torch.zeros(cap, dtype=torch.uint8, device="cuda")
+    coff = store.compress_device(d, offs, lens, None, comp)
+    host = comp.cpu().numpy()
+    return [host[int(coff[i]):int(coff[i + 1])].tobytes() for i in range(len(chunks))]
+
+
+def test_known_answers_single_chunk_api():
+    import squishrs_amd
+    # SURVEY.md Appendix B (real libzstd 1.5.7 outputs)
+    assert squishrs_amd.compress_chunk(b"hello squish").hex() == "28b52ffd200c61000068656c6c6f20737175697368"
+    assert squishrs_amd.compress_chunk(b"").hex() == "28b52ffd2000010000"
+    assert squishrs_amd.compress_chunk(b"\x01" * 1024).hex() == "28b52ffd60000345000008010100fc2b2004"
+    assert squishrs_amd.compress_chunk(b"abc" * 1000).hex() == "28b52ffd60b80a550000186162630100b2d37743"
+    assert squishrs_amd.compress_chunk(bytes(262144)).hex() == "28b52ffda0000004005400001000000100fbff39c00203001000"
+
+
+def test_golden_literals(gpu_store):
+    names = sorted(ZZ["literals"])
+    frames = _batch_compress(gpu_store, [bytes.fromhex(ZZ["literals"][k]["hex"]) for k in names])
+    for k, f in zip(names, frames):
+        assert f.hex() == ZZ["literals"][k]["frame"], k
+
+
+def test_golden_generated_all_strategies(gpu_store, oracle):
+    cases = ZZ["generated"]
+    chunks = [corpus.make(e["kind"], e["seed"], e["len"]) for e in cases]
+    frames = _batch_compress(gpu_store, chunks)
+    for e, c, f in zip(cases, chunks, frames):
+        tag = (e["kind"], e["seed"], e["len"])
+        assert len(f) == e["clen"], tag
+        assert hashlib.sha256(f).hexdigest() == e["sha256"], tag
+        if "frame" in e:
+            assert f.hex() == e["frame"], tag
+
+
+def test_golden_special_presplit_rle_raw(gpu_store, oracle):
+    import gen_golden
+    sp = gen_golden.special_inputs()
+    names = sorted(ZZ["special"])
+    frames = _batch_compress(gpu_store, [sp[k] for k in names])
+    for k, f in zip(names, frames):
+        assert len(f) == ZZ["special"][k]["clen"], k
+        assert hashlib.sha256(f).hexdigest() == ZZ["special"][k]["sha256"], k
+        assert oracle.decompress(f, len(sp[k])) == sp[k]
+
+
+def test_vs_oracle_ragged_batch(gpu_store, oracle):
+    rng = np.random.default_rng(11)
+    chunks = []
+    kinds = ["text", "records", "runs", "skewed", "mixed", "random"]
+    for i in range(60):
+        n = int(rng.choice([rng.integers(1, 300), rng.integers(300, 17000), rng.integers(17000, 270000),
+                            rng.integers(270000, 1200000)]))
+        chunks.append(corpus.make(kinds[i % len(kinds)], 100 + i, n))
+    frames = _batch_compress(gpu_store, chunks)
+    for c, f in zip(chunks, frames):
+        assert f == oracle.compress_chunk(c), len(c)
+
+
+def test_store_insert_semantics(oracle):
+    # src/util/tests.rs:106-166 restated against the HIP-backed ChunkStore
+    import squishrs_amd
+    st = squishrs_amd.ChunkStore(device=0, dedup_capacity=1 << 12)
+    data = b"\x2a" * 2048
+    r1 = st.insert(data)
+    r2 = st.insert(data)
+    assert r1.compressed_data is not None and r2.compressed_data is None
+    assert r1.hash == r2.hash and st.len() == 1 and not st.is_empty()
+    assert len(r1.compressed_data) < len(data)
+    assert oracle.decompress(r1.compressed_data, 2048) == data
+    r3 = st.insert(b"other chunk")
+    assert r3.compressed_data is not None and r3.hash != r1.hash and st.len() == 2
+    # batch form == n x insert in index order, bit-exact vs the oracle store
+    import oracle_lib
+    ost = oracle_lib.OracleStore(oracle)
+    chunks = [corpus.text_like(5, 40000), corpus.random_bytes(9, 1, 70000), corpus.text_like(5, 40000),
+              corpus.mixed(2, 300000), corpus.random_bytes(9, 1, 70000), b"x"]
+    st2 = squishrs_amd.ChunkStore(device=0, dedup_capacity=1 << 12)
+    got = st2.insert_batch(chunks)
+    for c, g in zip(chunks, got):
+        h, comp = ost.insert(c)
+        assert g.hash == h and g.compressed_data == comp
+    assert st2.len() == ost.len() == 4
+    st.close()
+    st2.close()
+
+
+def test_full_size_properties_256k(gpu_store, oracle):
+    """BASELINE configs 1/2 shape: 256 KiB random chunks -> raw-block frames of 262,159 bytes that
+    decode back; sampled bit-exact vs oracle; deterministic across runs."""
+    chunks = [corpus.random_bytes(21, i, 262144) for i in range(96)]
+    f1 = _batch_compress(gpu_store, chunks)
+    f2 = _batch_compress(gpu_store, chunks)
+    assert f1 == f2
+    for c, f in zip(chunks, f1):
+        assert len(f) == 262159
+        assert f[9 + 3:9 + 3 + 131072] == c[:131072]
+    for i in (0, 17, 95):
+        assert f1[i] == oracle.compress_chunk(chunks[i])
+
+
+def test_full_size_properties_2m(gpu_store, oracle):
+    chunks = [corpus.mixed(40 + i, 2097152) for i in range(6)] + [corpus.text_like(3, 2097152)]
+    frames = _batch_compress(gpu_store, chunks)
+    for c, f in zip(chunks, frames):
+        assert oracle.decompress(f, len(c)) == c
+    assert frames[0] == oracle.compress_chunk(chunks[0])
+    assert frames[-1] == oracle.compress_chunk(chunks[-1])
+
+
+def test_direct_vs_libzstd_when_present(gpu_store):
+    import zref
+    if not zref.available():
+        pytest.skip("libzstd 1.5.7 not in this image")
+    chunks = [corpus.text_like(77, 100000), corpus.mixed(78, 500000), corpus.records(79, 12000)]
+    for c, f in zip(chunks, _batch_compress(gpu_store, chunks)):
+        assert f == zref.compress(c)
