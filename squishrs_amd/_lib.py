@@ -49,6 +49,13 @@ def load():
         return _lib
     if not os.path.exists(LIB_PATH):
         raise SquishError(SQ_E_NODEVICE, f"{LIB_PATH} not built; run __graft_entry__.build()")
+    # One HIP runtime per process: torch bundles its own libamdhip64.so (SONAME libamdhip64.so.7).
+    # Importing torch first makes the loader resolve our DT_NEEDED libamdhip64.so.7 to that copy;
+    # the other order would give the process two runtimes and torch would see no GPU.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     L = ctypes.CDLL(LIB_PATH)
     vp, u8p = ctypes.c_void_p, ctypes.c_void_p
     L.sq_abi_version.restype = ctypes.c_uint32

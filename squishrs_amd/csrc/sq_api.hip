@@ -13,6 +13,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <ctime>
+#include <unistd.h>
 #include <new>
 #include <vector>
 
@@ -362,6 +364,34 @@ static int compress_async(sq_ctx* c, const u8* d_data, const u64* h_off, const u
         HIPCHK(hipGetLastError());
     }
     HIPCHK(hipEventRecord(c->ev[5], c->stream));
+    if (const char* wd = getenv("SQ_WATCHDOG_MS")) {
+        // bring-up aid: if the compressor does not finish in time, dump wave 0..3 progress markers
+        const long limit_ms = atol(wd);
+        long waited = 0;
+        while (hipStreamQuery(c->stream) == hipErrorNotReady && waited < limit_ms) {
+            struct timespec ts = {0, 5 * 1000 * 1000};
+            nanosleep(&ts, nullptr);
+            waited += 5;
+        }
+        if (hipStreamQuery(c->stream) == hipErrorNotReady) {
+            hipStream_t s2;
+            (void)hipStreamCreateWithFlags(&s2, hipStreamNonBlocking);
+            const sqz::WsLayout L = sqz::ws_layout(max_len);
+            for (u32 w = 0; w < std::min(waves, 4u); w++) {
+                u32 tr[64];
+                // per-chunk layouts differ from the pool layout: dump the dummy area of every
+                // distinct layout used in this batch (bring-up batches are uniform)
+                (void)hipMemcpyAsync(tr, (u8*)c->b_ws.p + (size_t)w * ws_each + L.dummy, sizeof(tr),
+                                     hipMemcpyDeviceToHost, s2);
+                (void)hipStreamSynchronize(s2);
+                fprintf(stderr, "[squish_gpu watchdog] wave %u trace:", w);
+                for (int k = 8; k < 24; k++) fprintf(stderr, " %u", tr[k]);
+                fprintf(stderr, "\n");
+            }
+            fflush(stderr);
+            _exit(3);
+        }
+    }
     hipLaunchKernelGGL(sqd::k_scan_lengths, dim3(1), dim3(1024), 0, c->stream, (const u32*)c->b_frame_len.p,
                        n, (u64*)c->b_out_off.p);
     HIPCHK(hipGetLastError());

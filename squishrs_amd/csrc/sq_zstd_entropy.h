@@ -63,8 +63,19 @@ struct LdsState {
     u8 tableSymbol[512];
     u8 grp[2048]; // wv_group scratch
     u32 ret[8];   // results handed from a serial region to the whole wave
+    u32* trace;   // 56 debug words in the wave's workspace (read by the host watchdog)
 };
 SQ_LDS LdsState g_lds;
+
+// progress markers for bring-up: slot 0 = stage, others free-form
+#if SQ_ON_DEVICE
+#define SQ_TRACE(slot, val)                                        \
+    do {                                                           \
+        if (wv_lane() == 0) g_lds.trace[slot] = (u32)(val);        \
+    } while (0)
+#else
+#define SQ_TRACE(slot, val) do { g_lds.trace[slot] = (u32)(val); } while (0)
+#endif
 
 // ---------------------------------------------------------------- constant tables
 #if SQ_ON_DEVICE
@@ -1236,7 +1247,10 @@ SQ_DEVFN u32 entropy_compress_seqstore(const SeqStore& ss, const Entropy* prev, 
         litSectionSize = compressLiterals(dst, dstCap, ss.lits, litSize, prev, next, strategy, suspect);
         if (is_err(litSectionSize)) return (blockSize <= dstCap) ? 0 : SQZ_ERR;
     }
+    SQ_TRACE(0, 81);
+    SQ_TRACE(6, litSectionSize);
     if (nbSeq) seqToCodes_and_hist(ss);
+    SQ_TRACE(0, 82);
     WV_SERIAL {
         u8* const ostart = dst;
         u8* const oend = dst + dstCap;

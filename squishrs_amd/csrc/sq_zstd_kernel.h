@@ -202,6 +202,7 @@ SQ_DEVFN u32 compressBlock_internal(MatchState& ms, SeqStore& ss, BlockState& bs
         }
         for (int i = 0; i < SQZ_REP_NUM; ++i) bs.rep[nx][i] = bs.rep[p][i];
         u32 lastLLSize;
+        SQ_TRACE(0, 6);
         if (ms.cp.strategy == STRAT_LAZY2) {
             lastLLSize = compressBlock_lazy<1>(ms, ss, bs.rep[nx], src, srcSize);
         } else if (ms.cp.strategy == STRAT_BTLAZY2) {
@@ -248,9 +249,13 @@ SQ_DEVFN u32 compressBlock_internal(MatchState& ms, SeqStore& ss, BlockState& bs
             bs.rep[nx][2] = g_lds.ret[7];
             wv_fence();
         }
+        SQ_TRACE(0, 7);
+        SQ_TRACE(4, ss.nseq);
         if (lastLLSize) wv_memcpy(ss.lits + ss.nlits, src + srcSize - lastLLSize, lastLLSize);
         ss.nlits += lastLLSize;
         cSize = entropy_compress_seqstore(ss, &g_lds.ent[p], &g_lds.ent[nx], ms.cp.strategy, dst, dstCap, srcSize);
+        SQ_TRACE(0, 9);
+        SQ_TRACE(5, cSize);
         if (is_err(cSize)) return cSize;
         if (!bs.isFirstBlock && cSize < 25 && wv_is_rle(src, srcSize)) {
             cSize = 1;
@@ -270,6 +275,10 @@ SQ_DEVFN u32 compress_frame_wave(const u8* src, u32 n, u8* dst, u32 cap, u8* ws,
     CParams const cp = get_cparams(n);
     u8* op = dst;
     u8* const oend = dst + cap;
+    WV_SERIAL { g_lds.trace = (u32*)(ws + L.dummy) + 8; }
+    wv_fence();
+    SQ_TRACE(0, 1);
+    SQ_TRACE(1, n);
     if (cap < 18) return 0;
     // ---- frame header (ZSTD_writeFrameHeader)
     u32 const fcsCode = (n >= 256) + (n >= 65536 + 256);
@@ -307,7 +316,9 @@ SQ_DEVFN u32 compress_frame_wave(const u8* src, u32 n, u8* dst, u32 cap, u8* ws,
     ms.dummy = (u32*)(ws + L.dummy);
     ms.hashLog3 = 0;
     ms.rowHashLog = 0;
+    SQ_TRACE(0, 2);
     wv_fill32(ms.hashTable, 0, (size_t)1 << cp.hashLog);
+    SQ_TRACE(0, 3);
     if (cp.strategy == STRAT_LAZY2) {
         ms.rowHashLog = cp.hashLog - 6;
     } else if (cp.strategy == STRAT_BTOPT) {
@@ -348,7 +359,11 @@ SQ_DEVFN u32 compress_frame_wave(const u8* src, u32 n, u8* dst, u32 cap, u8* ws,
     u32 remaining = n;
     s64 savings = 0;
     while (remaining) {
+        SQ_TRACE(0, 4);
+        SQ_TRACE(2, (u32)(ip - src));
         u32 const blockSize = optimalBlockSize(ip, remaining, savings, (Fingerprint*)(ws + L.fp));
+        SQ_TRACE(0, 5);
+        SQ_TRACE(3, blockSize);
         u32 const lastBlock = (blockSize == remaining);
         if ((u32)(oend - op) < 3 + 2 + 1) return 0;
         if (ms.nextToUpdate < SQZ_WINDOW_START) ms.nextToUpdate = SQZ_WINDOW_START;
@@ -380,33 +395,46 @@ SQ_DEVFN u32 compress_frame_wave(const u8* src, u32 n, u8* dst, u32 cap, u8* ws,
         bs.isFirstBlock = 0;
     }
     wv_fence();
+    SQ_TRACE(0, 10);
     return (u32)(op - dst);
 }
 
 #if SQ_ON_DEVICE
+// One chunk -> one frame in its output slot (kept out of line: keeps the queue loop simple).
+__device__ __noinline__ void compress_one(const u8* data, const u64* off, const u32* len, u32 idx, u8* slots,
+                                          const u64* slot_off, u32* frame_len, u8* ws, u32* err) {
+    u32 const L = len[idx];
+    WsLayout const lay = ws_layout(L); // offsets for this length are <= the pool's
+    u32 const cap = (u32)(slot_off[idx + 1] - slot_off[idx]);
+    u32 const r = compress_frame_wave(data + off[idx], L, slots + slot_off[idx], cap, ws, lay);
+    if (wv_lane() == 0) {
+        frame_len[idx] = r;
+        if (r == 0) atomicOr(err, 1u);
+    }
+}
+
 // Persistent compressor: grid = number of workspaces, block = one wave.  Each wave pulls chunk
 // indices from *queue until exhausted; every wave reaches the exit condition (idx >= n).
 __global__ void __launch_bounds__(64)
-k_compress_batch(const u8* __restrict__ data, const u64* __restrict__ off, const u32* __restrict__ len,
-                 const u8* __restrict__ select, u32 n, u8* __restrict__ slots, const u64* __restrict__ slot_off,
-                 u32* __restrict__ frame_len, u8* __restrict__ ws_pool, u64 ws_each, u32* __restrict__ queue,
-                 u32* __restrict__ err) {
+k_compress_batch(const u8* data, const u64* off, const u32* len, const u8* select, u32 n, u8* slots,
+                 const u64* slot_off, u32* frame_len, u8* ws_pool, u64 ws_each, u32* queue, u32* err) {
     u8* const ws = ws_pool + (u64)blockIdx.x * ws_each;
+    u32* const dbg = (u32*)(ws + ws_each - 256) + 8; // wave-level progress words for the watchdog
+    u32 iter = 0;
     for (;;) {
         u32 idx = 0;
-        if (threadIdx.x == 0) idx = atomicAdd(queue, 1u);
+        if (wv_lane() == 0) idx = atomicAdd(queue, 1u);
         idx = wv_uni(idx);
-        if (idx >= n) break;
-        if (select && !select[idx]) continue;
-        u32 const L = len[idx];
-        WsLayout const lay = ws_layout(L); // offsets for this length are <= the pool's
-        u32 const cap = (u32)(slot_off[idx + 1] - slot_off[idx]);
-        u32 const r = compress_frame_wave(data + off[idx], L, slots + slot_off[idx], cap, ws, lay);
-        if (threadIdx.x == 0) {
-            frame_len[idx] = r;
-            if (r == 0) atomicOr(err, 1u);
+        if (wv_lane() == 0) {
+            dbg[12] = 1000 + iter;
+            dbg[13] = idx;
         }
+        iter++;
+        if (idx >= n) break;
+        bool const take = (select == nullptr) || (select[idx] != 0);
+        if (take) compress_one(data, off, len, idx, slots, slot_off, frame_len, ws, err);
     }
+    if (wv_lane() == 0) dbg[11] = 777;
 }
 #endif
 
