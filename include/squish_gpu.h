@@ -85,6 +85,10 @@ int sq_pack_batch(sq_ctx* ctx, const uint8_t* data, const uint64_t* off, const u
 /* == ChunkStore::len (src/util/chunk.rs:116-118). */
 uint64_t sq_unique_count(const sq_ctx* ctx);
 
+/* == ChunkStore::new on an existing ctx (src/util/chunk.rs:52-56): empties the dedup set, keeping
+ * every device buffer.  Asynchronous on the ctx stream. */
+int sq_dedup_reset(sq_ctx* ctx);
+
 /* ---- stage-level entry points (same kernels sq_pack_batch chains; used by the multi-GPU
  * driver, the parity tests and bench.py).  d_* are DEVICE pointers, h_* HOST pointers. */
 

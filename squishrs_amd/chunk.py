@@ -87,6 +87,10 @@ class ChunkStore:
     def is_empty(self) -> bool:
         return self.len() == 0
 
+    def reset(self):
+        """ChunkStore::new on the same device buffers (empties the dedup set)."""
+        check(self._L.sq_dedup_reset(self._h))
+
     # -- batch forms -----------------------------------------------------------------------
     def insert_batch(self, chunks: Sequence[bytes]) -> List[InsertReturn]:
         """n x insert in index order through sq_pack_batch with host buffers."""

@@ -221,6 +221,15 @@ uint64_t sq_unique_count(const sq_ctx* c) {
     return (uint64_t)v;
 }
 
+int sq_dedup_reset(sq_ctx* c) {
+    if (!c) return SQ_E_INVAL;
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipMemsetAsync(c->d_table, 0, (c->table_mask + 1) * sizeof(u32), c->stream));
+    HIPCHK(hipMemsetAsync(c->d_unique, 0, 64, c->stream));
+    c->n_seen = 0;
+    return SQ_OK;
+}
+
 int sq_last_timings(sq_ctx* c, sq_timings* out) {
     if (!c || !out) return SQ_E_INVAL;
     *out = c->last;

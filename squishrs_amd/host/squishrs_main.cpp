@@ -1,0 +1,382 @@
+// squishrs_main.cpp -- C++ host driver above the C ABI (include/squish_gpu.h): the counterpart of
+// the reference's pack driver, keeping the CLI surface and the .squish v1.2 bytes identical.
+// (Rust is not available in the build image, so the host side is C++; INTEGRATION.md shows the
+// Rust binding a maintainer would add instead.)
+//
+//   ArchiveWriter::new / pack / process_file / write_files_metadata
+//                          /root/reference/src/archive/writer.rs:66-107,151-195,229-271,292-329
+//   writer_thread record   /root/reference/src/fsutil/writer.rs:17-39
+//   header helpers         /root/reference/src/util/header.rs:10-14,35-63,192-233
+//   walk_dir               /root/reference/src/fsutil/directory.rs:39-73
+//   CLI flags / messages   /root/reference/src/cmd/mod.rs:11-58, /root/reference/src/lib.rs:19-111,
+//                          /root/reference/src/main.rs:5-10
+//
+// Chunk records are emitted in canonical "-j 1" order (first occurrence in manifest order,
+// SURVEY.md Appendix E).  Every chunk's hash / dedup decision / frame comes from sq_pack_batch:
+// there is no CPU hashing or compression in this program.
+#include "../../include/squish_gpu.h"
+
+#include <dirent.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
+#include <cerrno>
+#include <cinttypes>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <ctime>
+#include <algorithm>
+#include <map>
+#include <string>
+#include <vector>
+
+static const char* kVersion = "1.2.0"; // CARGO_PKG_VERSION, Cargo.toml:3
+static bool g_tty = false;
+
+struct AppError {
+    std::string msg;
+};
+static std::string green(const std::string& s) { return g_tty ? "\x1b[32m" + s + "\x1b[0m" : s; }
+static std::string blue(const std::string& s) { return g_tty ? "\x1b[34m" + s + "\x1b[0m" : s; }
+static std::string red(const std::string& s) { return isatty(2) ? "\x1b[31m" + s + "\x1b[0m" : s; }
+
+// cmd/mod.rs:161-165 -- byte-unit decimal units, "{:.2} {}"
+static std::string format_bytes(uint64_t bytes) {
+    static const char* units[] = {"B", "KB", "MB", "GB", "TB", "PB", "EB"};
+    double v = (double)bytes;
+    int u = 0;
+    while (v >= 1000.0 && u < 6) {
+        v /= 1000.0;
+        u++;
+    }
+    char buf[64];
+    snprintf(buf, sizeof(buf), "%.2f %s", v, units[u]);
+    return buf;
+}
+
+static std::string with_commas(uint64_t v) { // num_format Locale::en
+    std::string s = std::to_string(v), o;
+    int c = 0;
+    for (size_t i = s.size(); i-- > 0;) {
+        o.insert(o.begin(), s[i]);
+        if (++c % 3 == 0 && i) o.insert(o.begin(), ',');
+    }
+    return o;
+}
+
+// fsutil/directory.rs:39-73: iterative DFS with stack.pop(); OS read_dir order (not sorted);
+// is_dir() follows symlinks.
+static std::vector<std::string> walk_dir(const std::string& root) {
+    std::vector<std::string> stack{root}, files;
+    while (!stack.empty()) {
+        std::string dir = stack.back();
+        stack.pop_back();
+        DIR* d = opendir(dir.c_str());
+        if (!d) throw AppError{"Failed to read directory " + dir + ": " + strerror(errno)};
+        std::vector<std::string> dirs;
+        while (struct dirent* e = readdir(d)) {
+            if (!strcmp(e->d_name, ".") || !strcmp(e->d_name, "..")) continue;
+            std::string p = dir + "/" + e->d_name;
+            struct stat st;
+            if (stat(p.c_str(), &st) == 0 && S_ISDIR(st.st_mode))
+                dirs.push_back(p);
+            else
+                files.push_back(p);
+        }
+        closedir(d);
+        for (auto& x : dirs) stack.push_back(x);
+    }
+    return files;
+}
+
+static void put_u64(std::string& b, uint64_t v) { b.append((const char*)&v, 8); } // LE host
+static void put_u32(std::string& b, uint32_t v) { b.append((const char*)&v, 4); }
+
+static void check(int rc, const char* what) {
+    if (rc != SQ_OK) {
+        if (rc == SQ_E_COMPRESS) throw AppError{"Compression error"}; // errors.rs:25-26
+        throw AppError{std::string("Unknown error: ") + what + ": " + sq_strerror(rc)};
+    }
+}
+
+struct FileMeta {
+    std::string rel;
+    uint64_t size;
+    std::vector<std::string> hashes; // 16 bytes each
+};
+
+static std::string strip_prefix(const std::string& path, const std::string& prefix) {
+    // Path::strip_prefix works on components: tolerate trailing slashes in the prefix
+    std::string pre = prefix;
+    while (pre.size() > 1 && pre.back() == '/') pre.pop_back();
+    if (path.compare(0, pre.size(), pre) != 0) throw AppError{"Unknown error: prefix not found"};
+    size_t i = pre.size();
+    while (i < path.size() && path[i] == '/') i++;
+    return path.substr(i);
+}
+
+static uint64_t pack(const std::string& input, const std::string& output, int device, uint64_t batch_bytes) {
+    std::string trimmed = input;
+    while (!trimmed.empty() && (trimmed.back() == '/' || trimmed.back() == '\\')) trimmed.pop_back();
+    std::vector<std::string> files = walk_dir(trimmed); // lib.rs:36
+
+    FILE* out = fopen(output.c_str(), "wb"); // writer.rs:72
+    if (!out) throw AppError{std::string("I/O error: ") + strerror(errno)};
+    {
+        std::string pre = "squish"; // header.rs:10-14
+        pre += kVersion;
+        put_u64(pre, (uint64_t)time(nullptr)); // header.rs:55-63
+        put_u64(pre, 0);                       // placeholder, writer.rs:83-84
+        fwrite(pre.data(), 1, pre.size(), out);
+    }
+    sq_config cfg;
+    memset(&cfg, 0, sizeof(cfg));
+    cfg.abi_version = SQ_ABI_VERSION;
+    cfg.device = device;
+    cfg.max_batch_bytes = batch_bytes;
+    uint64_t total_chunks = 0;
+    std::vector<uint64_t> sizes(files.size());
+    for (size_t i = 0; i < files.size(); i++) {
+        struct stat st;
+        if (stat(files[i].c_str(), &st) != 0) throw AppError{std::string("I/O error: ") + strerror(errno)};
+        sizes[i] = (uint64_t)st.st_size;
+        total_chunks += (sizes[i] + SQ_CHUNK_SIZE - 1) / SQ_CHUNK_SIZE;
+    }
+    cfg.dedup_capacity = total_chunks + 1024;
+    sq_ctx* ctx = nullptr;
+    check(sq_ctx_create(&cfg, &ctx), "sq_ctx_create");
+
+    std::vector<FileMeta> metas(files.size());
+    // batch state
+    std::vector<uint8_t> data;
+    std::vector<uint64_t> off;
+    std::vector<uint32_t> len;
+    std::vector<size_t> owner; // file index of each chunk in the batch
+    data.reserve((size_t)batch_bytes + SQ_CHUNK_SIZE);
+
+    auto flush = [&]() {
+        uint32_t n = (uint32_t)len.size();
+        if (!n) return;
+        std::vector<uint8_t> hashes((size_t)n * 16), is_new(n);
+        uint64_t cap = 0;
+        for (uint32_t i = 0; i < n; i++) cap += sq_compress_bound(len[i]) + 64;
+        std::vector<uint8_t> comp(cap);
+        std::vector<uint64_t> coff((size_t)n + 1);
+        check(sq_pack_batch(ctx, data.data(), off.data(), len.data(), n, hashes.data(), is_new.data(), comp.data(),
+                            cap, coff.data()),
+              "sq_pack_batch");
+        for (uint32_t i = 0; i < n; i++) {
+            metas[owner[i]].hashes.emplace_back((const char*)&hashes[(size_t)16 * i], 16); // writer.rs:267
+            if (is_new[i]) { // fsutil/writer.rs:21-36
+                uint64_t osz = SQ_CHUNK_SIZE /* chunk_buf.len(), writer.rs:255 */, csz = coff[i + 1] - coff[i];
+                fwrite(&hashes[(size_t)16 * i], 1, 16, out);
+                fwrite(&osz, 8, 1, out);
+                fwrite(&csz, 8, 1, out);
+                fwrite(&comp[coff[i]], 1, csz, out);
+            }
+        }
+        data.clear();
+        off.clear();
+        len.clear();
+        owner.clear();
+    };
+
+    for (size_t f = 0; f < files.size(); f++) { // writer.rs:229-271, files in slice order
+        metas[f].rel = strip_prefix(files[f], input);
+        metas[f].size = sizes[f];
+        FILE* in = fopen(files[f].c_str(), "rb");
+        if (!in) throw AppError{std::string("I/O error: ") + strerror(errno)};
+        for (;;) {
+            size_t pos = data.size();
+            data.resize(pos + SQ_CHUNK_SIZE);
+            size_t got = fread(&data[pos], 1, SQ_CHUNK_SIZE, in);
+            data.resize(pos + got);
+            if (got == 0) break; // writer.rs:241-245
+            off.push_back(pos);
+            len.push_back((uint32_t)got);
+            owner.push_back(f);
+            if (data.size() >= batch_bytes || len.size() >= 4096) flush();
+            if (got < SQ_CHUNK_SIZE) break;
+        }
+        fclose(in);
+    }
+    flush();
+    {
+        uint64_t count = sq_unique_count(ctx); // writer.rs:177-184
+        fseek(out, 19, SEEK_SET);
+        fwrite(&count, 8, 1, out);
+        fseek(out, 0, SEEK_END);
+    }
+    { // writer.rs:292-329
+        std::string m;
+        put_u32(m, (uint32_t)metas.size());
+        for (auto& fm : metas) {
+            put_u32(m, (uint32_t)fm.rel.size());
+            m += fm.rel;
+            put_u64(m, fm.size);
+            put_u32(m, (uint32_t)fm.hashes.size());
+            for (auto& h : fm.hashes) m += h;
+        }
+        fwrite(m.data(), 1, m.size(), out);
+    }
+    fflush(out);
+    uint64_t total = (uint64_t)ftell(out);
+    fclose(out);
+    sq_ctx_destroy(ctx);
+    return total;
+}
+
+// ---- list (archive/reader.rs:46-118,155-219; cmd/mod.rs:60-158) --------------------------------
+struct Summary {
+    uint64_t archive_size = 0, total_orig = 0, unique_chunks = 0, timestamp = 0;
+    std::string version;
+    std::vector<std::pair<std::string, uint64_t>> files;
+};
+static void rd(FILE* f, void* p, size_t n) {
+    if (fread(p, 1, n, f) != n) throw AppError{"Error reading from squish: failed to fill whole buffer"};
+}
+static Summary read_summary(const std::string& path) {
+    FILE* f = fopen(path.c_str(), "rb");
+    if (!f) throw AppError{"Specified file does not exist: `" + path + "`"};
+    Summary s;
+    struct stat st;
+    stat(path.c_str(), &st);
+    s.archive_size = (uint64_t)st.st_size;
+    char hdr[11];
+    if (fread(hdr, 1, 11, f) != 11) throw AppError{"I/O error: failed to fill whole buffer"};
+    if (memcmp(hdr, "squish", 6) != 0) throw AppError{"Archive format error: Invalid archive header: prefix mismatch"};
+    s.version.assign(hdr + 6, 5);
+    { // header.rs:119-163: major.minor must match
+        std::string v = s.version;
+        size_t d1 = v.find('.'), d2 = v.find('.', d1 == std::string::npos ? 0 : d1 + 1);
+        if (d1 == std::string::npos) throw AppError{"Archive format error: Invalid version format in archive header"};
+        std::string maj = v.substr(0, d1), mnr = v.substr(d1 + 1, d2 == std::string::npos ? std::string::npos : d2 - d1 - 1);
+        if (maj != "1" || mnr != "2")
+            throw AppError{"Archive format error: Incompatible version: archive " + maj + "." + mnr + " vs current 1.2"};
+    }
+    rd(f, &s.timestamp, 8);
+    rd(f, &s.unique_chunks, 8);
+    for (uint64_t i = 0; i < s.unique_chunks; i++) {
+        uint8_t h[16];
+        uint64_t osz, csz;
+        rd(f, h, 16);
+        rd(f, &osz, 8);
+        rd(f, &csz, 8);
+        if (fseek(f, (long)csz, SEEK_CUR)) throw AppError{"Error reading from squish: seek"};
+    }
+    uint32_t nfiles;
+    rd(f, &nfiles, 4);
+    for (uint32_t i = 0; i < nfiles; i++) {
+        uint32_t plen, cc;
+        uint64_t osz;
+        rd(f, &plen, 4);
+        std::string p(plen, '\0');
+        rd(f, &p[0], plen);
+        rd(f, &osz, 8);
+        rd(f, &cc, 4);
+        fseek(f, (long)cc * 16, SEEK_CUR);
+        s.total_orig += osz;
+        s.files.emplace_back(p, osz);
+    }
+    fclose(f);
+    return s;
+}
+static std::string date_of(uint64_t ts) { // header.rs:87-95 "%H:%M %d/%m/%Y" local time
+    time_t t = (time_t)ts;
+    struct tm tmv;
+    localtime_r(&t, &tmv);
+    char buf[64];
+    strftime(buf, sizeof(buf), "%H:%M %d/%m/%Y", &tmv);
+    return buf;
+}
+static void list_cmd(const std::string& squish, bool simple) {
+    Summary s = read_summary(squish);
+    double ratio = s.total_orig ? (double)s.archive_size / (double)s.total_orig * 100.0 : 0.0;
+    if (simple) { // lib.rs:67-80
+        printf("squish_size(bytes): %" PRIu64 ", original_size(bytes): %" PRIu64
+               ", compression ratio: %.2f%%, number_of_files: %zu, chunks_count: %" PRIu64 "\n",
+               s.archive_size, s.total_orig, ratio, s.files.size(), s.unique_chunks);
+        printf("%10s  File Path\n", "Size (Bytes)");
+        printf("----------  --------------------\n");
+        for (auto& f : s.files) printf("%10" PRIu64 "  %s\n", f.second, f.first.c_str());
+        return;
+    }
+    // cmd/mod.rs:60-158 (same labels and values; plain two-column layout)
+    printf("\nSquash breakdown:\n Squash Summary\n");
+    printf(" %-20s %s\n", "Creation Date (UTC)", date_of(s.timestamp).c_str());
+    printf(" %-20s %s\n", "Squish Version", s.version.c_str());
+    printf(" %-20s %s\n", "Compressed size", format_bytes(s.archive_size).c_str());
+    printf(" %-20s %s\n", "Original size", format_bytes(s.total_orig).c_str());
+    printf(" %-20s %.1f%%\n", "Compression Ratio", ratio);
+    printf(" %-20s %s\n", "Number of files", with_commas(s.files.size()).c_str());
+    printf(" %-20s %s\n", "Number of chunks", with_commas(s.unique_chunks).c_str());
+    std::map<std::string, size_t> dirs;
+    for (auto& f : s.files) dirs[f.first.substr(0, f.first.find('/'))]++;
+    std::vector<std::pair<std::string, size_t>> v(dirs.begin(), dirs.end());
+    std::stable_sort(v.begin(), v.end(), [](auto& a, auto& b) { return a.second > b.second; });
+    printf("\nTop-level directory breakdown:\n %-30s %s\n", "Directory", "File Count");
+    for (auto& d : v) printf(" %-30s %s\n", d.first.c_str(), with_commas(d.second).c_str());
+}
+
+static int usage() {
+    fprintf(stderr,
+            "Compact, compress, and deduplicate files into a single archive\n\n"
+            "Usage: squishrs [OPTIONS] <COMMAND>\n\nCommands:\n"
+            "  pack    Pack a directory\n  list    List files in an archive\n  unpack  Extract archive contents\n\n"
+            "Options:\n  -j, --max-threads <MAX_THREADS>  [default: 25]\n"
+            "      --device <ORDINAL>           GPU ordinal [default: 0]\n");
+    return 2;
+}
+
+int main(int argc, char** argv) {
+    g_tty = isatty(1);
+    std::vector<std::string> pos;
+    std::string output;
+    bool simple = false, have_output = false;
+    int device = 0;
+    long max_threads = 25; // cmd/mod.rs:16 (host worker count; the GPU path does not use Rayon)
+    for (int i = 1; i < argc; i++) {
+        std::string a = argv[i];
+        if ((a == "-j" || a == "--max-threads") && i + 1 < argc)
+            max_threads = atol(argv[++i]);
+        else if (a.rfind("--max-threads=", 0) == 0)
+            max_threads = atol(a.c_str() + 14);
+        else if ((a == "-o" || a == "--output") && i + 1 < argc) {
+            output = argv[++i];
+            have_output = true;
+        } else if (a == "--simple")
+            simple = true;
+        else if (a == "--device" && i + 1 < argc)
+            device = atoi(argv[++i]);
+        else if (a == "-h" || a == "--help")
+            return usage();
+        else
+            pos.push_back(a);
+    }
+    (void)max_threads;
+    try {
+        if (pos.size() < 2) return usage();
+        if (pos[0] == "pack") {
+            std::string input = pos[1];
+            if (!have_output) output = input + ".squish"; // lib.rs:31 (untrimmed input)
+            uint64_t batch = 1ull << 30;
+            if (const char* e = getenv("SQUISH_BATCH_BYTES")) batch = strtoull(e, nullptr, 10);
+            uint64_t sz = pack(input, output, device, batch);
+            std::string shown = output.rfind("./", 0) == 0 ? output.substr(2) : output;
+            printf("%s\nCompressed to %s\n%s: %s\n", green("Packing complete!").c_str(), shown.c_str(),
+                   blue("Final archive size").c_str(), format_bytes(sz).c_str()); // lib.rs:49-55
+        } else if (pos[0] == "list") {
+            list_cmd(pos[1], simple);
+        } else if (pos[0] == "unpack") {
+            // decode side: SURVEY.md 8(f) row f2, scheduled after the pack path; archives written
+            // here are unpacked by the reference's own `squishrs unpack`
+            throw AppError{"Unknown error: unpack is not part of this build (pack-side hot path only)"};
+        } else
+            return usage();
+    } catch (const AppError& e) {
+        fprintf(stderr, "%s: %s\n", red("Error").c_str(), e.msg.c_str()); // main.rs:6-9
+        return 1;
+    }
+    return 0;
+}

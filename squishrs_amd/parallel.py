@@ -1,0 +1,62 @@
+"""Multi-GPU pack path: one process per GPU, chunks sharded in contiguous
+global index ranges, ONE collective -- an all-gather of the per-rank 16-byte hashes (RCCL over xGMI
+when the backend is "nccl"; "gloo" in the CPU tests) -- after which every rank resolves "first
+occurrence in global index order" identically and compresses only its own new chunks.
+
+The reference has no distributed code; the dedup rule reproduced is ChunkStore::insert's
+exactly-once-per-hash (src/util/chunk.rs:80-100) in the canonical `-j 1` order (App. E).
+
+`stages` is the object that runs the three device stages; the product passes a ChunkStore (HIP).
+Tests inject a CPU stand-in to exercise the collective/host logic under gloo."""
+from typing import Optional
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+
+def shard_range(n_total: int, rank: int, world: int):
+    """Contiguous split of [0, n_total) -- global index = first + local index."""
+    base, rem = divmod(n_total, world)
+    first = rank * base + min(rank, rem)
+    return first, base + (1 if rank < rem else 0)
+
+
+class ShardedPacker:
+    def __init__(self, stages, group: Optional[dist.ProcessGroup] = None):
+        self.stages = stages
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+
+    def gather_hashes(self, hashes: torch.Tensor, n_local: int):
+        """All-gather of the ranks' hash arrays (16 B x n_local, padded to the max count).
+        Returns (all_hashes in global index order, n_total, my_first)."""
+        if self.world == 1:
+            return hashes[: n_local * 16], n_local, 0
+        dev = hashes.device
+        cnt = torch.tensor([n_local], dtype=torch.int64, device=dev)
+        counts = torch.zeros(self.world, dtype=torch.int64, device=dev)
+        dist.all_gather_into_tensor(counts, cnt, group=self.group)
+        counts_h = counts.cpu().numpy()
+        n_max = int(counts_h.max())
+        n_total = int(counts_h.sum())
+        my_first = int(counts_h[: self.rank].sum())
+        send = hashes[: n_max * 16]
+        if n_local < n_max:
+            send = torch.zeros(n_max * 16, dtype=torch.uint8, device=dev)
+            send[: n_local * 16] = hashes[: n_local * 16]
+        recv = torch.empty(self.world * n_max * 16, dtype=torch.uint8, device=dev)
+        dist.all_gather_into_tensor(recv, send.contiguous(), group=self.group)
+        if (counts_h == n_max).all():
+            return recv, n_total, my_first
+        parts = [recv[r * n_max * 16: r * n_max * 16 + int(counts_h[r]) * 16] for r in range(self.world)]
+        return torch.cat(parts), n_total, my_first
+
+    def pack(self, data, offs: np.ndarray, lens: np.ndarray, hashes, is_new, comp):
+        """hash -> all-gather -> global dedup -> compress own new chunks.  Returns comp_off."""
+        n = len(lens)
+        self.stages.hash_device(data, offs, lens, hashes)
+        all_hashes, n_total, my_first = self.gather_hashes(hashes, n)
+        self.stages.dedup_device(all_hashes, n_total, my_first, n, is_new)
+        return self.stages.compress_device(data, offs, lens, is_new, comp)

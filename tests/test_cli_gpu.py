@@ -1,0 +1,97 @@
+"""GPU: the C++ `squishrs` host driver (pack through sq_pack_batch) against the oracle's .squish
+restatement -- whole archive byte-identical except the 8 timestamp bytes --
+plus the reference's CLI behaviours from tests/cli_tests.rs that do not need `unpack`."""
+import json
+import os
+import subprocess
+
+import pytest
+
+import corpus
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CLI = os.path.join(ROOT, "squishrs_amd", "host", "squishrs")
+
+
+def _manifest_order(arch: bytes):
+    count = int.from_bytes(arch[19:27], "little")
+    pos = 27
+    for _ in range(count):
+        csz = int.from_bytes(arch[pos + 24:pos + 32], "little")
+        pos += 32 + csz
+    n = int.from_bytes(arch[pos:pos + 4], "little")
+    pos += 4
+    names = []
+    for _ in range(n):
+        pl = int.from_bytes(arch[pos:pos + 4], "little")
+        names.append(arch[pos + 4:pos + 4 + pl].decode())
+        pos += 4 + pl + 8
+        cc = int.from_bytes(arch[pos:pos + 4], "little")
+        pos += 4 + 16 * cc
+    assert pos == len(arch)
+    return names
+
+
+def _run(*args, cwd=None):
+    return subprocess.run([CLI, *args], cwd=cwd, capture_output=True, text=True, timeout=600)
+
+
+def test_pack_tree_byte_identical_to_oracle(tmp_path, oracle):
+    assert os.path.exists(CLI), "run __graft_entry__.build()"
+    tree = tmp_path / "in"
+    files = {
+        "a.txt": b"hello squish",
+        "empty.bin": b"",
+        "sub/text.txt": corpus.text_like(1, 300000),
+        "sub/dup.txt": corpus.text_like(1, 300000),           # exact duplicate -> one record
+        "sub/deep/random.bin": corpus.random_bytes(5, 1, 70000),
+        "big/mixed.bin": corpus.mixed(4, 2 * 2097152 + 12345),  # 3 chunks, tail of 12,345 B (btopt)
+        "big/zeros.bin": bytes(2097152 + 100),
+    }
+    for rel, data in files.items():
+        p = tree / rel
+        p.parent.mkdir(parents=True, exist_ok=True)
+        p.write_bytes(data)
+    out = tmp_path / "out.squish"
+    r = _run("pack", str(tree), "-o", str(out))
+    assert r.returncode == 0, r.stderr
+    assert "Packing complete!" in r.stdout and "Final archive size" in r.stdout
+    arch = out.read_bytes()
+    order = _manifest_order(arch)
+    assert sorted(order) == sorted(files)
+    exp = oracle.pack_archive([(rel, files[rel]) for rel in order], timestamp=0)
+    assert arch[:11] == b"squish1.2.0"
+    assert arch[19:] == exp[19:], "archive differs from the oracle restatement"
+    assert len(arch) == os.path.getsize(out)
+    # list --simple
+    r = _run("list", str(out), "--simple")
+    assert r.returncode == 0 and f"number_of_files: {len(files)}" in r.stdout
+
+
+def test_roundtrip_fixture_of_reference(tmp_path):
+    # tests/roundtrip.rs: one file "file.txt" = "hello squish" -> the 124-byte archive of App. A
+    fx = json.load(open(os.path.join(ROOT, "tests", "golden", "roundtrip_hello_squish.json")))
+    d = tmp_path / "in"
+    d.mkdir()
+    (d / "file.txt").write_bytes(b"hello squish")
+    out = tmp_path / "o.squish"
+    assert _run("pack", str(d), "-o", str(out)).returncode == 0
+    got = out.read_bytes()
+    exp = bytes.fromhex(fx["archive"])
+    assert len(got) == 124 and got[:11] == exp[:11] and got[19:] == exp[19:]
+
+
+def test_empty_dir_and_errors(tmp_path):
+    d = tmp_path / "empty"
+    d.mkdir()
+    out = tmp_path / "e.squish"
+    assert _run("pack", str(d), "-o", str(out)).returncode == 0
+    r = _run("list", str(out), "--simple")
+    assert r.returncode == 0 and "number_of_files: 0" in r.stdout       # cli_tests.rs:55-80
+    bad = tmp_path / "garbage.squish"
+    bad.write_bytes(b"this is not an archive at all")
+    r = _run("list", str(bad))
+    assert r.returncode != 0 and "Error" in r.stderr                    # cli_tests.rs:82-99
+    r = _run("list", str(tmp_path / "missing.squish"))
+    assert r.returncode != 0 and "Error" in r.stderr                    # cli_tests.rs:101-120

@@ -1,0 +1,127 @@
+"""CPU (gloo, world_size 2): the multi-GPU sharding + hash all-gather + global first-occurrence
+logic of squishrs_amd/parallel.py, with an oracle-backed stand-in for the device stages (test
+infrastructure; the product passes a HIP ChunkStore)."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+class OracleStages:
+    """Stand-in with the ChunkStore stage API; hashing/compression by the CPU oracle."""
+
+    def __init__(self):
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import oracle_lib
+        self.o = oracle_lib.load()
+        self.seen = set()
+
+    def hash_device(self, data, offs, lens, hashes):
+        d = data.numpy()
+        for i, (o_, l_) in enumerate(zip(offs, lens)):
+            h = self.o.hash_chunk(d[int(o_):int(o_) + int(l_)].tobytes())
+            hashes[16 * i:16 * i + 16] = torch.frombuffer(bytearray(h), dtype=torch.uint8)
+
+    def dedup_device(self, all_hashes, n_total, my_first, my_n, is_new):
+        hs = all_hashes.numpy().reshape(-1, 16)
+        for g in range(n_total):            # commit ALL hashes in global order (sq_dedup_global)
+            k = hs[g].tobytes()
+            new = k not in self.seen
+            self.seen.add(k)
+            if my_first <= g < my_first + my_n:
+                is_new[g - my_first] = 1 if new else 0
+
+    def compress_device(self, data, offs, lens, select, comp):
+        d = data.numpy()
+        off = np.zeros(len(lens) + 1, dtype=np.uint64)
+        pos = 0
+        for i, (o_, l_) in enumerate(zip(offs, lens)):
+            off[i] = pos
+            if select[i]:
+                f = self.o.compress_chunk(d[int(o_):int(o_) + int(l_)].tobytes())
+                comp[pos:pos + len(f)] = torch.frombuffer(bytearray(f), dtype=torch.uint8)
+                pos += len(f)
+        off[len(lens)] = pos
+        return off
+
+
+def _make_chunks():
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import corpus
+    base = [corpus.text_like(i, 3000 + 500 * i) for i in range(6)]
+    # global order with cross-shard duplicates: 11 chunks, shard0 gets 6, shard1 gets 5
+    order = [0, 1, 2, 0, 3, 1, 4, 2, 5, 5, 3]
+    return [base[i] for i in order], order
+
+
+def _worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    sys.path.insert(0, ROOT)
+    from squishrs_amd.parallel import ShardedPacker, shard_range
+    chunks, order = _make_chunks()
+    first, n = shard_range(len(chunks), rank, world)
+    mine = chunks[first:first + n]
+    lens = np.array([len(c) for c in mine], dtype=np.uint32)
+    offs = np.zeros(n, dtype=np.uint64)
+    offs[1:] = np.cumsum(lens.astype(np.uint64))[:-1]
+    data = torch.frombuffer(bytearray(b"".join(mine)), dtype=torch.uint8)
+    hashes = torch.zeros(n * 16, dtype=torch.uint8)
+    is_new = torch.zeros(n, dtype=torch.uint8)
+    comp = torch.zeros(int(lens.sum()) + 4096, dtype=torch.uint8)
+    st = OracleStages()
+    p = ShardedPacker(st)
+    coff = p.pack(data, offs, lens, hashes, is_new, comp)
+    q.put((rank, first, is_new.tolist(), len(st.seen), [int(x) for x in coff]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_shard_range_contiguous():
+    sys.path.insert(0, ROOT)
+    from squishrs_amd.parallel import shard_range
+    for n in (0, 1, 7, 8, 100000, 1000003):
+        for w in (1, 2, 4, 8):
+            tot = 0
+            for r in range(w):
+                f, c = shard_range(n, r, w)
+                assert f == tot
+                tot += c
+            assert tot == n
+
+
+def test_two_rank_global_first_occurrence():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    chunks, order = _make_chunks()
+    seen, exp = set(), []
+    for i in order:
+        exp.append(0 if i in seen else 1)
+        seen.add(i)
+    got = res[0][2] + res[1][2]
+    assert got == exp                                   # first occurrence in GLOBAL index order
+    assert res[0][3] == res[1][3] == len(seen)          # every rank ends with the same set
+    # duplicates produce empty frames; new chunks non-empty
+    for r in res:
+        off = r[4]
+        for j, flag in enumerate(r[2]):
+            assert (off[j + 1] - off[j] > 0) == bool(flag)
