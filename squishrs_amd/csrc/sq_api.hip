@@ -363,6 +363,14 @@ static int compress_async(sq_ctx* c, const u8* d_data, const u64* h_off, const u
     if ((r = c->b_misc.ensure(256))) return r;
     HIPCHK(hipMemsetAsync(c->b_misc.p, 0, 256, c->stream));
 
+    if (getenv("SQ_DEBUG")) {
+        int nb = 0;
+        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, sqz::k_compress_batch, 64, 0);
+        hipFuncAttributes fa;
+        (void)hipFuncGetAttributes(&fa, (const void*)sqz::k_compress_batch);
+        fprintf(stderr, "[squish_gpu] compress kernel: occupancy %d blocks/CU, regs %d, lds %zu, scratch %zu; waves %u, ws_each %zu\n",
+                nb, fa.numRegs, fa.sharedSizeBytes, fa.localSizeBytes, waves, ws_each);
+    }
     HIPCHK(hipEventRecord(c->ev[4], c->stream));
     {
         dim3 block(64), grid(waves);
@@ -410,6 +418,21 @@ static int compress_async(sq_ctx* c, const u8* d_data, const u64* h_off, const u
     HIPCHK(hipMemcpyAsync(h_err, (u32*)c->b_misc.p + 16, 4, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
     HIPCHK(hipEventElapsedTime(&c->last.compress_ms, c->ev[4], c->ev[5]));
+#ifdef SQ_PROF
+    {   // profiling build: sum the per-wave phase timers (100 MHz ticks) and print them
+        std::vector<unsigned long long> tot(13, 0), one(13);
+        for (u32 w = 0; w < waves; w++) {
+            (void)hipMemcpy(one.data(), (u8*)c->b_ws.p + (size_t)(w + 1) * ws_each - 512, 13 * 8, hipMemcpyDeviceToHost);
+            for (int k = 0; k < 13; k++) tot[k] += one[k];
+        }
+        static const char* nm[13] = {"frame_total", "table_clear", "dubt_update", "dubt_find", "row_update", "row_find",
+                                     "entropy", "copies", "presplit", "-", "-", "-", "chunks+1"};
+        fprintf(stderr, "[squish_gpu prof] waves=%u kernel=%.2f ms; per-wave mean ms:", waves, c->last.compress_ms);
+        for (int k = 0; k < 13; k++)
+            if (nm[k][0] != '-') fprintf(stderr, " %s=%.3f", nm[k], k == 12 ? (double)tot[k] / waves : (double)tot[k] / waves / 1e5);
+        fprintf(stderr, "\n");
+    }
+#endif
     if (*h_err) return SQ_E_COMPRESS;
     if (h_comp_off[n] > comp_cap) return SQ_E_CAP;
     HIPCHK(hipEventRecord(c->ev[6], c->stream));

@@ -44,3 +44,43 @@ SQ_DEV u64 sq_rd64(const u8* p) {
     __builtin_memcpy(&v, p, 8);
     return v;
 }
+
+// ---- explicit address spaces -------------------------------------------------------------------
+// Pointers that travel through structs / non-inlined calls degrade to generic ("flat") pointers;
+// flat_load/flat_store count on BOTH vmcnt and lgkmcnt and complete out of order, so hipcc drains
+// every counter to 0 before using a flat load's result -- which serialises all pipelined loads.
+// Every table / chunk / output byte of the compressor lives in global memory (HBM) and every
+// statistic in LDS, so the hot primitives assert the address space at the access:
+//   sq_g*  : global (address_space 1)  -> global_load_* / global_store_*
+//   SQ_L   : LDS    (address_space 3)  -> ds_*
+#if SQ_ON_DEVICE
+#define SQ_G __attribute__((address_space(1)))
+#define SQ_L __attribute__((address_space(3)))
+typedef u16 __attribute__((aligned(1))) sq_u16_ua;
+typedef u32 __attribute__((aligned(1))) sq_u32_ua;
+typedef u64 __attribute__((aligned(1))) sq_u64_ua;
+typedef u32 sq_v4u __attribute__((ext_vector_type(4)));
+typedef u32 sq_v2u __attribute__((ext_vector_type(2)));
+typedef sq_v4u __attribute__((aligned(1))) sq_v4u_ua;
+SQ_DEV u32 sq_grd8(const u8* p) { return *(const SQ_G u8*)p; }
+SQ_DEV u32 sq_grd16(const u8* p) { return *(const SQ_G sq_u16_ua*)p; }
+SQ_DEV u32 sq_grd32(const u8* p) { return *(const SQ_G sq_u32_ua*)p; }
+SQ_DEV u64 sq_grd64(const u8* p) { return *(const SQ_G sq_u64_ua*)p; }
+SQ_DEV sq_v4u sq_grd128(const u8* p) { return *(const SQ_G sq_v4u_ua*)p; }
+SQ_DEV void sq_gwr128(u8* p, sq_v4u v) { *(SQ_G sq_v4u_ua*)p = v; }
+SQ_DEV void sq_gwr8(u8* p, u32 v) { *(SQ_G u8*)p = (u8)v; }
+SQ_DEV u32 sq_gld32(const u32* p) { return *(const SQ_G u32*)p; }          // aligned table word
+SQ_DEV void sq_gst32(u32* p, u32 v) { *(SQ_G u32*)p = v; }
+SQ_DEV sq_v2u sq_gld64v(const u32* p) { return *(const SQ_G sq_v2u*)p; }   // 8-byte aligned pair
+SQ_DEV void sq_gst64v(u32* p, u32 a, u32 b) { *(SQ_G sq_v2u*)p = (sq_v2u){a, b}; }
+#else
+#define SQ_G
+#define SQ_L
+SQ_DEV u32 sq_grd8(const u8* p) { return *p; }
+SQ_DEV u32 sq_grd16(const u8* p) { return sq_rd16(p); }
+SQ_DEV u32 sq_grd32(const u8* p) { return sq_rd32(p); }
+SQ_DEV u64 sq_grd64(const u8* p) { return sq_rd64(p); }
+SQ_DEV void sq_gwr8(u8* p, u32 v) { *p = (u8)v; }
+SQ_DEV u32 sq_gld32(const u32* p) { return *p; }
+SQ_DEV void sq_gst32(u32* p, u32 v) { *p = v; }
+#endif

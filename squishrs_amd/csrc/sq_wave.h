@@ -28,9 +28,11 @@ SQ_DEV u32 wv_readlane(u32 v, u32 l) { return (u32)__builtin_amdgcn_readlane((in
 SQ_DEV u64 wv_readlane64(u64 v, u32 l) {
     return ((u64)wv_readlane((u32)(v >> 32), l) << 32) | wv_readlane((u32)v, l);
 }
-// order LDS / global accesses made by different lanes of this wave (compiler-level only: one
-// wave executes its memory instructions in program order)
-SQ_DEV void wv_fence() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); }
+// Order LDS / global accesses made by different lanes of this wave.  One wave issues its LDS
+// and its vector-memory instructions in program order, so all that is needed is to stop the
+// COMPILER from moving accesses across this point; a __builtin_amdgcn_fence (even at wavefront
+// scope) makes hipcc drain vmcnt/lgkmcnt to 0, which serialises every pipelined load behind it.
+SQ_DEV void wv_fence() { asm volatile("" ::: "memory"); }
 #else
 #define SQ_LDS static thread_local
 #define SQ_NOINLINE static __attribute__((noinline))
@@ -51,51 +53,51 @@ SQ_DEV void wv_fence() {}
 // ---- uniform global memory access: all lanes read one address; lane 0 alone writes ------------
 SQ_DEV u32 gld32(const u32* p) {
 #if SQ_ON_DEVICE
-    return wv_uni(*p);
+    return wv_uni(sq_gld32(p));
 #else
     return *p;
 #endif
 }
 SQ_DEV u32 gld8(const u8* p) {
 #if SQ_ON_DEVICE
-    return wv_uni(*p);
+    return wv_uni(sq_grd8(p));
 #else
     return *p;
 #endif
 }
 SQ_DEV u32 gld16(const u16* p) {
 #if SQ_ON_DEVICE
-    return wv_uni(*p);
+    return wv_uni(*(const SQ_G u16*)p);
 #else
     return *p;
 #endif
 }
 SQ_DEV void gst32(u32* p, u32 v) {
 #if SQ_ON_DEVICE
-    if (wv_lane() == 0) *p = v;
+    if (wv_lane() == 0) sq_gst32(p, v);
 #else
     *p = v;
 #endif
 }
 SQ_DEV void gst16(u16* p, u32 v) {
 #if SQ_ON_DEVICE
-    if (wv_lane() == 0) *p = (u16)v;
+    if (wv_lane() == 0) *(SQ_G u16*)p = (u16)v;
 #else
     *p = (u16)v;
 #endif
 }
 SQ_DEV void gst8(u8* p, u32 v) {
 #if SQ_ON_DEVICE
-    if (wv_lane() == 0) *p = (u8)v;
+    if (wv_lane() == 0) sq_gwr8(p, v);
 #else
     *p = (u8)v;
 #endif
 }
 // uniform unaligned source reads (chunk bytes are never written by the kernel)
-SQ_DEV u32 srd32(const u8* p) { return wv_uni(sq_rd32(p)); }
-SQ_DEV u64 srd64(const u8* p) { return wv_uni64(sq_rd64(p)); }
-SQ_DEV u32 srd16(const u8* p) { return wv_uni(sq_rd16(p)); }
-SQ_DEV u32 srd8(const u8* p) { return wv_uni(*p); }
+SQ_DEV u32 srd32(const u8* p) { return wv_uni(sq_grd32(p)); }
+SQ_DEV u64 srd64(const u8* p) { return wv_uni64(sq_grd64(p)); }
+SQ_DEV u32 srd16(const u8* p) { return wv_uni(sq_grd16(p)); }
+SQ_DEV u32 srd8(const u8* p) { return wv_uni(sq_grd8(p)); }
 
 // ---- wv_count: length of the common prefix of a[0..maxLen) and b[..] (ZSTD_count) -------------
 SQ_DEV u32 wv_count(const u8* a, const u8* b, u32 maxLen) {
@@ -110,11 +112,11 @@ SQ_DEV u32 wv_count(const u8* a, const u8* b, u32 maxLen) {
         const u32 o = base + lane * 8;
         u64 x;
         if (o + 8 <= maxLen) {
-            x = sq_rd64(a + o) ^ sq_rd64(b + o);
+            x = sq_grd64(a + o) ^ sq_grd64(b + o);
         } else if (o < maxLen) {
             const u32 valid = maxLen - o; // 1..7
             x = 0;
-            for (u32 k = 0; k < valid; k++) x |= (u64)(u8)(a[o + k] ^ b[o + k]) << (8 * k);
+            for (u32 k = 0; k < valid; k++) x |= (u64)(u8)(sq_grd8(a + o + k) ^ sq_grd8(b + o + k)) << (8 * k);
             x |= 1ull << (8 * valid); // stop at the limit
         } else {
             x = 1; // beyond the limit
@@ -135,13 +137,77 @@ SQ_DEV u32 wv_count(const u8* a, const u8* b, u32 maxLen) {
 #endif
 }
 
+// uniform 8-byte load of two adjacent table words (p 8-byte aligned)
+SQ_DEV void gld_pair(const u32* p, u32* a, u32* b) {
+#if SQ_ON_DEVICE
+    sq_v2u v = sq_gld64v(p);
+    *a = wv_uni(v.x);
+    *b = wv_uni(v.y);
+#else
+    *a = p[0];
+    *b = p[1];
+#endif
+}
+
+// wv_count plus the ordering of the first differing byte: *bLess = (b[len] < a[len]) when
+// len < maxLen (undefined otherwise).  Saves the separate byte-compare round trip of the tree walks.
+SQ_DEV u32 wv_count_cmp(const u8* a, const u8* b, u32 maxLen, u32* bLess) {
+#if SQ_ON_DEVICE
+    const u32 lane = wv_lane();
+    if (maxLen >= 8) {
+        u64 const wa = srd64(a), wb = srd64(b);
+        u64 const x = wa ^ wb;
+        if (x) {
+            u32 const k = (u32)(__builtin_ctzll(x) >> 3);
+            *bLess = ((wb >> (8 * k)) & 0xFF) < ((wa >> (8 * k)) & 0xFF);
+            return k;
+        }
+    }
+    for (u32 base = 0; base < maxLen; base += 512) {
+        const u32 o = base + lane * 8;
+        u64 x, wa = 0, wb = 0;
+        if (o + 8 <= maxLen) {
+            wa = sq_grd64(a + o);
+            wb = sq_grd64(b + o);
+            x = wa ^ wb;
+        } else if (o < maxLen) {
+            const u32 valid = maxLen - o; // 1..7
+            for (u32 k = 0; k < valid; k++) {
+                wa |= (u64)sq_grd8(a + o + k) << (8 * k);
+                wb |= (u64)sq_grd8(b + o + k) << (8 * k);
+            }
+            x = (wa ^ wb) | (1ull << (8 * valid)); // stop at the limit
+        } else {
+            x = 1; // beyond the limit
+        }
+        const u64 m = wv_ballot(x != 0);
+        if (m) {
+            const u32 first = (u32)__builtin_ctzll(m);
+            const u64 xv = wv_readlane64(x, first);
+            const u32 k = (u32)(__builtin_ctzll(xv) >> 3);
+            u32 r = base + first * 8 + k;
+            if (r >= maxLen) return maxLen;
+            const u64 av = wv_readlane64(wa, first), bv = wv_readlane64(wb, first);
+            *bLess = ((bv >> (8 * k)) & 0xFF) < ((av >> (8 * k)) & 0xFF);
+            return r;
+        }
+    }
+    return maxLen;
+#else
+    u32 n = 0;
+    while (n < maxLen && a[n] == b[n]) n++;
+    if (n < maxLen) *bLess = b[n] < a[n];
+    return n;
+#endif
+}
+
 // ---- coalesced fill / copy / compare ---------------------------------------------------------
 SQ_DEV void wv_fill32(u32* dst, u32 v, size_t nwords) { // dst 16-byte aligned, nwords % 4 == 0
 #if SQ_ON_DEVICE
-    uint4 q = make_uint4(v, v, v, v);
-    uint4* d = (uint4*)dst;
+    sq_v4u q = (sq_v4u){v, v, v, v};
+    u8* d = (u8*)dst;
     const size_t n16 = nwords / 4;
-    for (size_t i = wv_lane(); i < n16; i += 64) d[i] = q;
+    for (size_t i = wv_lane(); i < n16; i += 64) sq_gwr128(d + 16 * i, q);
 #else
     for (size_t i = 0; i < nwords; i++) dst[i] = v;
 #endif
@@ -150,13 +216,18 @@ SQ_DEV void wv_memcpy(u8* dst, const u8* src, u32 n) {
 #if SQ_ON_DEVICE
     const u32 lane = wv_lane();
     u32 pos = lane * 16;
-    for (; pos + 16 <= n; pos += 1024) {
-        uint4 v;
-        __builtin_memcpy(&v, src + pos, 16);
-        __builtin_memcpy(dst + pos, &v, 16);
+    // 4 KiB per iteration: four independent 16 B/lane loads in flight before the stores
+    for (; pos + 3 * 1024 + 16 <= n; pos += 4096) {
+        sq_v4u v0 = sq_grd128(src + pos), v1 = sq_grd128(src + pos + 1024), v2 = sq_grd128(src + pos + 2048),
+               v3 = sq_grd128(src + pos + 3072);
+        sq_gwr128(dst + pos, v0);
+        sq_gwr128(dst + pos + 1024, v1);
+        sq_gwr128(dst + pos + 2048, v2);
+        sq_gwr128(dst + pos + 3072, v3);
     }
+    for (; pos + 16 <= n; pos += 1024) sq_gwr128(dst + pos, sq_grd128(src + pos));
     if (pos < n)
-        for (u32 k = pos; k < n; k++) dst[k] = src[k]; // the single partial lane
+        for (u32 k = pos; k < n; k++) sq_gwr8(dst + k, sq_grd8(src + k)); // the single partial lane
     wv_fence();
 #else
     memcpy(dst, src, n);
@@ -169,9 +240,9 @@ SQ_DEV u32 wv_is_rle(const u8* src, u32 n) {
     const u64 pat = 0x0101010101010101ull * b0;
     bool bad = false;
     u32 pos = wv_lane() * 8;
-    for (; pos + 8 <= n; pos += 512) bad |= (sq_rd64(src + pos) != pat);
+    for (; pos + 8 <= n; pos += 512) bad |= (sq_grd64(src + pos) != pat);
     if (pos < n)
-        for (u32 k = pos; k < n; k++) bad |= (src[k] != (u8)b0);
+        for (u32 k = pos; k < n; k++) bad |= (sq_grd8(src + k) != b0);
     return wv_ballot(bad) == 0;
 #else
     for (u32 i = 1; i < n; i++)
@@ -184,7 +255,8 @@ SQ_DEV u32 wv_is_rle(const u8* src, u32 n) {
 // Returns nothing; count must be zeroed by the caller via wv_zero_lds.
 SQ_DEV void wv_zero_lds(u32* p, u32 nwords) {
 #if SQ_ON_DEVICE
-    for (u32 i = wv_lane(); i < nwords; i += 64) p[i] = 0;
+    SQ_L u32* const lp = (SQ_L u32*)p;
+    for (u32 i = wv_lane(); i < nwords; i += 64) lp[i] = 0;
     wv_fence();
 #else
     for (u32 i = 0; i < nwords; i++) p[i] = 0;
@@ -193,16 +265,41 @@ SQ_DEV void wv_zero_lds(u32* p, u32 nwords) {
 SQ_DEV void wv_hist_bytes(u32* count /*LDS*/, const u8* src, u32 n) {
 #if SQ_ON_DEVICE
     const u32 lane = wv_lane();
-    u32 pos = lane * 4;
-    for (; pos + 4 <= n; pos += 256) {
-        u32 w = sq_rd32(src + pos);
-        atomicAdd(&count[w & 0xFF], 1u);
-        atomicAdd(&count[(w >> 8) & 0xFF], 1u);
-        atomicAdd(&count[(w >> 16) & 0xFF], 1u);
-        atomicAdd(&count[w >> 24], 1u);
+    SQ_L u32* const lc = (SQ_L u32*)count;
+    u32 pos = lane * 16;
+    // 16 B per lane per load, two loads in flight
+    for (; pos + 1024 + 16 <= n; pos += 2048) {
+        sq_v4u a = sq_grd128(src + pos), b = sq_grd128(src + pos + 1024);
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            u32 w = a[k];
+            __hip_atomic_fetch_add(&lc[w & 0xFF], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            __hip_atomic_fetch_add(&lc[(w >> 8) & 0xFF], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            __hip_atomic_fetch_add(&lc[(w >> 16) & 0xFF], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            __hip_atomic_fetch_add(&lc[w >> 24], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            u32 w = b[k];
+            __hip_atomic_fetch_add(&lc[w & 0xFF], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            __hip_atomic_fetch_add(&lc[(w >> 8) & 0xFF], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            __hip_atomic_fetch_add(&lc[(w >> 16) & 0xFF], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            __hip_atomic_fetch_add(&lc[w >> 24], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+    }
+    for (; pos + 16 <= n; pos += 1024) {
+        sq_v4u a = sq_grd128(src + pos);
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            u32 w = a[k];
+            __hip_atomic_fetch_add(&lc[w & 0xFF], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            __hip_atomic_fetch_add(&lc[(w >> 8) & 0xFF], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            __hip_atomic_fetch_add(&lc[(w >> 16) & 0xFF], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            __hip_atomic_fetch_add(&lc[w >> 24], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
     }
     if (pos < n)
-        for (u32 k = pos; k < n; k++) atomicAdd(&count[src[k]], 1u);
+        for (u32 k = pos; k < n; k++) __hip_atomic_fetch_add(&lc[sq_grd8(src + k)], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     wv_fence();
 #else
     for (u32 i = 0; i < n; i++) count[src[i]]++;
@@ -213,8 +310,9 @@ SQ_DEV void wv_max_and_last(const u32* p /*LDS*/, u32 n, u32* maxOut, u32* lastN
 #if SQ_ON_DEVICE
     const u32 lane = wv_lane();
     u32 mx = 0, last = 0;
+    const SQ_L u32* const lp = (const SQ_L u32*)p;
     for (u32 i = lane; i < n; i += 64) {
-        u32 v = p[i];
+        u32 v = lp[i];
         mx = v > mx ? v : mx;
         if (v) last = i;
     }
@@ -252,9 +350,10 @@ SQ_DEV WvGroup wv_group(u32 key, bool active, u8* scratch /*LDS 2048 B*/) {
     g.gsize = 1;
     g.prevLane = 64;
     const u32 slot = (key * 2654435761u) >> 21; // 11 bits
-    if (active) scratch[slot] = (u8)lane;
+    SQ_L u8* const ls = (SQ_L u8*)scratch;
+    if (active) ls[slot] = (u8)lane;
     wv_fence();
-    bool loser = active && (scratch[slot] != (u8)lane);
+    bool loser = active && (ls[slot] != (u8)lane);
     u64 todo = wv_ballot(loser);
     const u64 act = wv_ballot(active);
     const u64 below = (lane == 0) ? 0ull : (~0ull >> (64 - lane));

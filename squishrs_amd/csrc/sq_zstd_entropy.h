@@ -64,8 +64,24 @@ struct LdsState {
     u8 grp[2048]; // wv_group scratch
     u32 ret[8];   // results handed from a serial region to the whole wave
     u32* trace;   // 56 debug words in the wave's workspace (read by the host watchdog)
+#ifdef SQ_PROF
+    unsigned long long prof[12]; // per-phase 100 MHz tick sums (profiling build only)
+#endif
 };
 SQ_LDS LdsState g_lds;
+
+// phase timers (profiling build only): s_memrealtime ticks (100 MHz) summed per phase
+#if defined(SQ_PROF) && SQ_ON_DEVICE
+#define PROF_T0(v) unsigned long long v = __builtin_amdgcn_s_memrealtime()
+#define PROF_ADD(slot, v)                                                              \
+    do {                                                                               \
+        unsigned long long e_ = __builtin_amdgcn_s_memrealtime();                      \
+        if (wv_lane() == 0) g_lds.prof[slot] += e_ - (v);                              \
+    } while (0)
+#else
+#define PROF_T0(v) do { } while (0)
+#define PROF_ADD(slot, v) do { } while (0)
+#endif
 
 // progress markers for bring-up: slot 0 = stage, others free-form
 #if SQ_ON_DEVICE
@@ -1239,6 +1255,7 @@ SQ_DEV void hist_stats(const u32* count, u32 maxIn, u32* maxOut, u32* mostFreque
 // 0 = emit a raw block, SQZ_ERR = internal error.
 SQ_DEVFN u32 entropy_compress_seqstore(const SeqStore& ss, const Entropy* prev, Entropy* next, u32 strategy,
                                        u8* dst, u32 dstCap, u32 blockSize) {
+    PROF_T0(t_ent);
     u32 const nbSeq = ss.nseq;
     u32 litSectionSize;
     {
@@ -1363,6 +1380,7 @@ SQ_DEVFN u32 entropy_compress_seqstore(const SeqStore& ss, const Entropy* prev, 
         g_lds.ret[2] = result;
     }
     wv_fence();
+    PROF_ADD(6, t_ent);
     return g_lds.ret[2];
 }
 

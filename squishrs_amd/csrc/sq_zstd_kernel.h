@@ -99,17 +99,18 @@ SQ_HD WsLayout ws_layout(u32 max_len) {
 SQ_HD size_t workspace_bytes(u32 max_len) { return ws_layout(max_len).total; }
 
 // ---------------------------------------------------------------- pre-block splitter (1.5.7)
-SQ_DEV u32 ps_hash2_10(const u8* p) { return ((u32)sq_rd16(p) * 0x9e3779b9U) >> 22; }
+SQ_DEV u32 ps_hash2_10(const u8* p) { return ((u32)sq_grd16(p) * 0x9e3779b9U) >> 22; }
 
 // recordFingerprint_generic(samplingRate 5, hashLog 10) over 8 KiB
 SQ_DEV void ps_record(Fingerprint* fp, const u8* src) {
     const u32 limit = 8192 - 2 + 1;
 #if SQ_ON_DEVICE
     const u32 lane = wv_lane();
-    for (u32 i = lane; i < 1024; i += 64) fp->events[i] = 0;
+    SQ_G u32* const ev = (SQ_G u32*)fp->events;
+    for (u32 i = lane; i < 1024; i += 64) ev[i] = 0;
     wv_fence();
-    for (u32 n = lane * 5; n < limit; n += 64 * 5) atomicAdd(&fp->events[ps_hash2_10(src + n)], 1u);
-    if (lane == 0) fp->nbEvents = limit / 5;
+    for (u32 n = lane * 5; n < limit; n += 64 * 5) __hip_atomic_fetch_add(&ev[ps_hash2_10(src + n)], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    if (lane == 0) sq_gst32(&fp->nbEvents, limit / 5);
     wv_fence();
 #else
     for (u32 i = 0; i < 1024; i++) fp->events[i] = 0;
@@ -123,7 +124,7 @@ SQ_DEV u32 ps_compare(const Fingerprint* ref, const Fingerprint* nw, int penalty
     const s64 nbA = (s64)gld32(&ref->nbEvents), nbB = (s64)gld32(&nw->nbEvents);
 #if SQ_ON_DEVICE
     for (u32 n = wv_lane(); n < 1024; n += 64) {
-        s64 d = (s64)ref->events[n] * nbB - (s64)nw->events[n] * nbA;
+        s64 d = (s64)sq_gld32(&ref->events[n]) * nbB - (s64)sq_gld32(&nw->events[n]) * nbA;
         distance += (u64)(d < 0 ? -d : d);
     }
     for (int m = 32; m >= 1; m >>= 1) {
@@ -145,8 +146,8 @@ SQ_DEV u32 ps_compare(const Fingerprint* ref, const Fingerprint* nw, int penalty
 SQ_DEV void ps_merge(Fingerprint* acc, const Fingerprint* nw) {
 #if SQ_ON_DEVICE
     const u32 lane = wv_lane();
-    for (u32 n = lane; n < 1024; n += 64) acc->events[n] += nw->events[n];
-    if (lane == 0) acc->nbEvents += nw->nbEvents;
+    for (u32 n = lane; n < 1024; n += 64) sq_gst32(&acc->events[n], sq_gld32(&acc->events[n]) + sq_gld32(&nw->events[n]));
+    if (lane == 0) sq_gst32(&acc->nbEvents, sq_gld32(&acc->nbEvents) + sq_gld32(&nw->nbEvents));
     wv_fence();
 #else
     for (u32 n = 0; n < 1024; n++) acc->events[n] += nw->events[n];
@@ -251,7 +252,9 @@ SQ_DEVFN u32 compressBlock_internal(MatchState& ms, SeqStore& ss, BlockState& bs
         }
         SQ_TRACE(0, 7);
         SQ_TRACE(4, ss.nseq);
+        PROF_T0(t_ll);
         if (lastLLSize) wv_memcpy(ss.lits + ss.nlits, src + srcSize - lastLLSize, lastLLSize);
+        PROF_ADD(7, t_ll);
         ss.nlits += lastLLSize;
         cSize = entropy_compress_seqstore(ss, &g_lds.ent[p], &g_lds.ent[nx], ms.cp.strategy, dst, dstCap, srcSize);
         SQ_TRACE(0, 9);
@@ -317,7 +320,9 @@ SQ_DEVFN u32 compress_frame_wave(const u8* src, u32 n, u8* dst, u32 cap, u8* ws,
     ms.hashLog3 = 0;
     ms.rowHashLog = 0;
     SQ_TRACE(0, 2);
+    PROF_T0(t_clr);
     wv_fill32(ms.hashTable, 0, (size_t)1 << cp.hashLog);
+    PROF_ADD(1, t_clr);
     SQ_TRACE(0, 3);
     if (cp.strategy == STRAT_LAZY2) {
         ms.rowHashLog = cp.hashLog - 6;
@@ -361,7 +366,9 @@ SQ_DEVFN u32 compress_frame_wave(const u8* src, u32 n, u8* dst, u32 cap, u8* ws,
     while (remaining) {
         SQ_TRACE(0, 4);
         SQ_TRACE(2, (u32)(ip - src));
+        PROF_T0(t_ps);
         u32 const blockSize = optimalBlockSize(ip, remaining, savings, (Fingerprint*)(ws + L.fp));
+        PROF_ADD(8, t_ps);
         SQ_TRACE(0, 5);
         SQ_TRACE(3, blockSize);
         u32 const lastBlock = (blockSize == remaining);
@@ -377,7 +384,9 @@ SQ_DEVFN u32 compress_frame_wave(const u8* src, u32 n, u8* dst, u32 cap, u8* ws,
                 op[1] = (u8)(h >> 8);
                 op[2] = (u8)(h >> 16);
             }
+            PROF_T0(t_raw);
             wv_memcpy(op + 3, ip, blockSize);
+            PROF_ADD(7, t_raw);
             cSize = 3 + blockSize;
         } else {
             u32 const h = (cSize == 1) ? lastBlock + (1u << 1) + (blockSize << 3) : lastBlock + (2u << 1) + (cSize << 3);
@@ -415,12 +424,17 @@ __device__ __noinline__ void compress_one(const u8* data, const u64* off, const 
 
 // Persistent compressor: grid = number of workspaces, block = one wave.  Each wave pulls chunk
 // indices from *queue until exhausted; every wave reaches the exit condition (idx >= n).
-__global__ void __launch_bounds__(64)
+__global__ void __launch_bounds__(64, 2) // 2 waves per SIMD: <= 256 registers, 8 waves per CU (LDS: 8 x 19 KiB)
 k_compress_batch(const u8* data, const u64* off, const u32* len, const u8* select, u32 n, u8* slots,
                  const u64* slot_off, u32* frame_len, u8* ws_pool, u64 ws_each, u32* queue, u32* err) {
     u8* const ws = ws_pool + (u64)blockIdx.x * ws_each;
     u32* const dbg = (u32*)(ws + ws_each - 256) + 8; // wave-level progress words for the watchdog
     u32 iter = 0;
+#ifdef SQ_PROF
+    if (wv_lane() == 0)
+        for (int k = 0; k < 12; k++) g_lds.prof[k] = 0;
+    wv_fence();
+#endif
     for (;;) {
         u32 idx = 0;
         if (wv_lane() == 0) idx = atomicAdd(queue, 1u);
@@ -432,9 +446,19 @@ k_compress_batch(const u8* data, const u64* off, const u32* len, const u8* selec
         iter++;
         if (idx >= n) break;
         bool const take = (select == nullptr) || (select[idx] != 0);
+        PROF_T0(t_all);
         if (take) compress_one(data, off, len, idx, slots, slot_off, frame_len, ws, err);
+        PROF_ADD(0, t_all);
     }
     if (wv_lane() == 0) dbg[11] = 777;
+#ifdef SQ_PROF
+    wv_fence();
+    if (wv_lane() == 0) {
+        unsigned long long* o = (unsigned long long*)(ws + ws_each - 512);
+        for (int k = 0; k < 12; k++) o[k] = g_lds.prof[k];
+        o[12] = iter;
+    }
+#endif
 }
 #endif
 

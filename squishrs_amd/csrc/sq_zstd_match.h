@@ -87,7 +87,9 @@ SQ_DEV u32 hash3(u32 v, u32 hBits) { return ((v << 8) * 506832829U) >> (32 - hBi
 
 // ZSTD_storeSeq: literal run copied by the wave, sequence record by lane 0
 SQ_DEV void storeSeq(SeqStore& ss, u32 litLength, const u8* literals, u32 offBase, u32 matchLength) {
+    PROF_T0(t_cp);
     if (litLength) wv_memcpy(ss.lits + ss.nlits, literals, litLength);
+    PROF_ADD(7, t_cp);
     ss.nlits += litLength;
     if (litLength > 0xFFFF) {
         ss.longLengthType = 1;
@@ -99,10 +101,7 @@ SQ_DEV void storeSeq(SeqStore& ss, u32 litLength, const u8* literals, u32 offBas
         ss.longLengthPos = ss.nseq;
     }
 #if SQ_ON_DEVICE
-    if (wv_lane() == 0) {
-        uint2 v = make_uint2(offBase, (litLength & 0xFFFF) | (mlBase << 16));
-        *(uint2*)&ss.seqs[ss.nseq] = v;
-    }
+    if (wv_lane() == 0) sq_gst64v((u32*)&ss.seqs[ss.nseq], offBase, (litLength & 0xFFFF) | (mlBase << 16));
 #else
     ss.seqs[ss.nseq].offBase = offBase;
     ss.seqs[ss.nseq].litLength = (u16)litLength;
@@ -122,25 +121,51 @@ SQ_DEVFN void dubt_update(MatchState& ms, u32 target) {
     u32 const btMask = (1u << (ms.cp.chainLog - 1)) - 1;
     const u8* const base = ms.base;
 #if SQ_ON_DEVICE
+    // Software-pipelined: U batches of 64 positions per iteration.  The hash-table gather of a
+    // batch feeds only that batch's bt store, while the scatter (new heads) needs just the
+    // position, so gather/scatter pairs of successive batches are issued back to back (one wave's
+    // memory operations to one address are performed in program order) and the bt stores are
+    // delayed to the end of the iteration: one memory round trip per U*64 positions.
     u32 const lane = wv_lane();
-    for (u32 idx0 = ms.nextToUpdate; idx0 < target; idx0 += 64) {
+    constexpr int U = 8;
+    u32 idx0 = ms.nextToUpdate;
+    for (; idx0 + 64 * U <= target; idx0 += 64 * U) {
+        u32 w[U], prev[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) w[u] = sq_grd32(base + idx0 + 64 * u + lane);
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            u32 const idx = idx0 + 64 * u + lane;
+            u32 const h = hash4(w[u], hashLog);
+            WvGroup const g = wv_group(h, true, g_lds.grp);
+            u32 pv = idx0 + 64 * u + g.prevLane;
+            if (g.prevLane >= 64) pv = sq_gld32(hashTable + h);
+            prev[u] = pv;
+            if (g.rank + 1 == g.gsize) sq_gst32(hashTable + h, idx);
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            u32 const idx = idx0 + 64 * u + lane;
+            sq_gst64v(bt + 2 * (idx & btMask), prev[u], SQZ_DUBT_UNSORTED);
+        }
+    }
+    for (; idx0 < target; idx0 += 64) {
         u32 const idx = idx0 + lane;
         bool const active = idx < target;
         u32 h = 0;
-        if (active) h = hash4(sq_rd32(base + idx), hashLog);
+        if (active) h = hash4(sq_grd32(base + idx), hashLog);
         WvGroup const g = wv_group(h, active, g_lds.grp);
         if (active) {
             u32 prev;
             if (g.prevLane < 64)
                 prev = idx0 + g.prevLane;
             else
-                prev = hashTable[h];
-            uint2 v = make_uint2(prev, SQZ_DUBT_UNSORTED);
-            *(uint2*)(bt + 2 * (idx & btMask)) = v;
-            if (g.rank + 1 == g.gsize) hashTable[h] = idx;
+                prev = sq_gld32(hashTable + h);
+            sq_gst64v(bt + 2 * (idx & btMask), prev, SQZ_DUBT_UNSORTED);
+            if (g.rank + 1 == g.gsize) sq_gst32(hashTable + h, idx);
         }
-        wv_fence();
     }
+    wv_fence();
 #else
     for (u32 idx = ms.nextToUpdate; idx < target; idx++) {
         u32 const h = hash4(sq_rd32(base + idx), hashLog);
@@ -153,7 +178,8 @@ SQ_DEVFN void dubt_update(MatchState& ms, u32 target) {
     ms.nextToUpdate = target;
 }
 
-// ZSTD_insertDUBT1 (noDict)
+// ZSTD_insertDUBT1 (noDict).  Per tree step ONE memory round trip: the node's two children are
+// fetched with one 8-byte load issued together with the match-extension loads.
 SQ_DEVFN void dubt_insert1(MatchState& ms, u32 curr, const u8* inputEnd, u32 nbCompares, u32 btLow) {
     u32* const bt = ms.chainTable;
     u32 const btMask = (1u << (ms.cp.chainLog - 1)) - 1;
@@ -167,11 +193,13 @@ SQ_DEVFN void dubt_insert1(MatchState& ms, u32 curr, const u8* inputEnd, u32 nbC
     u32 const windowLow = SQZ_WINDOW_START; // window always covers the whole chunk (see get_cparams)
     for (; nbCompares && (matchIndex > windowLow); --nbCompares) {
         u32* const nextPtr = bt + 2 * (matchIndex & btMask);
+        u32 child0, child1, mLess = 0;
+        gld_pair(nextPtr, &child0, &child1);
         u32 matchLength = commonLengthSmaller < commonLengthLarger ? commonLengthSmaller : commonLengthLarger;
         const u8* const match = base + matchIndex;
-        matchLength += wv_count(ip + matchLength, match + matchLength, ipRoom - matchLength);
+        matchLength += wv_count_cmp(ip + matchLength, match + matchLength, ipRoom - matchLength, &mLess);
         if (matchLength == ipRoom) break;
-        if (srd8(match + matchLength) < srd8(ip + matchLength)) {
+        if (mLess) {
             gst32(smallerPtr, matchIndex);
             commonLengthSmaller = matchLength;
             if (matchIndex <= btLow) {
@@ -179,7 +207,7 @@ SQ_DEVFN void dubt_insert1(MatchState& ms, u32 curr, const u8* inputEnd, u32 nbC
                 break;
             }
             smallerPtr = nextPtr + 1;
-            matchIndex = gld32(nextPtr + 1);
+            matchIndex = child1;
         } else {
             gst32(largerPtr, matchIndex);
             commonLengthLarger = matchLength;
@@ -188,7 +216,7 @@ SQ_DEVFN void dubt_insert1(MatchState& ms, u32 curr, const u8* inputEnd, u32 nbC
                 break;
             }
             largerPtr = nextPtr;
-            matchIndex = gld32(nextPtr);
+            matchIndex = child0;
         }
     }
     gst32(smallerPtr, 0);
@@ -216,17 +244,24 @@ SQ_DEVFN u32 dubt_find(MatchState& ms, const u8* const ip, const u8* const iend,
     u32 previousCandidate = 0;
     u32 const ipRoom = (u32)(iend - ip);
 
-    while ((matchIndex > unsortLimit) && (gld32(unsortedMark) == SQZ_DUBT_UNSORTED) && (nbCandidates > 1)) {
-        gst32(unsortedMark, previousCandidate);
-        previousCandidate = matchIndex;
-        matchIndex = gld32(nextCandidate);
-        nextCandidate = bt + 2 * (matchIndex & btMask);
-        unsortedMark = bt + 2 * (matchIndex & btMask) + 1;
-        nbCandidates--;
-    }
-    if ((matchIndex > unsortLimit) && (gld32(unsortedMark) == SQZ_DUBT_UNSORTED)) {
-        gst32(nextCandidate, 0);
-        gst32(unsortedMark, 0);
+    u32 const headIndex = matchIndex; // hashTable[h] is not written until the search below
+    {
+        // one 8-byte load per visited candidate: (next candidate, sort mark)
+        u32 nextC = 0, mark = 0;
+        if (matchIndex > unsortLimit) gld_pair(nextCandidate, &nextC, &mark);
+        while ((matchIndex > unsortLimit) && (mark == SQZ_DUBT_UNSORTED) && (nbCandidates > 1)) {
+            gst32(unsortedMark, previousCandidate);
+            previousCandidate = matchIndex;
+            matchIndex = nextC;
+            nextCandidate = bt + 2 * (matchIndex & btMask);
+            unsortedMark = bt + 2 * (matchIndex & btMask) + 1;
+            nbCandidates--;
+            if (matchIndex > unsortLimit) gld_pair(nextCandidate, &nextC, &mark);
+        }
+        if ((matchIndex > unsortLimit) && (mark == SQZ_DUBT_UNSORTED)) {
+            gst32(nextCandidate, 0);
+            gst32(unsortedMark, 0);
+        }
     }
     wv_fence();
     matchIndex = previousCandidate;
@@ -243,13 +278,15 @@ SQ_DEVFN u32 dubt_find(MatchState& ms, const u8* const ip, const u8* const iend,
         u32* largerPtr = bt + 2 * (curr & btMask) + 1;
         u32 matchEndIdx = curr + 8 + 1;
         u32 bestLength = 0;
-        matchIndex = gld32(hashTable + h);
+        matchIndex = headIndex;
         gst32(hashTable + h, curr);
         for (; nbCompares && (matchIndex > windowLow); --nbCompares) {
             u32* const nextPtr = bt + 2 * (matchIndex & btMask);
+            u32 child0, child1, mLess = 0;
+            gld_pair(nextPtr, &child0, &child1);
             u32 matchLength = commonLengthSmaller < commonLengthLarger ? commonLengthSmaller : commonLengthLarger;
             const u8* const match = base + matchIndex;
-            matchLength += wv_count(ip + matchLength, match + matchLength, ipRoom - matchLength);
+            matchLength += wv_count_cmp(ip + matchLength, match + matchLength, ipRoom - matchLength, &mLess);
             if (matchLength > bestLength) {
                 if (matchLength > matchEndIdx - matchIndex) matchEndIdx = matchIndex + matchLength;
                 if ((4 * (int)(matchLength - bestLength)) >
@@ -259,7 +296,7 @@ SQ_DEVFN u32 dubt_find(MatchState& ms, const u8* const ip, const u8* const iend,
                 }
                 if (matchLength == ipRoom) break;
             }
-            if (srd8(match + matchLength) < srd8(ip + matchLength)) {
+            if (mLess) {
                 gst32(smallerPtr, matchIndex);
                 commonLengthSmaller = matchLength;
                 if (matchIndex <= btLow) {
@@ -267,7 +304,7 @@ SQ_DEVFN u32 dubt_find(MatchState& ms, const u8* const ip, const u8* const iend,
                     break;
                 }
                 smallerPtr = nextPtr + 1;
-                matchIndex = gld32(nextPtr + 1);
+                matchIndex = child1;
             } else {
                 gst32(largerPtr, matchIndex);
                 commonLengthLarger = matchLength;
@@ -276,7 +313,7 @@ SQ_DEVFN u32 dubt_find(MatchState& ms, const u8* const ip, const u8* const iend,
                     break;
                 }
                 largerPtr = nextPtr;
-                matchIndex = gld32(nextPtr);
+                matchIndex = child0;
             }
         }
         gst32(smallerPtr, 0);
@@ -289,8 +326,13 @@ SQ_DEVFN u32 dubt_find(MatchState& ms, const u8* const ip, const u8* const iend,
 
 SQ_DEV u32 bt_find_best(MatchState& ms, const u8* ip, const u8* iLimit, u32* offBasePtr) {
     if (ip < ms.base + ms.nextToUpdate) return 0; // skipped area
+    PROF_T0(t_u);
     dubt_update(ms, (u32)(ip - ms.base));
-    return dubt_find(ms, ip, iLimit, offBasePtr);
+    PROF_ADD(2, t_u);
+    PROF_T0(t_f);
+    u32 const r = dubt_find(ms, ip, iLimit, offBasePtr);
+    PROF_ADD(3, t_f);
+    return r;
 }
 
 // ================================================================ row hash (lazy2)
@@ -314,25 +356,23 @@ SQ_DEVFN void row_insert_range(MatchState& ms, u32 from, u32 to) {
         u32 const idx = idx0 + lane;
         bool const active = idx < to;
         u32 hash = 0;
-        if (active) hash = hash5(sq_rd64(base + idx), hBits);
+        if (active) hash = hash5(sq_grd64(base + idx), hBits);
         u32 const relRow = (hash >> 8) << 6;
         WvGroup const g = wv_group(relRow, active, g_lds.grp);
+        u32 hb = 0;
         if (active) {
             u8* const tagRow = ms.tagTable + relRow;
             u32* const row = ms.hashTable + relRow;
-            u32 const hb = tagRow[0];
+            hb = sq_grd8(tagRow);
             u32 const pos = row_pos_after(hb, g.rank + 1);
             if (g.rank + 63 >= g.gsize) { // not overwritten by a later lane of this batch
-                tagRow[pos] = (u8)hash;
-                row[pos] = idx;
+                sq_gwr8(tagRow + pos, hash);
+                sq_gst32(row + pos, idx);
             }
         }
         wv_fence();
         // heads are written after every lane has read its (old) head byte
-        if (active && g.rank + 1 == g.gsize) {
-            u8* const tagRow = ms.tagTable + relRow;
-            tagRow[0] = (u8)row_pos_after(tagRow[0], g.gsize);
-        }
+        if (active && g.rank + 1 == g.gsize) sq_gwr8(ms.tagTable + relRow, row_pos_after(hb, g.gsize));
         wv_fence();
     }
 #else
@@ -365,11 +405,14 @@ SQ_DEVFN u32 row_find(MatchState& ms, const u8* const ip, const u8* const iLimit
     u32 const curr = (u32)(ip - base);
     u32 const lowLimit = SQZ_WINDOW_START;
     u32 ml = 4 - 1;
+    PROF_T0(t_ru);
     if (!ms.lazySkipping) {
         row_update(ms, curr);
     } else {
         ms.nextToUpdate = curr;
     }
+    PROF_ADD(4, t_ru);
+    PROF_T0(t_rf);
     u32 const hash = hash5(srd64(ip), ms.rowHashLog + 8);
     u32 const relRow = (hash >> 8) << 6;
     u32 const tag = hash & 0xFF;
@@ -381,8 +424,8 @@ SQ_DEVFN u32 row_find(MatchState& ms, const u8* const ip, const u8* const iLimit
     u32 const hb = gld8(tagRow);
     u32 const head = hb & 63;
     u32 const matchPos = (head + lane) & 63;
-    u32 const t = tagRow[matchPos];
-    u32 const cand = row[matchPos];
+    u32 const t = sq_grd8(tagRow + matchPos);
+    u32 const cand = sq_gld32(row + matchPos);
     bool const hit = (t == tag) && (matchPos != 0);
     u64 const M = wv_ballot(hit);
     u64 const B = wv_ballot(hit && cand < lowLimit);
@@ -395,9 +438,9 @@ SQ_DEVFN u32 row_find(MatchState& ms, const u8* const ip, const u8* const iLimit
     { // insert the current position (ZSTD_row_nextIndex)
         u32 const pos = row_pos_after(hb, 1);
         if (lane == 0) {
-            tagRow[0] = (u8)pos;
-            tagRow[pos] = (u8)tag;
-            row[pos] = ms.nextToUpdate;
+            sq_gwr8(tagRow, pos);
+            sq_gwr8(tagRow + pos, tag);
+            sq_gst32(row + pos, ms.nextToUpdate);
         }
         ms.nextToUpdate++;
     }
@@ -410,7 +453,7 @@ SQ_DEVFN u32 row_find(MatchState& ms, const u8* const ip, const u8* const iLimit
             u32 o = 0;
             bool done = false;
             while (!done && o + 8 <= limitLen) {
-                u64 x = sq_rd64(ip + o) ^ sq_rd64(m + o);
+                u64 x = sq_grd64(ip + o) ^ sq_grd64(m + o);
                 if (x) {
                     o += (u32)(__builtin_ctzll(x) >> 3);
                     done = true;
@@ -418,7 +461,7 @@ SQ_DEVFN u32 row_find(MatchState& ms, const u8* const ip, const u8* const iLimit
                     o += 8;
             }
             while (!done && o < limitLen) {
-                if (ip[o] != m[o])
+                if (sq_grd8(ip + o) != sq_grd8(m + o))
                     done = true;
                 else
                     o++;
@@ -473,6 +516,7 @@ SQ_DEVFN u32 row_find(MatchState& ms, const u8* const ip, const u8* const iLimit
         }
     }
 #endif
+    PROF_ADD(5, t_rf);
     return ml;
 }
 

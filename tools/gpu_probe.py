@@ -33,7 +33,7 @@ for spec in sys.argv[1:]:
     cases.append((kind, int(seed), int(n), int(rep)))
 
 o = oracle_lib.load()
-st = squishrs_amd.ChunkStore(device=0, dedup_capacity=1 << 12)
+st = squishrs_amd.ChunkStore(device=0, dedup_capacity=1 << 12, compress_waves=int(os.environ.get("SQ_WAVES", "0")))
 for kind, seed, n, rep in cases:
     chunks = [corpus.make(kind, seed + i, n) for i in range(rep)]
     lens = np.array([len(c) for c in chunks], dtype=np.uint32)
