@@ -433,6 +433,20 @@ static int compress_async(sq_ctx* c, const u8* d_data, const u64* h_off, const u
         fprintf(stderr, "\n");
     }
 #endif
+    if (*h_err && getenv("SQ_DEBUG")) {
+        const sqz::WsLayout L = sqz::ws_layout(max_len);
+        int shown = 0;
+        for (u32 w = 0; w < waves && shown < 8; w++) {
+            u32 tr[64];
+            (void)hipMemcpy(tr, (u8*)c->b_ws.p + (size_t)w * ws_each + L.dummy, sizeof(tr), hipMemcpyDeviceToHost);
+            if (tr[8 + 16]) {
+                fprintf(stderr, "[squish_gpu fault] wave %u:", w);
+                for (int k = 8; k < 8 + 24; k++) fprintf(stderr, " %u", tr[k]);
+                fprintf(stderr, "\n");
+                shown++;
+            }
+        }
+    }
     if (*h_err) return SQ_E_COMPRESS;
     if (h_comp_off[n] > comp_cap) return SQ_E_CAP;
     HIPCHK(hipEventRecord(c->ev[6], c->stream));

@@ -71,6 +71,11 @@ SQ_DEV void sq_gwr128(u8* p, sq_v4u v) { *(SQ_G sq_v4u_ua*)p = v; }
 SQ_DEV void sq_gwr8(u8* p, u32 v) { *(SQ_G u8*)p = (u8)v; }
 SQ_DEV u32 sq_gld32(const u32* p) { return *(const SQ_G u32*)p; }          // aligned table word
 SQ_DEV void sq_gst32(u32* p, u32 v) { *(SQ_G u32*)p = v; }
+// table loads: words this kernel itself rewrites (hash / chain / tag tables).  Relaxed agent-scope
+// atomic loads = global_load ... sc1: served by L2, never by a possibly stale L1 line or by the
+// scalar cache.  (Random 4-byte gathers gain nothing from the 32 KiB L1 anyway.)
+SQ_DEV u32 sq_tld32(const u32* p) { return __hip_atomic_load((const SQ_G u32*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+SQ_DEV u32 sq_tld8(const u8* p) { return (u32)__hip_atomic_load((const SQ_G u8*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 SQ_DEV sq_v2u sq_gld64v(const u32* p) { return *(const SQ_G sq_v2u*)p; }   // 8-byte aligned pair
 SQ_DEV void sq_gst64v(u32* p, u32 a, u32 b) { *(SQ_G sq_v2u*)p = (sq_v2u){a, b}; }
 #else
@@ -82,5 +87,7 @@ SQ_DEV u32 sq_grd32(const u8* p) { return sq_rd32(p); }
 SQ_DEV u64 sq_grd64(const u8* p) { return sq_rd64(p); }
 SQ_DEV void sq_gwr8(u8* p, u32 v) { *p = (u8)v; }
 SQ_DEV u32 sq_gld32(const u32* p) { return *p; }
+SQ_DEV u32 sq_tld32(const u32* p) { return *p; }
+SQ_DEV u32 sq_tld8(const u8* p) { return *p; }
 SQ_DEV void sq_gst32(u32* p, u32 v) { *p = v; }
 #endif

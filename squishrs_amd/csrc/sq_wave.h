@@ -33,12 +33,26 @@ SQ_DEV u64 wv_readlane64(u64 v, u32 l) {
 // COMPILER from moving accesses across this point; a __builtin_amdgcn_fence (even at wavefront
 // scope) makes hipcc drain vmcnt/lgkmcnt to 0, which serialises every pipelined load behind it.
 SQ_DEV void wv_fence() { asm volatile("" ::: "memory"); }
+// Full drain: every earlier vector-memory / LDS operation of this wave has COMPLETED.  Needed
+// where a later instruction reads what an earlier instruction (possibly of another lane, possibly
+// a flat_* one from a serial region) wrote: gfx950 issues a wave's memory instructions in order
+// but lets a load be performed before an older store has landed.
+SQ_DEV void wv_mem_sync() { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); }
+// Drain + drop this CU's vector-L1 lines (buffer_inv sc1): used once per chunk / block so no line
+// cached while the workspace held another chunk's tables can be hit again.
+SQ_DEV void wv_mem_sync_inv() {
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
 #else
 #define SQ_LDS static thread_local
 #define SQ_NOINLINE static __attribute__((noinline))
 SQ_DEV u32 wv_uni(u32 v) { return v; }
 SQ_DEV u64 wv_uni64(u64 v) { return v; }
 SQ_DEV void wv_fence() {}
+SQ_DEV void wv_mem_sync() {}
+SQ_DEV void wv_mem_sync_inv() {}
 #endif
 
 // A serial region: plain scalar code run by lane 0 only while the other lanes idle at the
@@ -51,23 +65,27 @@ SQ_DEV void wv_fence() {}
 #endif
 
 // ---- uniform global memory access: all lanes read one address; lane 0 alone writes ------------
+// The loads are relaxed agent-scope ATOMIC loads on purpose: a plain load from a wave-uniform
+// address is turned into s_load_dword by hipcc, and the scalar data cache is not coherent with
+// this wave's own vector stores (observed: ~1 stale table word per 10^4 chunks -> impossible
+// match indices).  Atomic loads stay on the vector path (global_load ... sc1).
 SQ_DEV u32 gld32(const u32* p) {
 #if SQ_ON_DEVICE
-    return wv_uni(sq_gld32(p));
+    return wv_uni(__hip_atomic_load((const SQ_G u32*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
 #else
     return *p;
 #endif
 }
 SQ_DEV u32 gld8(const u8* p) {
 #if SQ_ON_DEVICE
-    return wv_uni(sq_grd8(p));
+    return wv_uni((u32)__hip_atomic_load((const SQ_G u8*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
 #else
     return *p;
 #endif
 }
 SQ_DEV u32 gld16(const u16* p) {
 #if SQ_ON_DEVICE
-    return wv_uni(*(const SQ_G u16*)p);
+    return wv_uni((u32)__hip_atomic_load((const SQ_G u16*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
 #else
     return *p;
 #endif
@@ -140,9 +158,9 @@ SQ_DEV u32 wv_count(const u8* a, const u8* b, u32 maxLen) {
 // uniform 8-byte load of two adjacent table words (p 8-byte aligned)
 SQ_DEV void gld_pair(const u32* p, u32* a, u32* b) {
 #if SQ_ON_DEVICE
-    sq_v2u v = sq_gld64v(p);
-    *a = wv_uni(v.x);
-    *b = wv_uni(v.y);
+    u64 const v = __hip_atomic_load((const SQ_G u64*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    *a = wv_uni((u32)v);
+    *b = wv_uni((u32)(v >> 32));
 #else
     *a = p[0];
     *b = p[1];
@@ -208,6 +226,7 @@ SQ_DEV void wv_fill32(u32* dst, u32 v, size_t nwords) { // dst 16-byte aligned, 
     u8* d = (u8*)dst;
     const size_t n16 = nwords / 4;
     for (size_t i = wv_lane(); i < n16; i += 64) sq_gwr128(d + 16 * i, q);
+    wv_mem_sync();
 #else
     for (size_t i = 0; i < nwords; i++) dst[i] = v;
 #endif
@@ -228,7 +247,7 @@ SQ_DEV void wv_memcpy(u8* dst, const u8* src, u32 n) {
     for (; pos + 16 <= n; pos += 1024) sq_gwr128(dst + pos, sq_grd128(src + pos));
     if (pos < n)
         for (u32 k = pos; k < n; k++) sq_gwr8(dst + k, sq_grd8(src + k)); // the single partial lane
-    wv_fence();
+    wv_mem_sync();
 #else
     memcpy(dst, src, n);
 #endif

@@ -48,9 +48,8 @@ struct SeqDef {
     u16 litLength, mlBase;
 };
 
-// Everything a wave keeps in LDS (~19 KiB): 8 waves per CU fit in the 160 KiB of a CU.
-struct LdsState {
-    Entropy ent[2];
+// Everything a wave keeps in LDS (~19.5 KiB): 8 waves per CU fit in the 160 KiB of a CU.
+struct EntropyScratch { // live only inside the entropy stage of a block
     u32 count[256];
     NodeElt huffNodeTbl[2 * 256 + 2];
     struct {
@@ -61,6 +60,14 @@ struct LdsState {
     s16 norm[64];
     u16 cumul[64];
     u8 tableSymbol[512];
+};
+#define SQZ_BLOOM_WORDS 2048 // 65,536-bit Bloom filter of "live" hash buckets (match-finding phase)
+struct LdsState {
+    Entropy ent[2];
+    union {
+        EntropyScratch es;
+        u32 bloom[SQZ_BLOOM_WORDS];
+    } u;
     u8 grp[2048]; // wv_group scratch
     u32 ret[8];   // results handed from a serial region to the whole wave
     u32* trace;   // 56 debug words in the wave's workspace (read by the host watchdog)
@@ -410,14 +417,14 @@ SQ_DEVFN u32 fse_writeNCount(u8* out0, u32 cap, const s16* norm, u32 maxSym, u32
     return (u32)(out - out0);
 }
 
-// FSE_buildCTable_wksp; uses g_lds.cumul / g_lds.tableSymbol
+// FSE_buildCTable_wksp; uses g_lds.u.es.cumul / g_lds.u.es.tableSymbol
 SQ_DEVFN u32 fse_buildCTable(FseCT* ct, const s16* norm, u32 maxSym, u32 tableLog) {
     u32 const tableSize = 1u << tableLog;
     u32 const tableMask = tableSize - 1;
     u32 const step = (tableSize >> 1) + (tableSize >> 3) + 3;
     u32 const maxSV1 = maxSym + 1;
-    u16* const cumul = g_lds.cumul;
-    u8* const tableSymbol = g_lds.tableSymbol;
+    u16* const cumul = g_lds.u.es.cumul;
+    u8* const tableSymbol = g_lds.u.es.tableSymbol;
     u32 highThreshold = tableSize - 1;
     if (tableLog > 9 || maxSym > MaxML) return SQZ_ERR;
     ct->tableLog = (u16)tableLog;
@@ -601,24 +608,24 @@ SQ_DEVFN void huf_quickSort(NodeElt* arr, int low0, int high0) {
 SQ_DEVFN void huf_sort(NodeElt* huffNode, const u32* count, u32 maxSym) {
     u32 const maxSV1 = maxSym + 1;
     for (u32 n = 0; n < 192; n++) {
-        g_lds.rankPosition[n].base = 0;
-        g_lds.rankPosition[n].curr = 0;
+        g_lds.u.es.rankPosition[n].base = 0;
+        g_lds.u.es.rankPosition[n].curr = 0;
     }
-    for (u32 n = 0; n < maxSV1; ++n) g_lds.rankPosition[huf_getIndex(count[n])].base++;
+    for (u32 n = 0; n < maxSV1; ++n) g_lds.u.es.rankPosition[huf_getIndex(count[n])].base++;
     for (u32 n = 191; n > 0; --n) {
-        g_lds.rankPosition[n - 1].base += g_lds.rankPosition[n].base;
-        g_lds.rankPosition[n - 1].curr = g_lds.rankPosition[n - 1].base;
+        g_lds.u.es.rankPosition[n - 1].base += g_lds.u.es.rankPosition[n].base;
+        g_lds.u.es.rankPosition[n - 1].curr = g_lds.u.es.rankPosition[n - 1].base;
     }
     for (u32 n = 0; n < maxSV1; ++n) {
         u32 const c = count[n];
         u32 const r = huf_getIndex(c) + 1;
-        u32 const pos = g_lds.rankPosition[r].curr++;
+        u32 const pos = g_lds.u.es.rankPosition[r].curr++;
         huffNode[pos].count = c;
         huffNode[pos].byte = (u8)n;
     }
     for (u32 n = SQZ_RANK_DISTINCT_CUTOFF; n < 191; ++n) {
-        int const bucketSize = g_lds.rankPosition[n].curr - g_lds.rankPosition[n].base;
-        u32 const bucketStartIdx = g_lds.rankPosition[n].base;
+        int const bucketSize = g_lds.u.es.rankPosition[n].curr - g_lds.u.es.rankPosition[n].base;
+        u32 const bucketStartIdx = g_lds.u.es.rankPosition[n].base;
         if (bucketSize > 1) huf_quickSort(huffNode + bucketStartIdx, 0, bucketSize - 1);
     }
 }
@@ -717,11 +724,11 @@ SQ_DEVFN u32 huf_setMaxHeight(NodeElt* huffNode, u32 lastNonNull, u32 targetNbBi
     }
     return targetNbBits;
 }
-// HUF_buildCTable_wksp into g_lds.newHuf; returns maxNbBits
+// HUF_buildCTable_wksp into g_lds.u.es.newHuf; returns maxNbBits
 SQ_DEVFN u32 huf_buildCTable(const u32* count, u32 maxSym, u32 maxNbBits) {
-    NodeElt* const table = g_lds.huffNodeTbl;
+    NodeElt* const table = g_lds.u.es.huffNodeTbl;
     NodeElt* const huffNode = table + 1;
-    HufCT* const ct = &g_lds.newHuf;
+    HufCT* const ct = &g_lds.u.es.newHuf;
     for (u32 i = 0; i < 2 * 256 + 2; i++) {
         table[i].count = 0;
         table[i].parent = 0;
@@ -792,11 +799,11 @@ SQ_DEVFN u32 huf_compressWeights(u8* dst, u32 cap, const u8* weights, u32 wtSize
     }
     return (u32)(op - dst);
 }
-// HUF_writeCTable_wksp for g_lds.newHuf
+// HUF_writeCTable_wksp for g_lds.u.es.newHuf
 SQ_DEVFN u32 huf_writeCTable(u8* dst, u32 cap, u32 maxSym, u32 huffLog, FseCT* wct) {
-    const HufCT* ct = &g_lds.newHuf;
+    const HufCT* ct = &g_lds.u.es.newHuf;
     u8 bitsToWeight[SQZ_HUF_TABLELOG_MAX + 1];
-    u8* const huffWeight = g_lds.huffWeight;
+    u8* const huffWeight = g_lds.u.es.huffWeight;
     u8* op = dst;
     bitsToWeight[0] = 0;
     for (u32 n = 1; n < huffLog + 1; n++) bitsToWeight[n] = (u8)(huffLog + 1 - n);
@@ -904,7 +911,7 @@ SQ_DEVFN u32 compressLiterals(u8* dst, u32 dstCap, const u8* src, u32 srcSize, c
         next->huf = prev->huf;
         next->huf_repeat = prev->huf_repeat;
     }
-    wv_fence();
+    wv_mem_sync();
     {
         int const shift = (9 - (int)strategy) < 3 ? (9 - (int)strategy) : 3;
         u32 const mintc = (prev->huf_repeat == REP_VALID) ? 6u : (8u << shift);
@@ -916,19 +923,19 @@ SQ_DEVFN u32 compressLiterals(u8* dst, u32 dstCap, const u8* src, u32 srcSize, c
     u32 early = 0xFFFFFFFEu; // "continue"
     if (suspectUncompressible && srcSize >= 4096 * 10) {
         u32 l1, l2, dummy;
-        wv_zero_lds(g_lds.count, 256);
-        wv_hist_bytes(g_lds.count, src, 4096);
-        wv_max_and_last(g_lds.count, 256, &l1, &dummy);
-        wv_zero_lds(g_lds.count, 256);
-        wv_hist_bytes(g_lds.count, src + srcSize - 4096, 4096);
-        wv_max_and_last(g_lds.count, 256, &l2, &dummy);
+        wv_zero_lds(g_lds.u.es.count, 256);
+        wv_hist_bytes(g_lds.u.es.count, src, 4096);
+        wv_max_and_last(g_lds.u.es.count, 256, &l1, &dummy);
+        wv_zero_lds(g_lds.u.es.count, 256);
+        wv_hist_bytes(g_lds.u.es.count, src + srcSize - 4096, 4096);
+        wv_max_and_last(g_lds.u.es.count, 256, &l2, &dummy);
         if (l1 + l2 <= ((2 * 4096) >> 7) + 4) early = 0;
     }
     u32 largest = 0, maxSym = 255;
     if (early != 0) {
-        wv_zero_lds(g_lds.count, 256);
-        wv_hist_bytes(g_lds.count, src, srcSize);
-        wv_max_and_last(g_lds.count, 256, &largest, &maxSym);
+        wv_zero_lds(g_lds.u.es.count, 256);
+        wv_hist_bytes(g_lds.u.es.count, src, srcSize);
+        wv_max_and_last(g_lds.u.es.count, 256, &largest, &maxSym);
     }
     // --- table construction, header and stream emission: serial on lane 0
     WV_SERIAL {
@@ -939,7 +946,7 @@ SQ_DEVFN u32 compressLiterals(u8* dst, u32 dstCap, const u8* src, u32 srcSize, c
         u32 cLitSize = 0;
         u32 repeat = prev->huf_repeat;
         u32 hType = SET_COMPRESSED;
-        const u32* count = g_lds.count;
+        const u32* count = g_lds.u.es.count;
         do {
             if (early == 0) {
                 cLitSize = 0;
@@ -982,7 +989,7 @@ SQ_DEVFN u32 compressLiterals(u8* dst, u32 dstCap, const u8* src, u32 srcSize, c
                     u32 oldBits = 0, newBits = 0;
                     for (u32 s = 0; s <= maxSym; ++s) {
                         oldBits += (u32)prev->huf.nbBits[s] * count[s];
-                        newBits += (u32)g_lds.newHuf.nbBits[s] * count[s];
+                        newBits += (u32)g_lds.u.es.newHuf.nbBits[s] * count[s];
                     }
                     u32 const oldSize = oldBits >> 3, newSize = newBits >> 3;
                     if (oldSize <= hSize + newSize || hSize + 12 >= srcSize) {
@@ -996,9 +1003,9 @@ SQ_DEVFN u32 compressLiterals(u8* dst, u32 dstCap, const u8* src, u32 srcSize, c
                 }
                 op += hSize;
                 repeat = REP_NONE;
-                next->huf = g_lds.newHuf;
+                next->huf = g_lds.u.es.newHuf;
             }
-            cLitSize = huf_compressCTable(ostart, op, oend, src, srcSize, singleStream, &g_lds.newHuf);
+            cLitSize = huf_compressCTable(ostart, op, oend, src, srcSize, singleStream, &g_lds.u.es.newHuf);
         } while (0);
         if (repeat != REP_NONE) hType = SET_REPEAT;
         // ZSTD_compressLiterals post-processing
@@ -1040,7 +1047,7 @@ SQ_DEVFN u32 compressLiterals(u8* dst, u32 dstCap, const u8* src, u32 srcSize, c
         g_lds.ret[0] = mode;
         g_lds.ret[1] = cLitSize;
     }
-    wv_fence();
+    wv_mem_sync();
     u32 const mode = g_lds.ret[0], cLitSize = g_lds.ret[1];
     if (mode == 0) return noCompressLiterals(dst, dstCap, src, srcSize);
     if (mode == 1) { // ZSTD_compressRleLiteralsBlock
@@ -1097,9 +1104,9 @@ SQ_DEV u32 fseBitCost(const FseCT* ct, const u32* count, u32 max) {
 SQ_DEVFN u32 NCountCost(const u32* count, u32 max, u32 nbSeq, u32 FSELog) {
     u8 wksp[512];
     const u32 tableLog = fse_optimalTableLog(FSELog, nbSeq, max);
-    u32 e = fse_normalizeCount(g_lds.norm, tableLog, count, nbSeq, max, nbSeq >= 2048);
+    u32 e = fse_normalizeCount(g_lds.u.es.norm, tableLog, count, nbSeq, max, nbSeq >= 2048);
     if (is_err(e)) return e;
-    return fse_writeNCount(wksp, sizeof(wksp), g_lds.norm, max, tableLog);
+    return fse_writeNCount(wksp, sizeof(wksp), g_lds.u.es.norm, max, tableLog);
 }
 // SQZ_ERR compares as "infinite" exactly like libzstd's size_t error codes
 SQ_DEVFN u32 selectEncodingType(u32* repeatMode, const u32* count, u32 max, u32 mostFrequent, u32 nbSeq,
@@ -1135,8 +1142,8 @@ SQ_DEVFN u32 buildCTable(u8* dst, u32 dstCap, FseCT* nextCTable, u32 FSELog, u32
         return 1;
     case SET_REPEAT: *nextCTable = *prevCTable; return 0;
     case SET_BASIC:
-        for (u32 s = 0; s <= defaultMax; s++) g_lds.norm[s] = defaultNorm[s];
-        if (is_err(fse_buildCTable(nextCTable, g_lds.norm, defaultMax, defaultNormLog))) return SQZ_ERR;
+        for (u32 s = 0; s <= defaultMax; s++) g_lds.u.es.norm[s] = defaultNorm[s];
+        if (is_err(fse_buildCTable(nextCTable, g_lds.u.es.norm, defaultMax, defaultNormLog))) return SQZ_ERR;
         return 0;
     case SET_COMPRESSED: {
         u32 nbSeq_1 = nbSeq;
@@ -1146,13 +1153,13 @@ SQ_DEVFN u32 buildCTable(u8* dst, u32 dstCap, FseCT* nextCTable, u32 FSELog, u32
             nbSeq_1--;
         }
         {
-            u32 e = fse_normalizeCount(g_lds.norm, tableLog, count, nbSeq_1, max, nbSeq_1 >= 2048);
+            u32 e = fse_normalizeCount(g_lds.u.es.norm, tableLog, count, nbSeq_1, max, nbSeq_1 >= 2048);
             if (is_err(e)) return e;
         }
         {
-            u32 const NCountSize = fse_writeNCount(dst, dstCap, g_lds.norm, max, tableLog);
+            u32 const NCountSize = fse_writeNCount(dst, dstCap, g_lds.u.es.norm, max, tableLog);
             if (is_err(NCountSize)) return NCountSize;
-            if (is_err(fse_buildCTable(nextCTable, g_lds.norm, max, tableLog))) return SQZ_ERR;
+            if (is_err(fse_buildCTable(nextCTable, g_lds.u.es.norm, max, tableLog))) return SQZ_ERR;
             return NCountSize;
         }
     }
@@ -1209,9 +1216,9 @@ SQ_DEV void entropy_reset(Entropy* e) { // serial
 }
 
 // ZSTD_seqToCodes + the three code histograms, by the whole wave.  hist: 3 x 64 u32 in LDS
-// (g_lds.count[0..191]); most-frequent / max computed later in the serial part.
+// (g_lds.u.es.count[0..191]); most-frequent / max computed later in the serial part.
 SQ_DEV void seqToCodes_and_hist(const SeqStore& ss) {
-    wv_zero_lds(g_lds.count, 192);
+    wv_zero_lds(g_lds.u.es.count, 192);
 #if SQ_ON_DEVICE
     for (u32 u = wv_lane(); u < ss.nseq; u += 64) {
         SeqDef s = ss.seqs[u];
@@ -1221,11 +1228,11 @@ SQ_DEV void seqToCodes_and_hist(const SeqStore& ss) {
         ss.llCode[u] = (u8)ll;
         ss.ofCode[u] = (u8)of;
         ss.mlCode[u] = (u8)ml;
-        atomicAdd(&g_lds.count[ll], 1u);
-        atomicAdd(&g_lds.count[64 + of], 1u);
-        atomicAdd(&g_lds.count[128 + ml], 1u);
+        atomicAdd(&g_lds.u.es.count[ll], 1u);
+        atomicAdd(&g_lds.u.es.count[64 + of], 1u);
+        atomicAdd(&g_lds.u.es.count[128 + ml], 1u);
     }
-    wv_fence();
+    wv_mem_sync();
 #else
     for (u32 u = 0; u < ss.nseq; u++) {
         u32 ll = LLcode(ss.seqs[u].litLength), of = sq_highbit32(ss.seqs[u].offBase), ml = MLcode(ss.seqs[u].mlBase);
@@ -1234,9 +1241,9 @@ SQ_DEV void seqToCodes_and_hist(const SeqStore& ss) {
         ss.llCode[u] = (u8)ll;
         ss.ofCode[u] = (u8)of;
         ss.mlCode[u] = (u8)ml;
-        g_lds.count[ll]++;
-        g_lds.count[64 + of]++;
-        g_lds.count[128 + ml]++;
+        g_lds.u.es.count[ll]++;
+        g_lds.u.es.count[64 + of]++;
+        g_lds.u.es.count[128 + ml]++;
     }
 #endif
 }
@@ -1305,7 +1312,7 @@ SQ_DEVFN u32 entropy_compress_seqstore(const SeqStore& ss, const Entropy* prev, 
                 u32 bad = 0;
                 { // LL
                     u32 max, mf;
-                    u32* count = g_lds.count;
+                    u32* count = g_lds.u.es.count;
                     hist_stats(count, MaxLL, &max, &mf);
                     next->ll_repeat = prev->ll_repeat;
                     LLtype = selectEncodingType(&next->ll_repeat, count, max, mf, nbSeq, LLFSELog, &prev->ll,
@@ -1321,7 +1328,7 @@ SQ_DEVFN u32 entropy_compress_seqstore(const SeqStore& ss, const Entropy* prev, 
                 }
                 if (!bad) { // OF
                     u32 max, mf;
-                    u32* count = g_lds.count + 64;
+                    u32* count = g_lds.u.es.count + 64;
                     hist_stats(count, MaxOff, &max, &mf);
                     u32 const defaultAllowed = (max <= DefaultMaxOff);
                     next->of_repeat = prev->of_repeat;
@@ -1338,7 +1345,7 @@ SQ_DEVFN u32 entropy_compress_seqstore(const SeqStore& ss, const Entropy* prev, 
                 }
                 if (!bad) { // ML
                     u32 max, mf;
-                    u32* count = g_lds.count + 128;
+                    u32* count = g_lds.u.es.count + 128;
                     hist_stats(count, MaxML, &max, &mf);
                     next->ml_repeat = prev->ml_repeat;
                     MLtype = selectEncodingType(&next->ml_repeat, count, max, mf, nbSeq, MLFSELog, &prev->ml,
@@ -1379,7 +1386,7 @@ SQ_DEVFN u32 entropy_compress_seqstore(const SeqStore& ss, const Entropy* prev, 
         } while (0);
         g_lds.ret[2] = result;
     }
-    wv_fence();
+    wv_mem_sync();
     PROF_ADD(6, t_ent);
     return g_lds.ret[2];
 }

@@ -25,7 +25,8 @@ struct Fingerprint {
 };
 
 struct WsLayout {
-    size_t hashTable, table2, hashTable3, seqs, lits, llCode, ofCode, mlCode, optState, fp, dummy, total;
+    size_t hashTable, table2, hashTable3, seqs, lits, llCode, ofCode, mlCode, optState, fp, sched, liveList,
+        skipList, dummy, total;
 };
 
 #if SQ_ON_DEVICE
@@ -91,6 +92,12 @@ SQ_HD WsLayout ws_layout(u32 max_len) {
     o += ws_align(sizeof(opt::optstate));
     L.fp = o;
     o += ws_align(2 * sizeof(Fingerprint));
+    L.sched = o;
+    o += ws_align((size_t)SQZ_SCHED_CAP * 4);
+    L.liveList = o;
+    o += ws_align((size_t)SQZ_LIVE_CAP * 4);
+    L.skipList = o;
+    o += ws_align((size_t)SQZ_SKIP_CAP * 8);
     L.dummy = o;
     o += 256;
     L.total = o;
@@ -108,10 +115,10 @@ SQ_DEV void ps_record(Fingerprint* fp, const u8* src) {
     const u32 lane = wv_lane();
     SQ_G u32* const ev = (SQ_G u32*)fp->events;
     for (u32 i = lane; i < 1024; i += 64) ev[i] = 0;
-    wv_fence();
+    wv_mem_sync();
     for (u32 n = lane * 5; n < limit; n += 64 * 5) __hip_atomic_fetch_add(&ev[ps_hash2_10(src + n)], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     if (lane == 0) sq_gst32(&fp->nbEvents, limit / 5);
-    wv_fence();
+    wv_mem_sync();
 #else
     for (u32 i = 0; i < 1024; i++) fp->events[i] = 0;
     for (u32 n = 0; n < limit; n += 5) fp->events[ps_hash2_10(src + n)]++;
@@ -148,7 +155,7 @@ SQ_DEV void ps_merge(Fingerprint* acc, const Fingerprint* nw) {
     const u32 lane = wv_lane();
     for (u32 n = lane; n < 1024; n += 64) sq_gst32(&acc->events[n], sq_gld32(&acc->events[n]) + sq_gld32(&nw->events[n]));
     if (lane == 0) sq_gst32(&acc->nbEvents, sq_gld32(&acc->nbEvents) + sq_gld32(&nw->nbEvents));
-    wv_fence();
+    wv_mem_sync();
 #else
     for (u32 n = 0; n < 1024; n++) acc->events[n] += nw->events[n];
     acc->nbEvents += nw->nbEvents;
@@ -196,9 +203,13 @@ SQ_DEVFN u32 compressBlock_internal(MatchState& ms, SeqStore& ss, BlockState& bs
         ss.longLengthPos = 0;
         {
             u32 const curr = (u32)(src - ms.base);
+            ms.blockEndPos = curr + srcSize;
+            if (!ms.eager && !bs.isFirstBlock) bloom_rebuild(ms); // the entropy stage reused the LDS
             if (curr > ms.nextToUpdate + 384) {
                 u32 const d = curr - ms.nextToUpdate - 384;
-                ms.nextToUpdate = curr - (192 < d ? 192 : d);
+                u32 const n2u = curr - (192 < d ? 192 : d);
+                filter_add_skip(ms, ms.nextToUpdate, n2u);
+                ms.nextToUpdate = n2u;
             }
         }
         for (int i = 0; i < SQZ_REP_NUM; ++i) bs.rep[nx][i] = bs.rep[p][i];
@@ -239,7 +250,7 @@ SQ_DEVFN u32 compressBlock_internal(MatchState& ms, SeqStore& ss, BlockState& bs
                 g_lds.ret[6] = rr[1];
                 g_lds.ret[7] = rr[2];
             }
-            wv_fence();
+            wv_mem_sync();
             lastLLSize = g_lds.ret[0];
             ss.nseq = g_lds.ret[1];
             ss.nlits = g_lds.ret[2];
@@ -256,6 +267,7 @@ SQ_DEVFN u32 compressBlock_internal(MatchState& ms, SeqStore& ss, BlockState& bs
         if (lastLLSize) wv_memcpy(ss.lits + ss.nlits, src + srcSize - lastLLSize, lastLLSize);
         PROF_ADD(7, t_ll);
         ss.nlits += lastLLSize;
+        wv_mem_sync_inv(); // sequence records / literals written by other lanes have landed
         cSize = entropy_compress_seqstore(ss, &g_lds.ent[p], &g_lds.ent[nx], ms.cp.strategy, dst, dstCap, srcSize);
         SQ_TRACE(0, 9);
         SQ_TRACE(5, cSize);
@@ -279,7 +291,7 @@ SQ_DEVFN u32 compress_frame_wave(const u8* src, u32 n, u8* dst, u32 cap, u8* ws,
     u8* op = dst;
     u8* const oend = dst + cap;
     WV_SERIAL { g_lds.trace = (u32*)(ws + L.dummy) + 8; }
-    wv_fence();
+    wv_mem_sync_inv(); // previous chunk's traffic fully landed; no L1 line survives from it
     SQ_TRACE(0, 1);
     SQ_TRACE(1, n);
     if (cap < 18) return 0;
@@ -312,6 +324,7 @@ SQ_DEVFN u32 compress_frame_wave(const u8* src, u32 n, u8* dst, u32 cap, u8* ws,
     ms.base = src - SQZ_WINDOW_START;
     ms.nextToUpdate = SQZ_WINDOW_START;
     ms.lazySkipping = 0;
+    ms.fault = 0;
     ms.hashTable = (u32*)(ws + L.hashTable);
     ms.chainTable = (u32*)(ws + L.table2);
     ms.tagTable = ws + L.table2;
@@ -319,6 +332,15 @@ SQ_DEVFN u32 compress_frame_wave(const u8* src, u32 n, u8* dst, u32 cap, u8* ws,
     ms.dummy = (u32*)(ws + L.dummy);
     ms.hashLog3 = 0;
     ms.rowHashLog = 0;
+    ms.eager = (cp.strategy == STRAT_BTLAZY2) ? 0 : 1;
+    ms.nRepairs = 0;
+    ms.anchorPos = SQZ_WINDOW_START;
+    ms.chunkEndPos = n + SQZ_WINDOW_START;
+    ms.blockEndPos = SQZ_WINDOW_START + (n < SQZ_BLOCKSIZE_MAX ? n : SQZ_BLOCKSIZE_MAX);
+    ms.sched = (u32*)(ws + L.sched);
+    ms.liveList = (u32*)(ws + L.liveList);
+    ms.skipList = (u32*)(ws + L.skipList);
+    ms.nLive = ms.nSkip = 0;
     SQ_TRACE(0, 2);
     PROF_T0(t_clr);
     wv_fill32(ms.hashTable, 0, (size_t)1 << cp.hashLog);
@@ -350,7 +372,11 @@ SQ_DEVFN u32 compress_frame_wave(const u8* src, u32 n, u8* dst, u32 cap, u8* ws,
     }
     bs.prevIdx = 0;
     bs.isFirstBlock = 1;
-    wv_fence();
+    wv_mem_sync();
+    if (!ms.eager && n >= 9) { // btlazy2: predict the no-match search schedule, make its buckets live
+        wv_zero_lds(g_lds.u.bloom, SQZ_BLOOM_WORDS);
+        filter_repair(ms, SQZ_WINDOW_START + 1, SQZ_WINDOW_START, true);
+    }
 
     if (n == 0) { // ZSTD_writeLastEmptyBlock
         WV_SERIAL {
@@ -375,7 +401,7 @@ SQ_DEVFN u32 compress_frame_wave(const u8* src, u32 n, u8* dst, u32 cap, u8* ws,
         if ((u32)(oend - op) < 3 + 2 + 1) return 0;
         if (ms.nextToUpdate < SQZ_WINDOW_START) ms.nextToUpdate = SQZ_WINDOW_START;
         u32 cSize = compressBlock_internal(ms, ss, bs, ws + L.optState, op + 3, (u32)(oend - op) - 3, ip, blockSize);
-        if (is_err(cSize)) return 0;
+        if (is_err(cSize) || ms.fault) return 0;
         if (cSize == 0) { // ZSTD_noCompressBlock
             u32 const h = lastBlock + (0u << 1) + (blockSize << 3);
             if (blockSize + 3 > (u32)(oend - op)) return 0;
@@ -405,6 +431,10 @@ SQ_DEVFN u32 compress_frame_wave(const u8* src, u32 n, u8* dst, u32 cap, u8* ws,
     }
     wv_fence();
     SQ_TRACE(0, 10);
+    SQ_TRACE(30, ms.eager);
+    SQ_TRACE(31, ms.nRepairs);
+    SQ_TRACE(32, ms.nLive);
+    SQ_TRACE(33, ms.nSkip);
     return (u32)(op - dst);
 }
 

@@ -78,8 +78,29 @@ struct MatchState {
     u32 rowHashLog;
     u32 nextToUpdate;
     u32 lazySkipping;
+    u32 fault; // set when a table yields an index that cannot exist (>= current position): the
+               // frame is then reported as failed instead of emitting an undecodable match
+    // ---- btlazy2 insert filter (see "dead-insert elision" below)
+    u32 eager;       // 1 = every position is inserted (libzstd's literal behaviour)
+    u32 nRepairs;    // schedule re-predictions so far in this chunk
+    u32 anchorPos;   // parser anchor (index) at the current search
+    u32 blockEndPos; // index one past the current block
+    u32 chunkEndPos; // index one past the chunk
+    u32* sched;      // predicted search positions (workspace)
+    u32* liveList;   // bucket ids made live so far (workspace); rebuilds the Bloom filter per block
+    u32* skipList;   // [from,to) position ranges libzstd itself never inserts (workspace)
+    u32 nLive, nSkip;
     CParams cp;
 };
+
+// hash-table word of the btlazy2 finder: head index + two flag bits
+#define SQZ_HT_LIVE 0x80000000u
+#define SQZ_HT_PEND 0x40000000u
+#define SQZ_HT_IDX 0x3FFFFFFFu
+#define SQZ_SCHED_CAP 4096u
+#define SQZ_LIVE_CAP (96u << 10)
+#define SQZ_SKIP_CAP 256u
+#define SQZ_MAX_REPAIRS 24u
 
 SQ_DEV u32 hash4(u32 v, u32 hBits) { return (v * 2654435761U) >> (32 - hBits); }
 SQ_DEV u32 hash5(u64 v, u32 hBits) { return (u32)(((v << 24) * 889523592379ULL) >> (64 - hBits)); }
@@ -113,68 +134,270 @@ SQ_DEV void storeSeq(SeqStore& ss, u32 litLength, const u8* literals, u32 offBas
 // ================================================================ DUBT (btlazy2)
 #define SQZ_DUBT_UNSORTED 1u
 
-// ZSTD_updateDUBT: insert positions [nextToUpdate, target) as unsorted candidates.
-SQ_DEVFN void dubt_update(MatchState& ms, u32 target) {
+// ---------------------------------------------------------------- dead-insert elision
+// libzstd inserts EVERY position into the hash table / unsorted chain (ZSTD_updateDUBT).  The state
+// of a hash bucket is observable only through a later search that lands in the same bucket, buckets
+// do not interact, and all state dies with the chunk.  On incompressible data the lazy parser
+// searches one position in `step` (step grows to 512) and > 99 % of the 2^19 buckets are never
+// searched: their insertions are dead.  The finder therefore keeps buckets either LIVE (every
+// insertion applied, exactly as libzstd) or untouched:
+//   * at chunk start the parser's no-match search schedule is predicted (it depends only on the
+//     anchor and block bounds); the buckets of those positions (+1, +2 for the depth-1/2 searches)
+//     become LIVE; a 64 Kibit Bloom filter in LDS pre-filters positions so that the insertion
+//     stream touches the 2 MiB table only for (probably) live buckets;
+//   * a search that lands in a bucket that is not LIVE (a match changed the schedule) triggers a
+//     repair: re-predict from the real parser state, mark the new buckets PENDING, replay the
+//     chunk's earlier positions into exactly those buckets (a never-searched bucket is a pure
+//     insertion chain, so late replay is equivalent), then flip them LIVE;
+//   * after SQZ_MAX_REPAIRS repairs (compressible data) the finder replays everything once and
+//     switches to eager mode for the rest of the chunk.
+// Results are identical to inserting everything; only unobservable work is skipped.
+#if SQ_ON_DEVICE
+SQ_DEV void bloom_slots(u32 h, u32* w1, u32* m1, u32* w2, u32* m2) {
+    u32 const g1 = h & 0xFFFFu, g2 = (h * 0x9E3779B1u) >> 16;
+    *w1 = g1 >> 5;
+    *m1 = 1u << (g1 & 31);
+    *w2 = g2 >> 5;
+    *m2 = 1u << (g2 & 31);
+}
+SQ_DEV bool bloom_test(u32 h) {
+    u32 w1, m1, w2, m2;
+    bloom_slots(h, &w1, &m1, &w2, &m2);
+    const SQ_L u32* const B = (const SQ_L u32*)g_lds.u.bloom;
+    return (B[w1] & m1) && (B[w2] & m2);
+}
+SQ_DEV void bloom_add(u32 h) {
+    u32 w1, m1, w2, m2;
+    bloom_slots(h, &w1, &m1, &w2, &m2);
+    SQ_L u32* const B = (SQ_L u32*)g_lds.u.bloom;
+    __hip_atomic_fetch_or(&B[w1], m1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    __hip_atomic_fetch_or(&B[w2], m2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+#else
+SQ_DEV bool bloom_test(u32 h) {
+    u32 const g1 = h & 0xFFFFu, g2 = (h * 0x9E3779B1u) >> 16;
+    return (g_lds.u.bloom[g1 >> 5] & (1u << (g1 & 31))) && (g_lds.u.bloom[g2 >> 5] & (1u << (g2 & 31)));
+}
+SQ_DEV void bloom_add(u32 h) {
+    u32 const g1 = h & 0xFFFFu, g2 = (h * 0x9E3779B1u) >> 16;
+    g_lds.u.bloom[g1 >> 5] |= 1u << (g1 & 31);
+    g_lds.u.bloom[g2 >> 5] |= 1u << (g2 & 31);
+}
+#endif
+SQ_DEVFN void bloom_rebuild(MatchState& ms) {
+    wv_zero_lds(g_lds.u.bloom, SQZ_BLOOM_WORDS);
+#if SQ_ON_DEVICE
+    for (u32 i = wv_lane(); i < ms.nLive; i += 64) bloom_add(sq_gld32(ms.liveList + i));
+    wv_mem_sync();
+#else
+    for (u32 i = 0; i < ms.nLive; i++) bloom_add(ms.liveList[i]);
+#endif
+}
+
+// Insert positions [from, to) as unsorted candidates (ZSTD_updateDUBT) into the buckets selected
+// by MODE: 0 = regular update (live buckets; all buckets in eager mode), 1 = repair replay
+// (PENDING buckets), 2 = go-eager replay (every bucket that is not LIVE).
+template <int MODE>
+SQ_DEVFN void dubt_insert_range(MatchState& ms, u32 from, u32 to) {
     u32* const hashTable = ms.hashTable;
     u32 const hashLog = ms.cp.hashLog;
     u32* const bt = ms.chainTable;
     u32 const btMask = (1u << (ms.cp.chainLog - 1)) - 1;
     const u8* const base = ms.base;
+    bool const all = (MODE == 0) && ms.eager;
 #if SQ_ON_DEVICE
-    // Software-pipelined: U batches of 64 positions per iteration.  The hash-table gather of a
-    // batch feeds only that batch's bt store, while the scatter (new heads) needs just the
-    // position, so gather/scatter pairs of successive batches are issued back to back (one wave's
-    // memory operations to one address are performed in program order) and the bt stores are
-    // delayed to the end of the iteration: one memory round trip per U*64 positions.
+    // 64 positions per step.  A gather may hit a head written by the previous step and a load is
+    // not ordered behind an older store of the same wave, so a step that stored drains first.
     u32 const lane = wv_lane();
-    constexpr int U = 8;
-    u32 idx0 = ms.nextToUpdate;
-    for (; idx0 + 64 * U <= target; idx0 += 64 * U) {
-        u32 w[U], prev[U];
-#pragma unroll
-        for (int u = 0; u < U; u++) w[u] = sq_grd32(base + idx0 + 64 * u + lane);
-#pragma unroll
-        for (int u = 0; u < U; u++) {
-            u32 const idx = idx0 + 64 * u + lane;
-            u32 const h = hash4(w[u], hashLog);
-            WvGroup const g = wv_group(h, true, g_lds.grp);
-            u32 pv = idx0 + 64 * u + g.prevLane;
-            if (g.prevLane >= 64) pv = sq_gld32(hashTable + h);
-            prev[u] = pv;
-            if (g.rank + 1 == g.gsize) sq_gst32(hashTable + h, idx);
-        }
-#pragma unroll
-        for (int u = 0; u < U; u++) {
-            u32 const idx = idx0 + 64 * u + lane;
-            sq_gst64v(bt + 2 * (idx & btMask), prev[u], SQZ_DUBT_UNSORTED);
-        }
-    }
-    for (; idx0 < target; idx0 += 64) {
+    for (u32 idx0 = from; idx0 < to; idx0 += 64) {
         u32 const idx = idx0 + lane;
-        bool const active = idx < target;
+        bool const active = idx < to;
         u32 h = 0;
         if (active) h = hash4(sq_grd32(base + idx), hashLog);
-        WvGroup const g = wv_group(h, active, g_lds.grp);
-        if (active) {
-            u32 prev;
-            if (g.prevLane < 64)
-                prev = idx0 + g.prevLane;
-            else
-                prev = sq_gld32(hashTable + h);
+        bool cand = active;
+        if (MODE != 2 && !all) cand = active && bloom_test(h);
+        u32 head = 0;
+        if (cand) head = sq_tld32(hashTable + h);
+        bool take;
+        if (MODE == 0)
+            take = cand && (all || (head & SQZ_HT_LIVE));
+        else if (MODE == 1)
+            take = cand && (head & SQZ_HT_PEND) && !(head & SQZ_HT_LIVE);
+        else
+            take = cand && !(head & SQZ_HT_LIVE);
+        if (wv_ballot(take) == 0) continue;
+        WvGroup const g = wv_group(h, take, g_lds.grp);
+        if (take) {
+            u32 const prev = (g.prevLane < 64) ? idx0 + g.prevLane : (head & SQZ_HT_IDX);
             sq_gst64v(bt + 2 * (idx & btMask), prev, SQZ_DUBT_UNSORTED);
-            if (g.rank + 1 == g.gsize) sq_gst32(hashTable + h, idx);
+            if (g.rank + 1 == g.gsize) sq_gst32(hashTable + h, idx | (head & ~SQZ_HT_IDX));
         }
+        wv_mem_sync();
     }
-    wv_fence();
 #else
-    for (u32 idx = ms.nextToUpdate; idx < target; idx++) {
+    for (u32 idx = from; idx < to; idx++) {
         u32 const h = hash4(sq_rd32(base + idx), hashLog);
-        u32 const matchIndex = hashTable[h];
-        hashTable[h] = idx;
-        bt[2 * (idx & btMask)] = matchIndex;
+        if (MODE != 2 && !all && !bloom_test(h)) continue;
+        u32 const head = hashTable[h];
+        bool take;
+        if (MODE == 0)
+            take = all || (head & SQZ_HT_LIVE);
+        else if (MODE == 1)
+            take = (head & SQZ_HT_PEND) && !(head & SQZ_HT_LIVE);
+        else
+            take = !(head & SQZ_HT_LIVE);
+        if (!take) continue;
+        hashTable[h] = idx | (head & ~SQZ_HT_IDX);
+        bt[2 * (idx & btMask)] = head & SQZ_HT_IDX;
         bt[2 * (idx & btMask) + 1] = SQZ_DUBT_UNSORTED;
     }
 #endif
+}
+
+// replay [2, to) minus the ranges libzstd never inserted
+template <int MODE>
+SQ_DEVFN void dubt_replay(MatchState& ms, u32 to) {
+    u32 pos = SQZ_WINDOW_START;
+    for (u32 k = 0; k < ms.nSkip && pos < to; k++) {
+        u32 const a = gld32(ms.skipList + 2 * k), b = gld32(ms.skipList + 2 * k + 1);
+        if (a > pos) dubt_insert_range<MODE>(ms, pos, a < to ? a : to);
+        if (b > pos) pos = b;
+    }
+    if (pos < to) dubt_insert_range<MODE>(ms, pos, to);
+}
+
+SQ_DEVFN void filter_go_eager(MatchState& ms) {
+    if (ms.eager) return;
+    dubt_replay<2>(ms, ms.nextToUpdate);
+    ms.eager = 1;
+}
+
+// positions [from, to) are never inserted by libzstd (nextToUpdate jumped over them)
+SQ_DEV void filter_add_skip(MatchState& ms, u32 from, u32 to) {
+    if (ms.eager || ms.cp.strategy != STRAT_BTLAZY2 || to <= from) return;
+    if (ms.nSkip >= SQZ_SKIP_CAP) {
+        filter_go_eager(ms);
+        return;
+    }
+    gst32(ms.skipList + 2 * ms.nSkip, from);
+    gst32(ms.skipList + 2 * ms.nSkip + 1, to);
+    wv_mem_sync();
+    ms.nSkip++;
+}
+
+// The lazy parser's no-match search schedule from (pos, anchor) to the end of the chunk.
+SQ_DEVFN u32 filter_predict(MatchState& ms, u32 pos, u32 anc) {
+    WV_SERIAL {
+        u32 n = 0, p = pos, a = anc, bEnd = ms.blockEndPos;
+        u32* const sched = ms.sched;
+        for (;;) {
+            u32 const ilimit = bEnd - 8;
+            while (p < ilimit && n < SQZ_SCHED_CAP) {
+                sched[n++] = p;
+                p += ((p - a) >> 8) + 1;
+            }
+            if (bEnd >= ms.chunkEndPos || n >= SQZ_SCHED_CAP) break;
+            u32 nb = bEnd + (128u << 10);
+            if (nb > ms.chunkEndPos) nb = ms.chunkEndPos;
+            if (nb - bEnd < 9) break; // too small to search
+            p = a = bEnd;
+            bEnd = nb;
+        }
+        g_lds.ret[0] = n;
+    }
+    wv_mem_sync();
+    return g_lds.ret[0];
+}
+
+// Buckets of the n predicted positions (and +1, +2) become PENDING; returns nothing, appends to
+// liveList / Bloom.  Caller guarantees capacity.
+SQ_DEVFN void filter_mark(MatchState& ms, u32 n) {
+    u32 const total = n * 3;
+    u32 const hashLog = ms.cp.hashLog;
+#if SQ_ON_DEVICE
+    u32 const lane = wv_lane();
+    for (u32 i0 = 0; i0 < total; i0 += 64) {
+        u32 const i = i0 + lane;
+        bool fresh = false;
+        u32 h = 0;
+        if (i < total) {
+            u32 const p = sq_gld32(ms.sched + i / 3) + (i % 3);
+            if (p + 8 <= ms.chunkEndPos) {
+                h = hash4(sq_grd32(ms.base + p), hashLog);
+                u32 const v = sq_tld32(ms.hashTable + h);
+                if (!(v & (SQZ_HT_LIVE | SQZ_HT_PEND))) {
+                    sq_gst32(ms.hashTable + h, v | SQZ_HT_PEND);
+                    fresh = true;
+                }
+            }
+        }
+        u64 const m = wv_ballot(fresh);
+        if (m) {
+            if (fresh) {
+                u32 const r = (u32)__popcll(m & ((lane == 0) ? 0ull : (~0ull >> (64 - lane))));
+                sq_gst32(ms.liveList + ms.nLive + r, h);
+                bloom_add(h);
+            }
+            ms.nLive += (u32)__popcll(m);
+            wv_mem_sync();
+        }
+    }
+#else
+    for (u32 i = 0; i < total; i++) {
+        u32 const p = ms.sched[i / 3] + (i % 3);
+        if (p + 8 > ms.chunkEndPos) continue;
+        u32 const h = hash4(sq_rd32(ms.base + p), hashLog);
+        u32 const v = ms.hashTable[h];
+        if (!(v & (SQZ_HT_LIVE | SQZ_HT_PEND))) {
+            ms.hashTable[h] = v | SQZ_HT_PEND;
+            ms.liveList[ms.nLive++] = h;
+            bloom_add(h);
+        }
+    }
+#endif
+}
+// PENDING -> LIVE for liveList[start, nLive)
+SQ_DEVFN void filter_finalize(MatchState& ms, u32 start) {
+#if SQ_ON_DEVICE
+    for (u32 i = start + wv_lane(); i < ms.nLive; i += 64) {
+        u32 const h = sq_gld32(ms.liveList + i);
+        u32 const v = sq_tld32(ms.hashTable + h);
+        sq_gst32(ms.hashTable + h, (v & ~SQZ_HT_PEND) | SQZ_HT_LIVE);
+    }
+    wv_mem_sync();
+#else
+    for (u32 i = start; i < ms.nLive; i++) {
+        u32 const h = ms.liveList[i];
+        ms.hashTable[h] = (ms.hashTable[h] & ~SQZ_HT_PEND) | SQZ_HT_LIVE;
+    }
+#endif
+}
+// (re)predict from the real parser state and make the predicted buckets live
+SQ_DEVFN void filter_repair(MatchState& ms, u32 pos, u32 anc, bool first) {
+    if (ms.eager) return;
+    if (!first) {
+        if (ms.nRepairs >= SQZ_MAX_REPAIRS) {
+            filter_go_eager(ms);
+            return;
+        }
+        ms.nRepairs++;
+    }
+    u32 const n = filter_predict(ms, pos, anc);
+    if (ms.nLive + 3 * n > SQZ_LIVE_CAP) {
+        filter_go_eager(ms);
+        return;
+    }
+    u32 const start = ms.nLive;
+    filter_mark(ms, n);
+    if (ms.nLive > start) {
+        if (!first && ms.nextToUpdate > SQZ_WINDOW_START) dubt_replay<1>(ms, ms.nextToUpdate);
+        filter_finalize(ms, start);
+    }
+}
+
+// ZSTD_updateDUBT
+SQ_DEVFN void dubt_update(MatchState& ms, u32 target) {
+    dubt_insert_range<0>(ms, ms.nextToUpdate, target);
     ms.nextToUpdate = target;
 }
 
@@ -192,6 +415,16 @@ SQ_DEVFN void dubt_insert1(MatchState& ms, u32 curr, const u8* inputEnd, u32 nbC
     u32 matchIndex = gld32(smallerPtr);
     u32 const windowLow = SQZ_WINDOW_START; // window always covers the whole chunk (see get_cparams)
     for (; nbCompares && (matchIndex > windowLow); --nbCompares) {
+        if (matchIndex >= curr) {
+            ms.fault = 1;
+            SQ_TRACE(16, 1);
+            SQ_TRACE(17, matchIndex);
+            SQ_TRACE(18, curr);
+            SQ_TRACE(19, nbCompares);
+            SQ_TRACE(20, (u32)(smallerPtr - bt));
+            SQ_TRACE(21, (u32)(largerPtr - bt));
+            break;
+        }
         u32* const nextPtr = bt + 2 * (matchIndex & btMask);
         u32 child0, child1, mLess = 0;
         gld_pair(nextPtr, &child0, &child1);
@@ -221,7 +454,7 @@ SQ_DEVFN void dubt_insert1(MatchState& ms, u32 curr, const u8* inputEnd, u32 nbC
     }
     gst32(smallerPtr, 0);
     gst32(largerPtr, 0);
-    wv_fence();
+    wv_mem_sync();
 }
 
 // ZSTD_DUBT_findBestMatch (noDict, mls 4)
@@ -229,9 +462,14 @@ SQ_DEVFN u32 dubt_find(MatchState& ms, const u8* const ip, const u8* const iend,
     u32* const hashTable = ms.hashTable;
     u32 const hashLog = ms.cp.hashLog;
     u32 const h = hash4(srd32(ip), hashLog);
-    u32 matchIndex = gld32(hashTable + h);
     const u8* const base = ms.base;
     u32 const curr = (u32)(ip - base);
+    u32 headWord = gld32(hashTable + h);
+    if (!ms.eager && !(headWord & SQZ_HT_LIVE)) { // the schedule changed: make this bucket exact
+        filter_repair(ms, curr, ms.anchorPos, false);
+        headWord = gld32(hashTable + h);
+    }
+    u32 matchIndex = headWord & SQZ_HT_IDX;
     u32 const windowLow = SQZ_WINDOW_START;
     u32* const bt = ms.chainTable;
     u32 const btMask = (1u << (ms.cp.chainLog - 1)) - 1;
@@ -263,7 +501,7 @@ SQ_DEVFN u32 dubt_find(MatchState& ms, const u8* const ip, const u8* const iend,
             gst32(unsortedMark, 0);
         }
     }
-    wv_fence();
+    wv_mem_sync();
     matchIndex = previousCandidate;
     while (matchIndex) {
         u32* const nextCandidateIdxPtr = bt + 2 * (matchIndex & btMask) + 1;
@@ -279,8 +517,19 @@ SQ_DEVFN u32 dubt_find(MatchState& ms, const u8* const ip, const u8* const iend,
         u32 matchEndIdx = curr + 8 + 1;
         u32 bestLength = 0;
         matchIndex = headIndex;
-        gst32(hashTable + h, curr);
+        gst32(hashTable + h, curr | (headWord & ~SQZ_HT_IDX));
         for (; nbCompares && (matchIndex > windowLow); --nbCompares) {
+            if (matchIndex >= curr) {
+                ms.fault = 1;
+                SQ_TRACE(16, 2);
+                SQ_TRACE(17, matchIndex);
+                SQ_TRACE(18, curr);
+                SQ_TRACE(19, nbCompares);
+                SQ_TRACE(20, headIndex);
+                SQ_TRACE(21, h);
+                SQ_TRACE(22, previousCandidate);
+                break;
+            }
             u32* const nextPtr = bt + 2 * (matchIndex & btMask);
             u32 child0, child1, mLess = 0;
             gld_pair(nextPtr, &child0, &child1);
@@ -318,7 +567,8 @@ SQ_DEVFN u32 dubt_find(MatchState& ms, const u8* const ip, const u8* const iend,
         }
         gst32(smallerPtr, 0);
         gst32(largerPtr, 0);
-        wv_fence();
+        wv_mem_sync();
+        if (matchEndIdx - 8 > curr + 1) filter_add_skip(ms, curr + 1, matchEndIdx - 8);
         ms.nextToUpdate = matchEndIdx - 8;
         return bestLength;
     }
@@ -363,7 +613,7 @@ SQ_DEVFN void row_insert_range(MatchState& ms, u32 from, u32 to) {
         if (active) {
             u8* const tagRow = ms.tagTable + relRow;
             u32* const row = ms.hashTable + relRow;
-            hb = sq_grd8(tagRow);
+            hb = sq_tld8(tagRow);
             u32 const pos = row_pos_after(hb, g.rank + 1);
             if (g.rank + 63 >= g.gsize) { // not overwritten by a later lane of this batch
                 sq_gwr8(tagRow + pos, hash);
@@ -373,7 +623,7 @@ SQ_DEVFN void row_insert_range(MatchState& ms, u32 from, u32 to) {
         wv_fence();
         // heads are written after every lane has read its (old) head byte
         if (active && g.rank + 1 == g.gsize) sq_gwr8(ms.tagTable + relRow, row_pos_after(hb, g.gsize));
-        wv_fence();
+        wv_mem_sync();
     }
 #else
     for (u32 idx = from; idx < to; idx++) {
@@ -424,10 +674,11 @@ SQ_DEVFN u32 row_find(MatchState& ms, const u8* const ip, const u8* const iLimit
     u32 const hb = gld8(tagRow);
     u32 const head = hb & 63;
     u32 const matchPos = (head + lane) & 63;
-    u32 const t = sq_grd8(tagRow + matchPos);
-    u32 const cand = sq_gld32(row + matchPos);
+    u32 const t = sq_tld8(tagRow + matchPos);
+    u32 const cand = sq_tld32(row + matchPos);
     bool const hit = (t == tag) && (matchPos != 0);
     u64 const M = wv_ballot(hit);
+    if (wv_ballot(hit && cand >= curr)) ms.fault = 1;
     u64 const B = wv_ballot(hit && cand < lowLimit);
     u64 valid = M;
     if (B) {
@@ -444,7 +695,7 @@ SQ_DEVFN u32 row_find(MatchState& ms, const u8* const ip, const u8* const iLimit
         }
         ms.nextToUpdate++;
     }
-    wv_fence();
+    wv_mem_sync();
     if (valid) {
         // one candidate per lane: full match length, then first-maximum selection
         u32 L = 0;
@@ -553,6 +804,7 @@ SQ_DEVFN u32 compressBlock_lazy(MatchState& ms, SeqStore& ss, u32* rep, const u8
         u32 matchLength = 0;
         u32 offBase = 1; // REPCODE1_TO_OFFBASE
         const u8* start = ip + 1;
+        ms.anchorPos = (u32)(anchor - base);
 
         if ((offset_1 > 0) && (srd32(ip + 1 - offset_1) == srd32(ip + 1))) {
             matchLength = wv_count(ip + 1 + 4, ip + 1 + 4 - offset_1, (u32)(iend - (ip + 1 + 4))) + 4;

@@ -4,6 +4,7 @@
 // GPU.  Never linked into libsquish_gpu.so; not a fallback for anything.
 #define SQ_SIM 1
 #include "../../squishrs_amd/csrc/sq_zstd_kernel.h"
+#include <stdio.h>
 #include <stdlib.h>
 
 extern "C" size_t sim_compress_chunk(const uint8_t* src, size_t n, uint8_t* dst, size_t cap, int poison) {
@@ -14,6 +15,10 @@ extern "C" size_t sim_compress_chunk(const uint8_t* src, size_t n, uint8_t* dst,
     memset(&sqz::g_lds, poison ? 0x5A : 0, sizeof(sqz::g_lds));
     u8* wsa = (u8*)(((uintptr_t)ws + 255) & ~(uintptr_t)255);
     u32 r = sqz::compress_frame_wave(src, (u32)n, dst, (u32)cap, wsa, L);
+    if (getenv("SQ_SIM_STATS")) {
+        const u32* t = (const u32*)(wsa + L.dummy) + 8;
+        fprintf(stderr, "[sim] n=%zu eager=%u repairs=%u live=%u skips=%u\n", n, t[30], t[31], t[32], t[33]);
+    }
     free(ws);
     return r;
 }

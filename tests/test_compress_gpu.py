@@ -148,3 +148,53 @@ def test_direct_vs_libzstd_when_present(gpu_store):
     chunks = [corpus.text_like(77, 100000), corpus.mixed(78, 500000), corpus.records(79, 12000)]
     for c, f in zip(chunks, _batch_compress(gpu_store, chunks)):
         assert f == zref.compress(c)
+
+
+def test_scale_no_corruption_random_256k(gpu_store, oracle):
+    """30,000 random 256 KiB chunks through the persistent kernel (many chunks per wave, so every
+    workspace is reused dozens of times): every frame must be the 262,159-byte two-raw-block frame
+    whose payload is the input; a sample is compared with the oracle bit for bit.  Guards against
+    stale table words leaking from one chunk into the next."""
+    import torch
+    import corpus_gpu
+    import squishrs_amd
+    n, L = 30000, 262144
+    data = corpus_gpu.random_chunks(5, 0, n, L, device="cuda", group=8192)
+    offs = np.arange(n, dtype=np.uint64) * np.uint64(L)
+    lens = np.full(n, L, dtype=np.uint32)
+    comp = torch.empty(n * (squishrs_amd.compress_bound(L) + 16), dtype=torch.uint8, device="cuda")
+    for _ in range(2):
+        coff = gpu_store.compress_device(data, offs, lens, None, comp)
+        sizes = np.diff(coff.astype(np.int64))
+        assert (sizes == 262159).all(), np.nonzero(sizes != 262159)[0][:10]
+        frames = comp[:n * 262159].view(n, 262159)
+        assert torch.equal(frames[:, 12:12 + 131072], data.view(n, L)[:, :131072])
+        assert torch.equal(frames[:, 12 + 131072 + 3:], data.view(n, L)[:, 131072:])
+    for i in (0, 12345, n - 1):
+        c = corpus.random_bytes(5, i, L)
+        assert frames[i].cpu().numpy().tobytes() == oracle.compress_chunk(c)
+
+
+def test_scale_compressible_sampled_decode(gpu_store, oracle):
+    """1,024 compressible 256 KiB chunks + 96 mixed 2 MiB chunks: every frame of a spread sample
+    decodes back to its input with the oracle's independent decoder and equals the oracle frame."""
+    rng = np.random.default_rng(3)
+    kinds = ["text", "records", "mixed", "skewed"]
+    chunks = [corpus.make(kinds[i % 4], 1000 + (i % 37), 262144) for i in range(1024)]
+    frames = _batch_compress(gpu_store, chunks)
+    ref = {}
+    for i in rng.choice(len(chunks), size=48, replace=False):
+        key = (kinds[i % 4], 1000 + (i % 37))
+        if key not in ref:
+            ref[key] = oracle.compress_chunk(chunks[i])
+        assert frames[i] == ref[key], i
+    big = [corpus.mixed(500 + (i % 12), 2097152) for i in range(96)]
+    fb = _batch_compress(gpu_store, big)
+    refb = {}
+    for i in range(0, 96, 5):
+        k = i % 12
+        if k not in refb:
+            refb[k] = oracle.compress_chunk(big[i])
+        assert fb[i] == refb[k], i
+    for i in range(96):
+        assert fb[i] == fb[i % 12]          # identical inputs -> identical frames, whichever wave
