@@ -426,7 +426,7 @@ static int compress_async(sq_ctx* c, const u8* d_data, const u64* h_off, const u
             for (int k = 0; k < 13; k++) tot[k] += one[k];
         }
         static const char* nm[13] = {"frame_total", "table_clear", "dubt_update", "dubt_find", "row_update", "row_find",
-                                     "entropy", "copies", "presplit", "-", "-", "-", "chunks+1"};
+                                     "entropy", "copies", "presplit+filterinit", "epoch_insert", "epoch_predicate", "epoch_rollback", "chunks+1"};
         fprintf(stderr, "[squish_gpu prof] waves=%u kernel=%.2f ms; per-wave mean ms:", waves, c->last.compress_ms);
         for (int k = 0; k < 13; k++)
             if (nm[k][0] != '-') fprintf(stderr, " %s=%.3f", nm[k], k == 12 ? (double)tot[k] / waves : (double)tot[k] / waves / 1e5);

@@ -26,7 +26,7 @@ struct Fingerprint {
 
 struct WsLayout {
     size_t hashTable, table2, hashTable3, seqs, lits, llCode, ofCode, mlCode, optState, fp, sched, liveList,
-        skipList, dummy, total;
+        skipList, blockTab, dummy, total;
 };
 
 #if SQ_ON_DEVICE
@@ -98,6 +98,8 @@ SQ_HD WsLayout ws_layout(u32 max_len) {
     o += ws_align((size_t)SQZ_LIVE_CAP * 4);
     L.skipList = o;
     o += ws_align((size_t)SQZ_SKIP_CAP * 8);
+    L.blockTab = o;
+    o += ws_align((size_t)SQZ_BLOCKTAB_CAP * 8);
     L.dummy = o;
     o += 256;
     L.total = o;
@@ -204,6 +206,15 @@ SQ_DEVFN u32 compressBlock_internal(MatchState& ms, SeqStore& ss, BlockState& bs
         {
             u32 const curr = (u32)(src - ms.base);
             ms.blockEndPos = curr + srcSize;
+            if (ms.cp.strategy == STRAT_BTLAZY2) {
+                if (ms.nBlocks < SQZ_BLOCKTAB_CAP) {
+                    gst32(ms.blockTab + 2 * ms.nBlocks, curr);
+                    gst32(ms.blockTab + 2 * ms.nBlocks + 1, curr + srcSize);
+                    ms.nBlocks++;
+                    wv_mem_sync();
+                } else
+                    ms.specOff = 1; // no room to remember this block's end: no deferred searches in it
+            }
             if (!ms.eager && !bs.isFirstBlock) bloom_rebuild(ms); // the entropy stage reused the LDS
             if (curr > ms.nextToUpdate + 384) {
                 u32 const d = curr - ms.nextToUpdate - 384;
@@ -212,6 +223,7 @@ SQ_DEVFN u32 compressBlock_internal(MatchState& ms, SeqStore& ss, BlockState& bs
                 ms.nextToUpdate = n2u;
             }
         }
+        ms.nxEnt = nx;
         for (int i = 0; i < SQZ_REP_NUM; ++i) bs.rep[nx][i] = bs.rep[p][i];
         u32 lastLLSize;
         SQ_TRACE(0, 6);
@@ -340,7 +352,11 @@ SQ_DEVFN u32 compress_frame_wave(const u8* src, u32 n, u8* dst, u32 cap, u8* ws,
     ms.sched = (u32*)(ws + L.sched);
     ms.liveList = (u32*)(ws + L.liveList);
     ms.skipList = (u32*)(ws + L.skipList);
-    ms.nLive = ms.nSkip = 0;
+    ms.blockTab = (u32*)(ws + L.blockTab);
+    ms.nLive = ms.nSkip = ms.nBlocks = 0;
+    ms.specOff = 0;
+    ms.nxEnt = 1;
+    ms.nEpoch = ms.nSpecFail = ms.nReplay = 0;
     SQ_TRACE(0, 2);
     PROF_T0(t_clr);
     wv_fill32(ms.hashTable, 0, (size_t)1 << cp.hashLog);
@@ -374,8 +390,10 @@ SQ_DEVFN u32 compress_frame_wave(const u8* src, u32 n, u8* dst, u32 cap, u8* ws,
     bs.isFirstBlock = 1;
     wv_mem_sync();
     if (!ms.eager && n >= 9) { // btlazy2: predict the no-match search schedule, make its buckets live
+        PROF_T0(t_fs);
         wv_zero_lds(g_lds.u.bloom, SQZ_BLOOM_WORDS);
         filter_repair(ms, SQZ_WINDOW_START + 1, SQZ_WINDOW_START, true);
+        PROF_ADD(8, t_fs);
     }
 
     if (n == 0) { // ZSTD_writeLastEmptyBlock
@@ -435,6 +453,9 @@ SQ_DEVFN u32 compress_frame_wave(const u8* src, u32 n, u8* dst, u32 cap, u8* ws,
     SQ_TRACE(31, ms.nRepairs);
     SQ_TRACE(32, ms.nLive);
     SQ_TRACE(33, ms.nSkip);
+    SQ_TRACE(34, ms.nEpoch);
+    SQ_TRACE(35, ms.nSpecFail);
+    SQ_TRACE(36, ms.nReplay);
     return (u32)(op - dst);
 }
 

@@ -89,7 +89,11 @@ struct MatchState {
     u32* sched;      // predicted search positions (workspace)
     u32* liveList;   // bucket ids made live so far (workspace); rebuilds the Bloom filter per block
     u32* skipList;   // [from,to) position ranges libzstd itself never inserts (workspace)
-    u32 nLive, nSkip;
+    u32* blockTab;   // (start, end) index pairs of the blocks compressed so far (workspace)
+    u32 nLive, nSkip, nBlocks;
+    u32 specOff;     // 1 = speculative search epochs disabled
+    u32 nxEnt;       // index of the entropy-table slot that is scratch during match finding
+    u32 nEpoch, nSpecFail, nReplay; // statistics (trace words 34..36)
     CParams cp;
 };
 
@@ -101,6 +105,8 @@ struct MatchState {
 #define SQZ_LIVE_CAP (96u << 10)
 #define SQZ_SKIP_CAP 256u
 #define SQZ_MAX_REPAIRS 24u
+#define SQZ_BLOCKTAB_CAP 64u
+#define SQZ_DUBT_SEARCHED 0xFFFFFFFFu // sort mark of a deferred (not yet replayed) search node
 
 SQ_DEV u32 hash4(u32 v, u32 hBits) { return (v * 2654435761U) >> (32 - hBits); }
 SQ_DEV u32 hash5(u64 v, u32 hBits) { return (u32)(((v << 24) * 889523592379ULL) >> (64 - hBits)); }
@@ -206,10 +212,117 @@ SQ_DEVFN void dubt_insert_range(MatchState& ms, u32 from, u32 to) {
     const u8* const base = ms.base;
     bool const all = (MODE == 0) && ms.eager;
 #if SQ_ON_DEVICE
+    u32 const lane = wv_lane();
+    u64 const below = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+    u32 idx0 = from;
+    if (MODE != 2 && !all) {
+        // Filtered stream: super-batches of 1024 positions.  Phase 1 hashes all of them and keeps
+        // the Bloom-positive ones (a few %) in an LDS staging list, in position order; phase 2
+        // gathers their table words in one go and keeps the positions whose bucket qualifies;
+        // phase 3 inserts those (usually < 64) with the ordered per-step procedure.  Memory round
+        // trips per 1024 positions: ~4 instead of ~2 per 64.
+        // staging: candidates (idx, h) in the wv_group scratch, survivors (idx, h, head) in the
+        // "next" entropy-table slot, which is dead until the entropy stage of this block
+        SQ_L u32* const stage = (SQ_L u32*)g_lds.grp;
+        SQ_L u32* const surv = (SQ_L u32*)&g_lds.ent[ms.nxEnt & 1];
+        bool pendingStores = false;
+        for (; idx0 + 2048 <= to; idx0 += 2048) {
+            u32 cnt = 0;
+            // phase 1: two rounds of 16 coalesced loads; all Bloom probes of a round are issued
+            // before any staging write so the LDS reads pipeline instead of serialising
+#pragma unroll 1
+            for (u32 r = 0; r < 2; r++) {
+                u32 w[16];
+#pragma unroll
+                for (u32 u = 0; u < 16; u++) w[u] = sq_grd32(base + idx0 + 1024 * r + 64 * u + lane);
+                u32 cm = 0;
+#pragma unroll
+                for (u32 u = 0; u < 16; u++) {
+                    w[u] = hash4(w[u], hashLog);
+                    cm |= (bloom_test(w[u]) ? 1u : 0u) << u;
+                }
+                wv_fence();
+#pragma unroll
+                for (u32 u = 0; u < 16; u++) {
+                    bool const c = (cm >> u) & 1;
+                    u64 const m = wv_ballot(c);
+                    if (c) {
+                        u32 const slot = cnt + (u32)__popcll(m & below);
+                        if (slot < 256) {
+                            stage[2 * slot] = idx0 + 1024 * r + 64 * u + lane;
+                            stage[2 * slot + 1] = w[u];
+                        }
+                    }
+                    cnt += (u32)__popcll(m);
+                }
+                wv_fence();
+            }
+            if (cnt > 256) break; // Bloom saturated: finish with the simple loop below
+            wv_fence();
+            if (pendingStores) { // the previous super-batch's table stores must land before we gather
+                wv_mem_sync();
+                pendingStores = false;
+            }
+            // phase 2: one round trip for all candidates' table words; survivors -> surv[]
+            u32 cidx[4], ch[4], chead[4];
+#pragma unroll
+            for (u32 g = 0; g < 4; g++) {
+                u32 const j = 64 * g + lane;
+                cidx[g] = ch[g] = chead[g] = 0;
+                if (j < cnt) {
+                    cidx[g] = stage[2 * j];
+                    ch[g] = stage[2 * j + 1];
+                    chead[g] = sq_tld32(hashTable + ch[g]);
+                }
+            }
+            u32 ntake = 0;
+#pragma unroll
+            for (u32 g = 0; g < 4; g++) {
+                bool take = (64 * g + lane) < cnt;
+                if (MODE == 0)
+                    take = take && (chead[g] & SQZ_HT_LIVE);
+                else
+                    take = take && (chead[g] & SQZ_HT_PEND) && !(chead[g] & SQZ_HT_LIVE);
+                u64 const m = wv_ballot(take);
+                if (take) {
+                    u32 const slot = ntake + (u32)__popcll(m & below);
+                    surv[3 * slot] = cidx[g];
+                    surv[3 * slot + 1] = ch[g];
+                    surv[3 * slot + 2] = chead[g];
+                }
+                ntake += (u32)__popcll(m);
+            }
+            wv_fence();
+            // phase 3: ordered insertion of the survivors, 64 per step (usually a single step that
+            // reuses the heads gathered in phase 2)
+            for (u32 j0 = 0; j0 < ntake; j0 += 64) {
+                u32 const j = j0 + lane;
+                bool const act = j < ntake;
+                u32 idx = 0, h = 0, head = 0;
+                if (act) {
+                    idx = surv[3 * j];
+                    h = surv[3 * j + 1];
+                    head = surv[3 * j + 2];
+                }
+                if (j0 > 0) { // an earlier step of this super-batch may have rewritten these heads
+                    wv_mem_sync();
+                    if (act) head = sq_tld32(hashTable + h);
+                }
+                WvGroup const g = wv_group(h, act, g_lds.grp);
+                u32 const prevPos = (u32)__shfl((int)idx, (int)(g.prevLane & 63), 64);
+                if (act) {
+                    u32 const prev = (g.prevLane < 64) ? prevPos : (head & SQZ_HT_IDX);
+                    sq_gst64v(bt + 2 * (idx & btMask), prev, SQZ_DUBT_UNSORTED);
+                    if (g.rank + 1 == g.gsize) sq_gst32(hashTable + h, idx | (head & ~SQZ_HT_IDX));
+                }
+                pendingStores = true;
+            }
+        }
+        if (pendingStores) wv_mem_sync();
+    }
     // 64 positions per step.  A gather may hit a head written by the previous step and a load is
     // not ordered behind an older store of the same wave, so a step that stored drains first.
-    u32 const lane = wv_lane();
-    for (u32 idx0 = from; idx0 < to; idx0 += 64) {
+    for (; idx0 < to; idx0 += 64) {
         u32 const idx = idx0 + lane;
         bool const active = idx < to;
         u32 h = 0;
@@ -310,12 +423,47 @@ SQ_DEVFN u32 filter_predict(MatchState& ms, u32 pos, u32 anc) {
 }
 
 // Buckets of the n predicted positions (and +1, +2) become PENDING; returns nothing, appends to
-// liveList / Bloom.  Caller guarantees capacity.
-SQ_DEVFN void filter_mark(MatchState& ms, u32 n) {
+// liveList / Bloom.  Caller guarantees capacity.  `first`: the table is still all zero, so the
+// words are stored blindly as LIVE (no gather, no finalize pass).
+SQ_DEVFN void filter_mark(MatchState& ms, u32 n, bool first) {
     u32 const total = n * 3;
     u32 const hashLog = ms.cp.hashLog;
 #if SQ_ON_DEVICE
     u32 const lane = wv_lane();
+    if (first) {
+        u64 const belowm = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+        for (u32 i0 = 0; i0 < total; i0 += 256) {
+            u32 pp[4], ww[4];
+            bool ok[4];
+#pragma unroll
+            for (u32 g = 0; g < 4; g++) {
+                u32 const i = i0 + 64 * g + lane;
+                pp[g] = 0;
+                if (i < total) pp[g] = sq_gld32(ms.sched + i / 3) + (i % 3);
+            }
+#pragma unroll
+            for (u32 g = 0; g < 4; g++) {
+                u32 const i = i0 + 64 * g + lane;
+                ok[g] = (i < total) && (pp[g] + 8 <= ms.chunkEndPos);
+                ww[g] = 0;
+                if (ok[g]) ww[g] = sq_grd32(ms.base + pp[g]);
+            }
+#pragma unroll
+            for (u32 g = 0; g < 4; g++) {
+                u32 const h = hash4(ww[g], hashLog);
+                u64 const m = wv_ballot(ok[g]);
+                if (ok[g]) {
+                    u32 const r = (u32)__popcll(m & belowm);
+                    sq_gst32(ms.hashTable + h, SQZ_HT_LIVE);
+                    sq_gst32(ms.liveList + ms.nLive + r, h);
+                    bloom_add(h);
+                }
+                ms.nLive += (u32)__popcll(m);
+            }
+        }
+        wv_mem_sync();
+        return;
+    }
     for (u32 i0 = 0; i0 < total; i0 += 64) {
         u32 const i = i0 + lane;
         bool fresh = false;
@@ -348,6 +496,12 @@ SQ_DEVFN void filter_mark(MatchState& ms, u32 n) {
         if (p + 8 > ms.chunkEndPos) continue;
         u32 const h = hash4(sq_rd32(ms.base + p), hashLog);
         u32 const v = ms.hashTable[h];
+        if (first) {
+            ms.hashTable[h] = SQZ_HT_LIVE;
+            ms.liveList[ms.nLive++] = h;
+            bloom_add(h);
+            continue;
+        }
         if (!(v & (SQZ_HT_LIVE | SQZ_HT_PEND))) {
             ms.hashTable[h] = v | SQZ_HT_PEND;
             ms.liveList[ms.nLive++] = h;
@@ -388,9 +542,9 @@ SQ_DEVFN void filter_repair(MatchState& ms, u32 pos, u32 anc, bool first) {
         return;
     }
     u32 const start = ms.nLive;
-    filter_mark(ms, n);
-    if (ms.nLive > start) {
-        if (!first && ms.nextToUpdate > SQZ_WINDOW_START) dubt_replay<1>(ms, ms.nextToUpdate);
+    filter_mark(ms, n, first);
+    if (!first && ms.nLive > start) {
+        if (ms.nextToUpdate > SQZ_WINDOW_START) dubt_replay<1>(ms, ms.nextToUpdate);
         filter_finalize(ms, start);
     }
 }
@@ -457,19 +611,14 @@ SQ_DEVFN void dubt_insert1(MatchState& ms, u32 curr, const u8* inputEnd, u32 nbC
     wv_mem_sync();
 }
 
-// ZSTD_DUBT_findBestMatch (noDict, mls 4)
-SQ_DEVFN u32 dubt_find(MatchState& ms, const u8* const ip, const u8* const iend, u32* offBasePtr) {
-    u32* const hashTable = ms.hashTable;
-    u32 const hashLog = ms.cp.hashLog;
-    u32 const h = hash4(srd32(ip), hashLog);
+// Body of ZSTD_DUBT_findBestMatch (noDict, mls 4) for the position `curr`, given the bucket head
+// as it was when `curr` was reached: sorts the unsorted candidates, walks the tree, makes `curr`
+// the root.  Does not touch the hash table.
+SQ_DEVFN u32 dubt_search_core(MatchState& ms, u32 curr, const u8* const iend, u32 const headIndex, u32* offBasePtr,
+                              u32* matchEndIdxOut) {
     const u8* const base = ms.base;
-    u32 const curr = (u32)(ip - base);
-    u32 headWord = gld32(hashTable + h);
-    if (!ms.eager && !(headWord & SQZ_HT_LIVE)) { // the schedule changed: make this bucket exact
-        filter_repair(ms, curr, ms.anchorPos, false);
-        headWord = gld32(hashTable + h);
-    }
-    u32 matchIndex = headWord & SQZ_HT_IDX;
+    const u8* const ip = base + curr;
+    u32 matchIndex = headIndex;
     u32 const windowLow = SQZ_WINDOW_START;
     u32* const bt = ms.chainTable;
     u32 const btMask = (1u << (ms.cp.chainLog - 1)) - 1;
@@ -481,8 +630,6 @@ SQ_DEVFN u32 dubt_find(MatchState& ms, const u8* const ip, const u8* const iend,
     u32 nbCandidates = nbCompares;
     u32 previousCandidate = 0;
     u32 const ipRoom = (u32)(iend - ip);
-
-    u32 const headIndex = matchIndex; // hashTable[h] is not written until the search below
     {
         // one 8-byte load per visited candidate: (next candidate, sort mark)
         u32 nextC = 0, mark = 0;
@@ -510,68 +657,292 @@ SQ_DEVFN u32 dubt_find(MatchState& ms, const u8* const ip, const u8* const iend,
         matchIndex = nextCandidateIdx;
         nbCandidates++;
     }
-    {
-        u32 commonLengthSmaller = 0, commonLengthLarger = 0;
-        u32* smallerPtr = bt + 2 * (curr & btMask);
-        u32* largerPtr = bt + 2 * (curr & btMask) + 1;
-        u32 matchEndIdx = curr + 8 + 1;
-        u32 bestLength = 0;
-        matchIndex = headIndex;
-        gst32(hashTable + h, curr | (headWord & ~SQZ_HT_IDX));
-        for (; nbCompares && (matchIndex > windowLow); --nbCompares) {
-            if (matchIndex >= curr) {
-                ms.fault = 1;
-                SQ_TRACE(16, 2);
-                SQ_TRACE(17, matchIndex);
-                SQ_TRACE(18, curr);
-                SQ_TRACE(19, nbCompares);
-                SQ_TRACE(20, headIndex);
-                SQ_TRACE(21, h);
-                SQ_TRACE(22, previousCandidate);
+    u32 commonLengthSmaller = 0, commonLengthLarger = 0;
+    u32* smallerPtr = bt + 2 * (curr & btMask);
+    u32* largerPtr = bt + 2 * (curr & btMask) + 1;
+    u32 matchEndIdx = curr + 8 + 1;
+    u32 bestLength = 0;
+    matchIndex = headIndex;
+    for (; nbCompares && (matchIndex > windowLow); --nbCompares) {
+        if (matchIndex >= curr) {
+            ms.fault = 1;
+            SQ_TRACE(16, 2);
+            SQ_TRACE(17, matchIndex);
+            SQ_TRACE(18, curr);
+            SQ_TRACE(19, nbCompares);
+            SQ_TRACE(20, headIndex);
+            break;
+        }
+        u32* const nextPtr = bt + 2 * (matchIndex & btMask);
+        u32 child0, child1, mLess = 0;
+        gld_pair(nextPtr, &child0, &child1);
+        u32 matchLength = commonLengthSmaller < commonLengthLarger ? commonLengthSmaller : commonLengthLarger;
+        const u8* const match = base + matchIndex;
+        matchLength += wv_count_cmp(ip + matchLength, match + matchLength, ipRoom - matchLength, &mLess);
+        if (matchLength > bestLength) {
+            if (matchLength > matchEndIdx - matchIndex) matchEndIdx = matchIndex + matchLength;
+            if ((4 * (int)(matchLength - bestLength)) >
+                (int)(sq_highbit32(curr - matchIndex + 1) - sq_highbit32(*offBasePtr))) {
+                bestLength = matchLength;
+                *offBasePtr = OFFSET_TO_OFFBASE(curr - matchIndex);
+            }
+            if (matchLength == ipRoom) break;
+        }
+        if (mLess) {
+            gst32(smallerPtr, matchIndex);
+            commonLengthSmaller = matchLength;
+            if (matchIndex <= btLow) {
+                smallerPtr = ms.dummy;
                 break;
             }
-            u32* const nextPtr = bt + 2 * (matchIndex & btMask);
-            u32 child0, child1, mLess = 0;
-            gld_pair(nextPtr, &child0, &child1);
-            u32 matchLength = commonLengthSmaller < commonLengthLarger ? commonLengthSmaller : commonLengthLarger;
-            const u8* const match = base + matchIndex;
-            matchLength += wv_count_cmp(ip + matchLength, match + matchLength, ipRoom - matchLength, &mLess);
-            if (matchLength > bestLength) {
-                if (matchLength > matchEndIdx - matchIndex) matchEndIdx = matchIndex + matchLength;
-                if ((4 * (int)(matchLength - bestLength)) >
-                    (int)(sq_highbit32(curr - matchIndex + 1) - sq_highbit32(*offBasePtr))) {
-                    bestLength = matchLength;
-                    *offBasePtr = OFFSET_TO_OFFBASE(curr - matchIndex);
-                }
-                if (matchLength == ipRoom) break;
+            smallerPtr = nextPtr + 1;
+            matchIndex = child1;
+        } else {
+            gst32(largerPtr, matchIndex);
+            commonLengthLarger = matchLength;
+            if (matchIndex <= btLow) {
+                largerPtr = ms.dummy;
+                break;
             }
-            if (mLess) {
-                gst32(smallerPtr, matchIndex);
-                commonLengthSmaller = matchLength;
-                if (matchIndex <= btLow) {
-                    smallerPtr = ms.dummy;
-                    break;
+            largerPtr = nextPtr;
+            matchIndex = child0;
+        }
+    }
+    gst32(smallerPtr, 0);
+    gst32(largerPtr, 0);
+    wv_mem_sync();
+    *matchEndIdxOut = matchEndIdx;
+    return bestLength;
+}
+
+// index one past the block that contains position `pos`
+SQ_DEV u32 block_end_of(const MatchState& ms, u32 pos) {
+    for (u32 k = 0; k < ms.nBlocks; k++) {
+        u32 const e = gld32(ms.blockTab + 2 * k + 1);
+        if (pos < e) return e;
+    }
+    return ms.blockEndPos;
+}
+
+// Deferred searches (speculative epochs, below) sit in a bucket's chain as nodes whose sort mark is
+// SQZ_DUBT_SEARCHED and whose `next` is the bucket head at their time.  Before an exact search may
+// use the bucket they are replayed, oldest first, with the very same search body: replaying the
+// search of node s only touches nodes older than s, so the result is the state libzstd would hold.
+SQ_DEVFN void dubt_materialize(MatchState& ms, u32 headIndex) {
+    u32* const bt = ms.chainTable;
+    u32 const btMask = (1u << (ms.cp.chainLog - 1)) - 1;
+    for (;;) {
+        u32 found = 0, foundNext = 0;
+        u32 idx = headIndex;
+        while (idx > SQZ_WINDOW_START) {
+            u32 nx, mk;
+            gld_pair(bt + 2 * (idx & btMask), &nx, &mk);
+            if (mk == SQZ_DUBT_SEARCHED) {
+                found = idx;
+                foundNext = nx;
+            } else if (mk != SQZ_DUBT_UNSORTED)
+                break; // sorted node: nothing deferred below it
+            if (nx >= idx) { // cannot happen in a well-formed chain
+                ms.fault = 1;
+                return;
+            }
+            idx = nx;
+        }
+        if (!found) return;
+        u32 off = 999999999, mend = 0;
+        ms.nReplay++;
+        (void)dubt_search_core(ms, found, ms.base + block_end_of(ms, found), foundNext, &off, &mend);
+        if (ms.fault) return;
+    }
+}
+
+// ZSTD_DUBT_findBestMatch (noDict, mls 4)
+SQ_DEVFN u32 dubt_find(MatchState& ms, const u8* const ip, const u8* const iend, u32* offBasePtr) {
+    u32* const hashTable = ms.hashTable;
+    u32 const h = hash4(srd32(ip), ms.cp.hashLog);
+    u32 const curr = (u32)(ip - ms.base);
+    u32 headWord = gld32(hashTable + h);
+    if (!ms.eager && !(headWord & SQZ_HT_LIVE)) { // the schedule changed: make this bucket exact
+        filter_repair(ms, curr, ms.anchorPos, false);
+        headWord = gld32(hashTable + h);
+    }
+    u32 const headIndex = headWord & SQZ_HT_IDX;
+    dubt_materialize(ms, headIndex);
+    u32 matchEndIdx = curr + 9;
+    u32 const bestLength = dubt_search_core(ms, curr, iend, headIndex, offBasePtr, &matchEndIdx);
+    gst32(hashTable + h, curr | (headWord & ~SQZ_HT_IDX));
+    wv_mem_sync();
+    if (matchEndIdx - 8 > curr + 1) filter_add_skip(ms, curr + 1, matchEndIdx - 8);
+    ms.nextToUpdate = matchEndIdx - 8;
+    return bestLength;
+}
+
+// ---------------------------------------------------------------- speculative search epochs
+// While the lazy parser finds nothing, its next searches are at predictable positions
+// (step = ((ip - anchor) >> 8) + 1) and each one is a chain of dependent memory round trips that
+// almost always ends in "no match".  An epoch evaluates up to 64 of those searches at once, one
+// per lane: (1) the positions up to the last one are inserted in one filtered sweep; (2) every
+// lane walks its own bucket and asks a conservative question -- is there ANY older position in
+// the bucket with the same 4 bytes, does the repcode test fire, is the bucket anything but a plain
+// chain?  (3) searches before the first "maybe" certainly fail; their only effect, the re-sorting
+// of their bucket, is deferred by leaving the searched position in the chain as a SEARCHED node
+// (replayed by dubt_materialize if the bucket is ever searched for real); (4) insertions at or
+// beyond the first "maybe" are rolled back and the parser continues there with the exact code.
+SQ_DEVFN void dubt_rollback(MatchState& ms, u32 from, u32 to) {
+    u32* const hashTable = ms.hashTable;
+    u32* const bt = ms.chainTable;
+    u32 const btMask = (1u << (ms.cp.chainLog - 1)) - 1;
+    u32 const hashLog = ms.cp.hashLog;
+    bool const all = ms.eager != 0;
+#if SQ_ON_DEVICE
+    u32 const lane = wv_lane();
+    for (u32 idx0 = from; idx0 < to; idx0 += 64) {
+        u32 const idx = idx0 + lane;
+        if (idx < to) {
+            u32 const h = hash4(sq_grd32(ms.base + idx), hashLog);
+            if (all || bloom_test(h)) {
+                u32 const hw = sq_tld32(hashTable + h);
+                if ((all || (hw & SQZ_HT_LIVE)) && (hw & SQZ_HT_IDX) >= from) {
+                    u32 cur = hw & SQZ_HT_IDX;
+                    while (cur >= from) cur = sq_tld32(bt + 2 * (cur & btMask));
+                    sq_gst32(hashTable + h, cur | (hw & ~SQZ_HT_IDX));
                 }
-                smallerPtr = nextPtr + 1;
-                matchIndex = child1;
-            } else {
-                gst32(largerPtr, matchIndex);
-                commonLengthLarger = matchLength;
-                if (matchIndex <= btLow) {
-                    largerPtr = ms.dummy;
-                    break;
-                }
-                largerPtr = nextPtr;
-                matchIndex = child0;
             }
         }
-        gst32(smallerPtr, 0);
-        gst32(largerPtr, 0);
-        wv_mem_sync();
-        if (matchEndIdx - 8 > curr + 1) filter_add_skip(ms, curr + 1, matchEndIdx - 8);
-        ms.nextToUpdate = matchEndIdx - 8;
-        return bestLength;
     }
+    wv_mem_sync();
+#else
+    for (u32 idx = from; idx < to; idx++) {
+        u32 const h = hash4(sq_rd32(ms.base + idx), hashLog);
+        if (!all && !bloom_test(h)) continue;
+        u32 const hw = hashTable[h];
+        if (!(all || (hw & SQZ_HT_LIVE))) continue;
+        u32 cur = hw & SQZ_HT_IDX;
+        while (cur >= from) cur = bt[2 * (cur & btMask)];
+        hashTable[h] = cur | (hw & ~SQZ_HT_IDX);
+    }
+#endif
+}
+
+// Returns how many scheduled searches, starting at pos0, certainly fail; *nextPos = where the
+// parser continues (the first unproven position, or the position after the last proven one).
+SQ_DEVFN u32 spec_epoch(MatchState& ms, u32 pos0, u32 anc, u32 off1, u32 ilimitPos, u32* nextPos) {
+    u32* const hashTable = ms.hashTable;
+    u32* const bt = ms.chainTable;
+    u32 const btMask = (1u << (ms.cp.chainLog - 1)) - 1;
+    u32 const hashLog = ms.cp.hashLog;
+    const u8* const base = ms.base;
+    bool const all = ms.eager != 0;
+    u32 const n2u0 = ms.nextToUpdate;
+#if SQ_ON_DEVICE
+    u32 const lane = wv_lane();
+    u32 myPos = 0, K = 0, lastPos = pos0, p = pos0;
+    for (u32 j = 0; j < 64 && p < ilimitPos; j++) {
+        if (lane == j) myPos = p;
+        K++;
+        lastPos = p;
+        p += ((p - anc) >> 8) + 1;
+    }
+    u32 const nextAfter = p;
+    if (K < 8) return 0;
+    PROF_T0(t_bulk);
+    if (lastPos + 1 > ms.nextToUpdate) {
+        dubt_insert_range<0>(ms, ms.nextToUpdate, lastPos + 1);
+        ms.nextToUpdate = lastPos + 1;
+    }
+    PROF_ADD(9, t_bulk);
+    PROF_T0(t_pred);
+    bool const have = lane < K;
+    bool hit = false;
+    if (have) {
+        u32 const w = sq_grd32(base + myPos);
+        if (off1 > 0 && sq_grd32(base + myPos + 1 - off1) == sq_grd32(base + myPos + 1)) hit = true;
+        if (!hit && myPos >= n2u0) { // below nextToUpdate: "skipped area", the search is not even run
+            u32 const h = hash4(w, hashLog);
+            u32 const hw = sq_tld32(hashTable + h);
+            if (!all && !(hw & SQZ_HT_LIVE)) hit = true;
+            u32 idx = hw & SQZ_HT_IDX, steps = 0;
+            while (!hit && idx > SQZ_WINDOW_START) {
+                u64 const pr = __hip_atomic_load((const SQ_G u64*)(bt + 2 * (idx & btMask)), __ATOMIC_RELAXED,
+                                                 __HIP_MEMORY_SCOPE_AGENT);
+                u32 const nx = (u32)pr, mk = (u32)(pr >> 32);
+                if (idx < myPos) {
+                    if (sq_grd32(base + idx) == w || (mk != SQZ_DUBT_UNSORTED && mk != SQZ_DUBT_SEARCHED)) hit = true;
+                }
+                if (nx >= idx || ++steps > 64) hit = true; // malformed / too long: let the exact code decide
+                idx = nx;
+            }
+        }
+    }
+    u64 const hm = wv_ballot(hit);
+    u32 const first = hm ? (u32)__builtin_ctzll(hm) : K;
+    if (have && lane < first && myPos >= n2u0) sq_gst32(bt + 2 * (myPos & btMask) + 1, SQZ_DUBT_SEARCHED);
+    wv_mem_sync();
+    PROF_ADD(10, t_pred);
+    if (first < K) {
+        u32 const firstPos = wv_readlane(myPos, first);
+        u32 const keep = firstPos > n2u0 ? firstPos : n2u0;
+        PROF_T0(t_rb);
+        if (lastPos + 1 > keep) dubt_rollback(ms, keep, lastPos + 1);
+        PROF_ADD(11, t_rb);
+        ms.nextToUpdate = keep;
+        *nextPos = firstPos;
+    } else {
+        *nextPos = nextAfter;
+    }
+    return first;
+#else
+    u32 pos[64];
+    u32 K = 0, p = pos0;
+    for (; K < 64 && p < ilimitPos; K++) {
+        pos[K] = p;
+        p += ((p - anc) >> 8) + 1;
+    }
+    u32 const nextAfter = p;
+    if (K < 8) return 0;
+    u32 const lastPos = pos[K - 1];
+    if (lastPos + 1 > ms.nextToUpdate) {
+        dubt_insert_range<0>(ms, ms.nextToUpdate, lastPos + 1);
+        ms.nextToUpdate = lastPos + 1;
+    }
+    u32 first = K;
+    for (u32 j = 0; j < K; j++) {
+        u32 const myPos = pos[j];
+        bool hit = false;
+        u32 const w = sq_rd32(base + myPos);
+        if (off1 > 0 && sq_rd32(base + myPos + 1 - off1) == sq_rd32(base + myPos + 1)) hit = true;
+        if (!hit && myPos >= n2u0) {
+            u32 const h = hash4(w, hashLog);
+            u32 const hw = hashTable[h];
+            if (!all && !(hw & SQZ_HT_LIVE)) hit = true;
+            u32 idx = hw & SQZ_HT_IDX, steps = 0;
+            while (!hit && idx > SQZ_WINDOW_START) {
+                u32 const nx = bt[2 * (idx & btMask)], mk = bt[2 * (idx & btMask) + 1];
+                if (idx < myPos) {
+                    if (sq_rd32(base + idx) == w || (mk != SQZ_DUBT_UNSORTED && mk != SQZ_DUBT_SEARCHED)) hit = true;
+                }
+                if (nx >= idx || ++steps > 64) hit = true;
+                idx = nx;
+            }
+        }
+        if (hit) {
+            first = j;
+            break;
+        }
+    }
+    for (u32 j = 0; j < first; j++)
+        if (pos[j] >= n2u0) bt[2 * (pos[j] & btMask) + 1] = SQZ_DUBT_SEARCHED;
+    if (first < K) {
+        u32 const firstPos = pos[first];
+        u32 const keep = firstPos > n2u0 ? firstPos : n2u0;
+        if (lastPos + 1 > keep) dubt_rollback(ms, keep, lastPos + 1);
+        ms.nextToUpdate = keep;
+        *nextPos = firstPos;
+    } else {
+        *nextPos = nextAfter;
+    }
+    return first;
+#endif
 }
 
 SQ_DEV u32 bt_find_best(MatchState& ms, const u8* ip, const u8* iLimit, u32* offBasePtr) {
@@ -791,6 +1162,7 @@ SQ_DEVFN u32 compressBlock_lazy(MatchState& ms, SeqStore& ss, u32* rep, const u8
     u32 offset_1 = rep[0], offset_2 = rep[1];
     u32 offsetSaved1 = 0, offsetSaved2 = 0;
 
+    u32 failStreak = 0, exactAt = 0; // speculative epochs start after 16 plain failures in a row
     ip += (ip == prefixLowest);
     {
         u32 const curr = (u32)(ip - base);
@@ -805,6 +1177,19 @@ SQ_DEVFN u32 compressBlock_lazy(MatchState& ms, SeqStore& ss, u32* rep, const u8
         u32 offBase = 1; // REPCODE1_TO_OFFBASE
         const u8* start = ip + 1;
         ms.anchorPos = (u32)(anchor - base);
+        if (!ROW && !ms.specOff && failStreak >= 16 && (u32)(ip - base) != exactAt) {
+            u32 nextPos = 0;
+            u32 const f = spec_epoch(ms, (u32)(ip - base), ms.anchorPos, offset_1, (u32)(ilimit - base), &nextPos);
+            if (ms.fault) break;
+            exactAt = nextPos; // if a "maybe" stopped the epoch, that position is done by the exact code
+            ms.nEpoch++;
+            ms.nSpecFail += f;
+            if (f) {
+                failStreak += f;
+                ip = base + nextPos;
+                continue;
+            }
+        }
 
         if ((offset_1 > 0) && (srd32(ip + 1 - offset_1) == srd32(ip + 1))) {
             matchLength = wv_count(ip + 1 + 4, ip + 1 + 4 - offset_1, (u32)(iend - (ip + 1 + 4))) + 4;
@@ -818,8 +1203,10 @@ SQ_DEVFN u32 compressBlock_lazy(MatchState& ms, SeqStore& ss, u32* rep, const u8
             u32 const step = ((u32)(ip - anchor) >> 8) + 1;
             ip += step;
             ms.lazySkipping = step > 8;
+            failStreak++;
             continue;
         }
+        failStreak = 0;
         while (ip < ilimit) {
             ip++;
             if ((offset_1 > 0) && (srd32(ip) == srd32(ip - offset_1))) {
