@@ -6,7 +6,8 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libsquish_gpu.so")
+# SQUISH_GPU_LIB selects another build of the same library (e.g. the -DSQ_PROF phase-timer build)
+LIB_PATH = os.environ.get("SQUISH_GPU_LIB") or os.path.join(_HERE, "libsquish_gpu.so")
 
 SQ_OK = 0
 SQ_E_INVAL, SQ_E_NOMEM, SQ_E_CAP, SQ_E_DEVICE, SQ_E_COMPRESS, SQ_E_NODEVICE = -1, -2, -3, -4, -5, -6

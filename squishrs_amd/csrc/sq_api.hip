@@ -420,19 +420,32 @@ static int compress_async(sq_ctx* c, const u8* d_data, const u64* h_off, const u
     HIPCHK(hipEventElapsedTime(&c->last.compress_ms, c->ev[4], c->ev[5]));
 #ifdef SQ_PROF
     {   // profiling build: sum the per-wave phase timers (100 MHz ticks) and print them
-        std::vector<unsigned long long> tot(13, 0), one(13);
+        std::vector<unsigned long long> tot(33, 0), one(33);
         for (u32 w = 0; w < waves; w++) {
-            (void)hipMemcpy(one.data(), (u8*)c->b_ws.p + (size_t)(w + 1) * ws_each - 512, 13 * 8, hipMemcpyDeviceToHost);
-            for (int k = 0; k < 13; k++) tot[k] += one[k];
+            (void)hipMemcpy(one.data(), (u8*)c->b_ws.p + (size_t)(w + 1) * ws_each - 1024, 33 * 8, hipMemcpyDeviceToHost);
+            for (int k = 0; k < 33; k++) tot[k] += one[k];
         }
-        static const char* nm[13] = {"frame_total", "table_clear", "dubt_update", "dubt_find", "row_update", "row_find",
-                                     "entropy", "copies", "presplit+filterinit", "epoch_insert", "epoch_predicate", "epoch_rollback", "chunks+1"};
+        static const char* nm[33] = {"frame_total", "table_clear", "dubt_update", "dubt_find", "row_update", "row_find",
+                                     "entropy", "copies", "presplit+filterinit", "epoch_insert", "epoch_predicate", "epoch_rollback",
+                                     "ins_phase1", "ins_phase23", "ins_tail", "bloom_rebuild",
+                                     "#tail_iters", "#bloom_overflow", "#superbatches", "#candidates", "#survivors", "#nLive_sum", "#repairs_x1000+eager_x1e6", "#exact_finds",
+                                     "cert_predict", "cert_build", "cert_scan_p1", "cert_scan_p2", "cert_blockwalk", "-", "-", "-", "chunks+1"};
         fprintf(stderr, "[squish_gpu prof] waves=%u kernel=%.2f ms; per-wave mean ms:", waves, c->last.compress_ms);
-        for (int k = 0; k < 13; k++)
-            if (nm[k][0] != '-') fprintf(stderr, " %s=%.3f", nm[k], k == 12 ? (double)tot[k] / waves : (double)tot[k] / waves / 1e5);
+        for (int k = 0; k < 33; k++)
+            if (nm[k][0] != '-') fprintf(stderr, " %s=%.3f", nm[k], (k >= 16 && k < 24) || k == 32 ? (double)tot[k] / waves : (double)tot[k] / waves / 1e5);
         fprintf(stderr, "\n");
     }
 #endif
+    if (getenv("SQ_DEBUG_STATS")) { // per-wave statistics words of the last chunk each wave compressed
+        const sqz::WsLayout L = sqz::ws_layout(max_len);
+        for (u32 w = 0; w < waves && w < 6; w++) {
+            u32 tr[64];
+            (void)hipMemcpy(tr, (u8*)c->b_ws.p + (size_t)w * ws_each + L.dummy, sizeof(tr), hipMemcpyDeviceToHost);
+            fprintf(stderr, "[squish_gpu stats] wave %u: n=%u eager=%u repairs=%u live=%u skips=%u epochs=%u specfail=%u replays=%u certified=%u dbg=%u,%u,%u,%u\n",
+                    w, tr[8 + 1], tr[8 + 30], tr[8 + 31], tr[8 + 32], tr[8 + 33], tr[8 + 34], tr[8 + 35], tr[8 + 36], tr[8 + 37],
+                    tr[8 + 40], tr[8 + 41], tr[8 + 42], tr[8 + 43]);
+        }
+    }
     if (*h_err && getenv("SQ_DEBUG")) {
         const sqz::WsLayout L = sqz::ws_layout(max_len);
         int shown = 0;

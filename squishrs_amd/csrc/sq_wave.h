@@ -23,7 +23,7 @@ SQ_DEV u64 wv_uni64(u64 v) {
     u32 lo = wv_uni((u32)v), hi = wv_uni((u32)(v >> 32));
     return ((u64)hi << 32) | lo;
 }
-SQ_DEV u64 wv_ballot(bool p) { return __ballot(p); }
+SQ_DEV u64 wv_ballot(bool p) { return __builtin_amdgcn_ballot_w64(p); }
 SQ_DEV u32 wv_readlane(u32 v, u32 l) { return (u32)__builtin_amdgcn_readlane((int)v, (int)l); }
 SQ_DEV u64 wv_readlane64(u64 v, u32 l) {
     return ((u64)wv_readlane((u32)(v >> 32), l) << 32) | wv_readlane((u32)v, l);

@@ -72,7 +72,7 @@ struct LdsState {
     u32 ret[8];   // results handed from a serial region to the whole wave
     u32* trace;   // 56 debug words in the wave's workspace (read by the host watchdog)
 #ifdef SQ_PROF
-    unsigned long long prof[12]; // per-phase 100 MHz tick sums (profiling build only)
+    unsigned long long prof[32]; // per-phase 100 MHz tick sums (profiling build only)
 #endif
 };
 SQ_LDS LdsState g_lds;
@@ -85,9 +85,14 @@ SQ_LDS LdsState g_lds;
         unsigned long long e_ = __builtin_amdgcn_s_memrealtime();                      \
         if (wv_lane() == 0) g_lds.prof[slot] += e_ - (v);                              \
     } while (0)
+#define PROF_CNT(slot, n)                                                              \
+    do {                                                                               \
+        if (wv_lane() == 0) g_lds.prof[slot] += (n);                                   \
+    } while (0)
 #else
 #define PROF_T0(v) do { } while (0)
 #define PROF_ADD(slot, v) do { } while (0)
+#define PROF_CNT(slot, n) do { } while (0)
 #endif
 
 // progress markers for bring-up: slot 0 = stage, others free-form

@@ -15,7 +15,6 @@
 
 namespace sqz {
 
-#define SQZ_BLOCKSIZE_MAX (128u << 10)
 #define SQZ_MAX_NBSEQ (SQZ_BLOCKSIZE_MAX / 3 + 2)
 
 struct Fingerprint {
@@ -26,7 +25,7 @@ struct Fingerprint {
 
 struct WsLayout {
     size_t hashTable, table2, hashTable3, seqs, lits, llCode, ofCode, mlCode, optState, fp, sched, liveList,
-        skipList, blockTab, dummy, total;
+        skipList, blockTab, certSched, dummy, total;
 };
 
 #if SQ_ON_DEVICE
@@ -100,6 +99,8 @@ SQ_HD WsLayout ws_layout(u32 max_len) {
     o += ws_align((size_t)SQZ_SKIP_CAP * 8);
     L.blockTab = o;
     o += ws_align((size_t)SQZ_BLOCKTAB_CAP * 8);
+    L.certSched = o;
+    o += ws_align((size_t)SQZ_SCHED_CAP * 4);
     L.dummy = o;
     o += 256;
     L.total = o;
@@ -216,6 +217,7 @@ SQ_DEVFN u32 compressBlock_internal(MatchState& ms, SeqStore& ss, BlockState& bs
                     ms.specOff = 1; // no room to remember this block's end: no deferred searches in it
             }
             if (!ms.eager && !bs.isFirstBlock) bloom_rebuild(ms); // the entropy stage reused the LDS
+            ms.sbMax = 256; // live buckets are dense right after a block start; grows back as they thin out
             if (curr > ms.nextToUpdate + 384) {
                 u32 const d = curr - ms.nextToUpdate - 384;
                 u32 const n2u = curr - (192 < d ? 192 : d);
@@ -294,8 +296,17 @@ SQ_DEVFN u32 compressBlock_internal(MatchState& ms, SeqStore& ss, BlockState& bs
     return cSize;
 }
 
+// State of a wave's hash-table area across the chunks of one launch.  gen == 0: the area holds
+// unknown words (start of a launch, or the previous chunk had another workspace layout / strategy).
+// Consecutive btlazy2 chunks of the same size class (same layout) tag their words with gen
+// instead of clearing the table (SQZ_HT_TAG in sq_zstd_match.h).
+struct TableGen {
+    u32 gen;
+    u32 windowLog; // size class of the chunk that last cleared / tagged the table
+};
+
 // Returns the frame length, 0 on error.
-SQ_DEVFN u32 compress_frame_wave(const u8* src, u32 n, u8* dst, u32 cap, u8* ws, const WsLayout& L) {
+SQ_DEVFN u32 compress_frame_wave(const u8* src, u32 n, u8* dst, u32 cap, u8* ws, const WsLayout& L, TableGen& tg) {
     MatchState ms;
     SeqStore ss;
     BlockState bs;
@@ -353,13 +364,28 @@ SQ_DEVFN u32 compress_frame_wave(const u8* src, u32 n, u8* dst, u32 cap, u8* ws,
     ms.liveList = (u32*)(ws + L.liveList);
     ms.skipList = (u32*)(ws + L.skipList);
     ms.blockTab = (u32*)(ws + L.blockTab);
+    ms.certSched = (u32*)(ws + L.certSched);
+    ms.nCert = ms.nCertDone = ms.certEnd = 0;
     ms.nLive = ms.nSkip = ms.nBlocks = 0;
     ms.specOff = 0;
+    ms.sbMax = 256;
     ms.nxEnt = 1;
     ms.nEpoch = ms.nSpecFail = ms.nReplay = 0;
     SQ_TRACE(0, 2);
     PROF_T0(t_clr);
-    wv_fill32(ms.hashTable, 0, (size_t)1 << cp.hashLog);
+    ms.genBits = 0;
+    if (cp.strategy == STRAT_BTLAZY2) {
+        if (tg.gen == 0 || tg.gen + 2 > SQZ_HT_GEN_MAX || tg.windowLog != cp.windowLog) { // a chunk uses up to 2
+            wv_fill32(ms.hashTable, 0, (size_t)1 << cp.hashLog);
+            tg.gen = 0;
+            tg.windowLog = cp.windowLog;
+        }
+        tg.gen++;
+        ms.genBits = tg.gen << SQZ_HT_GEN_SHIFT;
+    } else {
+        wv_fill32(ms.hashTable, 0, (size_t)1 << cp.hashLog);
+        tg.gen = 0;
+    }
     PROF_ADD(1, t_clr);
     SQ_TRACE(0, 3);
     if (cp.strategy == STRAT_LAZY2) {
@@ -391,8 +417,23 @@ SQ_DEVFN u32 compress_frame_wave(const u8* src, u32 n, u8* dst, u32 cap, u8* ws,
     wv_mem_sync();
     if (!ms.eager && n >= 9) { // btlazy2: predict the no-match search schedule, make its buckets live
         PROF_T0(t_fs);
+        // whole-chunk no-match certificate first (it borrows the table areas under its own
+        // generation; the next generation makes its words read as empty again)
+        PROF_T0(t_pr);
+        u32 const nS = filter_predict(ms, SQZ_WINDOW_START + 1, SQZ_WINDOW_START, ms.certSched);
+        PROF_ADD(24, t_pr);
+        if (nS > 0 && nS < SQZ_SCHED_CAP) {
+            ms.nCert = nS;
+            cert_compute(ms);
+            tg.gen++;
+            ms.genBits = tg.gen << SQZ_HT_GEN_SHIFT;
+        }
         wv_zero_lds(g_lds.u.bloom, SQZ_BLOOM_WORDS);
-        filter_repair(ms, SQZ_WINDOW_START + 1, SQZ_WINDOW_START, true);
+        if (ms.certEnd <= SQZ_WINDOW_START + 1) {
+            // nothing certified: predicted buckets live from the start (cheaper than the first repair)
+            ms.certEnd = 0;
+            filter_repair(ms, SQZ_WINDOW_START + 1, SQZ_WINDOW_START, true);
+        } // else: the filter comes to life at the first exact search (dubt_find -> filter_repair)
         PROF_ADD(8, t_fs);
     }
 
@@ -449,6 +490,8 @@ SQ_DEVFN u32 compress_frame_wave(const u8* src, u32 n, u8* dst, u32 cap, u8* ws,
     }
     wv_fence();
     SQ_TRACE(0, 10);
+    PROF_CNT(21, ms.nLive);
+    PROF_CNT(22, ms.nRepairs * 1000 + ms.eager * 1000000);
     SQ_TRACE(30, ms.eager);
     SQ_TRACE(31, ms.nRepairs);
     SQ_TRACE(32, ms.nLive);
@@ -456,17 +499,18 @@ SQ_DEVFN u32 compress_frame_wave(const u8* src, u32 n, u8* dst, u32 cap, u8* ws,
     SQ_TRACE(34, ms.nEpoch);
     SQ_TRACE(35, ms.nSpecFail);
     SQ_TRACE(36, ms.nReplay);
+    SQ_TRACE(37, ms.nCertDone);
     return (u32)(op - dst);
 }
 
 #if SQ_ON_DEVICE
 // One chunk -> one frame in its output slot (kept out of line: keeps the queue loop simple).
 __device__ __noinline__ void compress_one(const u8* data, const u64* off, const u32* len, u32 idx, u8* slots,
-                                          const u64* slot_off, u32* frame_len, u8* ws, u32* err) {
+                                          const u64* slot_off, u32* frame_len, u8* ws, u32* err, TableGen& tg) {
     u32 const L = len[idx];
     WsLayout const lay = ws_layout(L); // offsets for this length are <= the pool's
     u32 const cap = (u32)(slot_off[idx + 1] - slot_off[idx]);
-    u32 const r = compress_frame_wave(data + off[idx], L, slots + slot_off[idx], cap, ws, lay);
+    u32 const r = compress_frame_wave(data + off[idx], L, slots + slot_off[idx], cap, ws, lay, tg);
     if (wv_lane() == 0) {
         frame_len[idx] = r;
         if (r == 0) atomicOr(err, 1u);
@@ -481,9 +525,10 @@ k_compress_batch(const u8* data, const u64* off, const u32* len, const u8* selec
     u8* const ws = ws_pool + (u64)blockIdx.x * ws_each;
     u32* const dbg = (u32*)(ws + ws_each - 256) + 8; // wave-level progress words for the watchdog
     u32 iter = 0;
+    TableGen tg = {0, 0}; // this wave's hash-table area holds unknown words
 #ifdef SQ_PROF
     if (wv_lane() == 0)
-        for (int k = 0; k < 12; k++) g_lds.prof[k] = 0;
+        for (int k = 0; k < 32; k++) g_lds.prof[k] = 0;
     wv_fence();
 #endif
     for (;;) {
@@ -498,16 +543,16 @@ k_compress_batch(const u8* data, const u64* off, const u32* len, const u8* selec
         if (idx >= n) break;
         bool const take = (select == nullptr) || (select[idx] != 0);
         PROF_T0(t_all);
-        if (take) compress_one(data, off, len, idx, slots, slot_off, frame_len, ws, err);
+        if (take) compress_one(data, off, len, idx, slots, slot_off, frame_len, ws, err, tg);
         PROF_ADD(0, t_all);
     }
     if (wv_lane() == 0) dbg[11] = 777;
 #ifdef SQ_PROF
     wv_fence();
     if (wv_lane() == 0) {
-        unsigned long long* o = (unsigned long long*)(ws + ws_each - 512);
-        for (int k = 0; k < 12; k++) o[k] = g_lds.prof[k];
-        o[12] = iter;
+        unsigned long long* o = (unsigned long long*)(ws + ws_each - 1024);
+        for (int k = 0; k < 32; k++) o[k] = g_lds.prof[k];
+        o[32] = iter;
     }
 #endif
 }

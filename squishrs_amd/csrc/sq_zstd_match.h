@@ -17,6 +17,7 @@
 namespace sqz {
 
 #define SQZ_WINDOW_START 2u
+#define SQZ_BLOCKSIZE_MAX (128u << 10)
 #define SQZ_REP_NUM 3
 #define SQZ_MINMATCH 3
 #define OFFSET_TO_OFFBASE(o) ((o) + SQZ_REP_NUM)
@@ -94,6 +95,13 @@ struct MatchState {
     u32 specOff;     // 1 = speculative search epochs disabled
     u32 nxEnt;       // index of the entropy-table slot that is scratch during match finding
     u32 nEpoch, nSpecFail, nReplay; // statistics (trace words 34..36)
+    // ---- whole-chunk no-match certificate (see cert_build / cert_scan)
+    u32* certSched;  // the schedule the certificate was computed for (workspace)
+    u32 nCert;       // entries in certSched
+    u32 nCertDone;   // leading entries whose searches were skipped as certainly failing
+    u32 certEnd;     // every scheduled search at a position < certEnd certainly fails; 0 = no certificate
+    u32 sbMax;       // current super-batch length of the filtered insertion stream (256..2048)
+    u32 genBits;     // btlazy2 hash-table generation tag of this chunk, in place (bits 19..29)
     CParams cp;
 };
 
@@ -101,12 +109,28 @@ struct MatchState {
 #define SQZ_HT_LIVE 0x80000000u
 #define SQZ_HT_PEND 0x40000000u
 #define SQZ_HT_IDX 0x3FFFFFFFu
+// Generation tag: a btlazy2 chunk is at most 256 KiB, so an index needs 19 bits; bits 19..29 hold
+// the number of the chunk (within this wave's launch) that wrote the word.  A word with another
+// tag reads as 0 = "empty bucket", so the 2 MiB table is cleared once per launch and wave instead
+// of once per chunk (SQZ_HT_GEN_MAX chunks later it is cleared again).
+#define SQZ_HT_TAG 0x3FF80000u
+#define SQZ_HT_GEN_SHIFT 19
+#define SQZ_HT_GEN_MAX 2046u // 2047 is the tag of the all-ones SEARCHED mark, never used
 #define SQZ_SCHED_CAP 4096u
 #define SQZ_LIVE_CAP (96u << 10)
 #define SQZ_SKIP_CAP 256u
 #define SQZ_MAX_REPAIRS 24u
 #define SQZ_BLOCKTAB_CAP 64u
+#ifndef SQZ_EPOCH_AFTER_FAILS
+#define SQZ_EPOCH_AFTER_FAILS 16u // plain no-match searches in a row before speculative epochs start
+#endif
+#ifndef SQZ_EPOCH_MIN_K
+#define SQZ_EPOCH_MIN_K 8u // an epoch needs at least this many scheduled searches left in the block
+#endif
 #define SQZ_DUBT_SEARCHED 0xFFFFFFFFu // sort mark of a deferred (not yet replayed) search node
+
+SQ_DEV u32 ht_dec(const MatchState& ms, u32 w) { return ((w & SQZ_HT_TAG) == ms.genBits) ? (w & ~SQZ_HT_TAG) : 0u; }
+SQ_DEV u32 ht_enc(const MatchState& ms, u32 w) { return w | ms.genBits; }
 
 SQ_DEV u32 hash4(u32 v, u32 hBits) { return (v * 2654435761U) >> (32 - hBits); }
 SQ_DEV u32 hash5(u64 v, u32 hBits) { return (u32)(((v << 24) * 889523592379ULL) >> (64 - hBits)); }
@@ -191,6 +215,7 @@ SQ_DEV void bloom_add(u32 h) {
 }
 #endif
 SQ_DEVFN void bloom_rebuild(MatchState& ms) {
+    PROF_T0(t_br);
     wv_zero_lds(g_lds.u.bloom, SQZ_BLOOM_WORDS);
 #if SQ_ON_DEVICE
     for (u32 i = wv_lane(); i < ms.nLive; i += 64) bloom_add(sq_gld32(ms.liveList + i));
@@ -198,6 +223,7 @@ SQ_DEVFN void bloom_rebuild(MatchState& ms) {
 #else
     for (u32 i = 0; i < ms.nLive; i++) bloom_add(ms.liveList[i]);
 #endif
+    PROF_ADD(15, t_br);
 }
 
 // Insert positions [from, to) as unsorted candidates (ZSTD_updateDUBT) into the buckets selected
@@ -216,49 +242,80 @@ SQ_DEVFN void dubt_insert_range(MatchState& ms, u32 from, u32 to) {
     u64 const below = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
     u32 idx0 = from;
     if (MODE != 2 && !all) {
-        // Filtered stream: super-batches of 1024 positions.  Phase 1 hashes all of them and keeps
+        // Filtered stream: super-batches of up to 2048 positions.  Phase 1 hashes all of them and keeps
         // the Bloom-positive ones (a few %) in an LDS staging list, in position order; phase 2
         // gathers their table words in one go and keeps the positions whose bucket qualifies;
         // phase 3 inserts those (usually < 64) with the ordered per-step procedure.  Memory round
-        // trips per 1024 positions: ~4 instead of ~2 per 64.
+        // trips per 2048 positions: ~4 instead of ~2 per 64.
         // staging: candidates (idx, h) in the wv_group scratch, survivors (idx, h, head) in the
         // "next" entropy-table slot, which is dead until the entropy stage of this block
         SQ_L u32* const stage = (SQ_L u32*)g_lds.grp;
         SQ_L u32* const surv = (SQ_L u32*)&g_lds.ent[ms.nxEnt & 1];
         bool pendingStores = false;
-        for (; idx0 + 2048 <= to; idx0 += 2048) {
+        // ranges of <= 128 positions (the updates between two exact searches) go straight to the
+        // per-64 loop below; everything longer is cut into super-batches of up to 2048 positions
+        for (; idx0 < to && to - idx0 > 128;) {
+            // super-batch length: adapts downwards when the Bloom filter has become dense enough
+            // (after schedule repairs) to overflow the 256-entry candidate list
+            u32 const lim = (to - idx0 < ms.sbMax) ? to - idx0 : ms.sbMax;
+            u32 const lastPos = idx0 + lim - 1;
             u32 cnt = 0;
-            // phase 1: two rounds of 16 coalesced loads; all Bloom probes of a round are issued
-            // before any staging write so the LDS reads pipeline instead of serialising
+            PROF_T0(t_p1);
+            // phase 1: rounds of 16 coalesced loads (addresses clamped to the range, no branches),
+            // then per group of 4 loads: hashes, all 8 Bloom probes issued back to back, candidate
+            // compaction in position order
+            const SQ_L u32* const B = (const SQ_L u32*)g_lds.u.bloom;
 #pragma unroll 1
             for (u32 r = 0; r < 2; r++) {
+                if (1024 * r >= lim) break;
+                u32 const rl = lim - 1024 * r; // positions of this round (may exceed 1024)
                 u32 w[16];
 #pragma unroll
-                for (u32 u = 0; u < 16; u++) w[u] = sq_grd32(base + idx0 + 1024 * r + 64 * u + lane);
-                u32 cm = 0;
-#pragma unroll
                 for (u32 u = 0; u < 16; u++) {
-                    w[u] = hash4(w[u], hashLog);
-                    cm |= (bloom_test(w[u]) ? 1u : 0u) << u;
+                    u32 const pz = idx0 + 1024 * r + 64 * u + lane;
+                    w[u] = sq_grd32(base + (pz < lastPos ? pz : lastPos));
                 }
-                wv_fence();
 #pragma unroll
-                for (u32 u = 0; u < 16; u++) {
-                    bool const c = (cm >> u) & 1;
-                    u64 const m = wv_ballot(c);
-                    if (c) {
-                        u32 const slot = cnt + (u32)__popcll(m & below);
-                        if (slot < 256) {
-                            stage[2 * slot] = idx0 + 1024 * r + 64 * u + lane;
-                            stage[2 * slot + 1] = w[u];
-                        }
+                for (u32 q = 0; q < 4; q++) {
+                    if (256 * q >= rl) break;
+                    u32 p1[4], p2[4];
+#pragma unroll
+                    for (u32 v = 0; v < 4; v++) {
+                        u32 const h = hash4(w[4 * q + v], hashLog);
+                        w[4 * q + v] = h;
+                        p1[v] = B[(h & 0xFFFFu) >> 5];
+                        p2[v] = B[(h * 0x9E3779B1u) >> 21];
                     }
-                    cnt += (u32)__popcll(m);
+#pragma unroll
+                    for (u32 v = 0; v < 4; v++) {
+                        u32 const h = w[4 * q + v];
+                        u32 const u = 4 * q + v;
+                        bool const c = (64 * u + lane < rl) & (((p1[v] >> (h & 31)) & (p2[v] >> (((h * 0x9E3779B1u) >> 16) & 31)) & 1u) != 0);
+                        u64 const m = wv_ballot(c);
+                        u32 const slot = cnt + (u32)__popcll(m & below);
+                        if (c && slot < 256) {
+                            stage[2 * slot] = idx0 + 1024 * r + 64 * u + lane;
+                            stage[2 * slot + 1] = h;
+                        }
+                        cnt += (u32)__popcll(m);
+                    }
                 }
                 wv_fence();
             }
-            if (cnt > 256) break; // Bloom saturated: finish with the simple loop below
+            PROF_ADD(12, t_p1);
+            PROF_CNT(18, 1);
+            PROF_CNT(19, cnt);
+            if (cnt > 256) {
+                PROF_CNT(17, 1);
+                if (ms.sbMax > 256) { // retry this range with half the length
+                    ms.sbMax >>= 1;
+                    continue;
+                }
+                break; // saturated filter: finish with the per-64 loop below
+            }
+            if (cnt <= 96 && lim == ms.sbMax && ms.sbMax < 2048) ms.sbMax <<= 1; // sparse again: grow back
             wv_fence();
+            PROF_T0(t_p23);
             if (pendingStores) { // the previous super-batch's table stores must land before we gather
                 wv_mem_sync();
                 pendingStores = false;
@@ -272,7 +329,7 @@ SQ_DEVFN void dubt_insert_range(MatchState& ms, u32 from, u32 to) {
                 if (j < cnt) {
                     cidx[g] = stage[2 * j];
                     ch[g] = stage[2 * j + 1];
-                    chead[g] = sq_tld32(hashTable + ch[g]);
+                    chead[g] = ht_dec(ms, sq_tld32(hashTable + ch[g]));
                 }
             }
             u32 ntake = 0;
@@ -293,6 +350,7 @@ SQ_DEVFN void dubt_insert_range(MatchState& ms, u32 from, u32 to) {
                 ntake += (u32)__popcll(m);
             }
             wv_fence();
+            PROF_CNT(20, ntake);
             // phase 3: ordered insertion of the survivors, 64 per step (usually a single step that
             // reuses the heads gathered in phase 2)
             for (u32 j0 = 0; j0 < ntake; j0 += 64) {
@@ -306,23 +364,27 @@ SQ_DEVFN void dubt_insert_range(MatchState& ms, u32 from, u32 to) {
                 }
                 if (j0 > 0) { // an earlier step of this super-batch may have rewritten these heads
                     wv_mem_sync();
-                    if (act) head = sq_tld32(hashTable + h);
+                    if (act) head = ht_dec(ms, sq_tld32(hashTable + h));
                 }
                 WvGroup const g = wv_group(h, act, g_lds.grp);
                 u32 const prevPos = (u32)__shfl((int)idx, (int)(g.prevLane & 63), 64);
                 if (act) {
                     u32 const prev = (g.prevLane < 64) ? prevPos : (head & SQZ_HT_IDX);
                     sq_gst64v(bt + 2 * (idx & btMask), prev, SQZ_DUBT_UNSORTED);
-                    if (g.rank + 1 == g.gsize) sq_gst32(hashTable + h, idx | (head & ~SQZ_HT_IDX));
+                    if (g.rank + 1 == g.gsize) sq_gst32(hashTable + h, ht_enc(ms, idx | (head & ~SQZ_HT_IDX)));
                 }
                 pendingStores = true;
             }
+            PROF_ADD(13, t_p23);
+            idx0 += lim;
         }
         if (pendingStores) wv_mem_sync();
     }
+    PROF_T0(t_tail);
     // 64 positions per step.  A gather may hit a head written by the previous step and a load is
     // not ordered behind an older store of the same wave, so a step that stored drains first.
     for (; idx0 < to; idx0 += 64) {
+        PROF_CNT(16, 1);
         u32 const idx = idx0 + lane;
         bool const active = idx < to;
         u32 h = 0;
@@ -330,7 +392,7 @@ SQ_DEVFN void dubt_insert_range(MatchState& ms, u32 from, u32 to) {
         bool cand = active;
         if (MODE != 2 && !all) cand = active && bloom_test(h);
         u32 head = 0;
-        if (cand) head = sq_tld32(hashTable + h);
+        if (cand) head = ht_dec(ms, sq_tld32(hashTable + h));
         bool take;
         if (MODE == 0)
             take = cand && (all || (head & SQZ_HT_LIVE));
@@ -343,15 +405,16 @@ SQ_DEVFN void dubt_insert_range(MatchState& ms, u32 from, u32 to) {
         if (take) {
             u32 const prev = (g.prevLane < 64) ? idx0 + g.prevLane : (head & SQZ_HT_IDX);
             sq_gst64v(bt + 2 * (idx & btMask), prev, SQZ_DUBT_UNSORTED);
-            if (g.rank + 1 == g.gsize) sq_gst32(hashTable + h, idx | (head & ~SQZ_HT_IDX));
+            if (g.rank + 1 == g.gsize) sq_gst32(hashTable + h, ht_enc(ms, idx | (head & ~SQZ_HT_IDX)));
         }
         wv_mem_sync();
     }
+    PROF_ADD(14, t_tail);
 #else
     for (u32 idx = from; idx < to; idx++) {
         u32 const h = hash4(sq_rd32(base + idx), hashLog);
         if (MODE != 2 && !all && !bloom_test(h)) continue;
-        u32 const head = hashTable[h];
+        u32 const head = ht_dec(ms, hashTable[h]);
         bool take;
         if (MODE == 0)
             take = all || (head & SQZ_HT_LIVE);
@@ -360,7 +423,7 @@ SQ_DEVFN void dubt_insert_range(MatchState& ms, u32 from, u32 to) {
         else
             take = !(head & SQZ_HT_LIVE);
         if (!take) continue;
-        hashTable[h] = idx | (head & ~SQZ_HT_IDX);
+        hashTable[h] = ht_enc(ms, idx | (head & ~SQZ_HT_IDX));
         bt[2 * (idx & btMask)] = head & SQZ_HT_IDX;
         bt[2 * (idx & btMask) + 1] = SQZ_DUBT_UNSORTED;
     }
@@ -379,9 +442,42 @@ SQ_DEVFN void dubt_replay(MatchState& ms, u32 to) {
     if (pos < to) dubt_insert_range<MODE>(ms, pos, to);
 }
 
+// Searches skipped under the no-match certificate were never executed, so the buckets they would
+// have re-sorted hold them (after a replay) as plain unsorted nodes.  Give them the mark of a
+// deferred search, exactly what a speculative epoch leaves behind; dubt_materialize replays them if
+// the bucket is ever searched.  MODE 1: buckets being made live by the current repair (PENDING);
+// MODE 2: every bucket that was not live when the finder went eager.
+template <int MODE>
+SQ_DEVFN void cert_mark_deferred(MatchState& ms) {
+    if (ms.nCertDone == 0) return;
+    u32* const bt = ms.chainTable;
+    u32 const btMask = (1u << (ms.cp.chainLog - 1)) - 1;
+#if SQ_ON_DEVICE
+    for (u32 i = wv_lane(); i < ms.nCertDone; i += 64) {
+        u32 const s = sq_gld32(ms.certSched + i);
+        if (s >= ms.nextToUpdate) continue; // not inserted yet (cannot happen: the search inserts it)
+        u32 const h = hash4(sq_grd32(ms.base + s), ms.cp.hashLog);
+        u32 const v = ht_dec(ms, sq_tld32(ms.hashTable + h));
+        bool const mine = (MODE == 1) ? ((v & SQZ_HT_PEND) && !(v & SQZ_HT_LIVE)) : !(v & SQZ_HT_LIVE);
+        if (mine) sq_gst32(bt + 2 * (s & btMask) + 1, SQZ_DUBT_SEARCHED);
+    }
+    wv_mem_sync();
+#else
+    for (u32 i = 0; i < ms.nCertDone; i++) {
+        u32 const s = ms.certSched[i];
+        if (s >= ms.nextToUpdate) continue;
+        u32 const h = hash4(sq_rd32(ms.base + s), ms.cp.hashLog);
+        u32 const v = ht_dec(ms, ms.hashTable[h]);
+        bool const mine = (MODE == 1) ? ((v & SQZ_HT_PEND) && !(v & SQZ_HT_LIVE)) : !(v & SQZ_HT_LIVE);
+        if (mine) bt[2 * (s & btMask) + 1] = SQZ_DUBT_SEARCHED;
+    }
+#endif
+}
+
 SQ_DEVFN void filter_go_eager(MatchState& ms) {
     if (ms.eager) return;
     dubt_replay<2>(ms, ms.nextToUpdate);
+    cert_mark_deferred<2>(ms);
     ms.eager = 1;
 }
 
@@ -399,10 +495,9 @@ SQ_DEV void filter_add_skip(MatchState& ms, u32 from, u32 to) {
 }
 
 // The lazy parser's no-match search schedule from (pos, anchor) to the end of the chunk.
-SQ_DEVFN u32 filter_predict(MatchState& ms, u32 pos, u32 anc) {
+SQ_DEVFN u32 filter_predict(MatchState& ms, u32 pos, u32 anc, u32* const sched) {
     WV_SERIAL {
         u32 n = 0, p = pos, a = anc, bEnd = ms.blockEndPos;
-        u32* const sched = ms.sched;
         for (;;) {
             u32 const ilimit = bEnd - 8;
             while (p < ilimit && n < SQZ_SCHED_CAP) {
@@ -410,7 +505,7 @@ SQ_DEVFN u32 filter_predict(MatchState& ms, u32 pos, u32 anc) {
                 p += ((p - a) >> 8) + 1;
             }
             if (bEnd >= ms.chunkEndPos || n >= SQZ_SCHED_CAP) break;
-            u32 nb = bEnd + (128u << 10);
+            u32 nb = bEnd + SQZ_BLOCKSIZE_MAX;
             if (nb > ms.chunkEndPos) nb = ms.chunkEndPos;
             if (nb - bEnd < 9) break; // too small to search
             p = a = bEnd;
@@ -454,7 +549,7 @@ SQ_DEVFN void filter_mark(MatchState& ms, u32 n, bool first) {
                 u64 const m = wv_ballot(ok[g]);
                 if (ok[g]) {
                     u32 const r = (u32)__popcll(m & belowm);
-                    sq_gst32(ms.hashTable + h, SQZ_HT_LIVE);
+                    sq_gst32(ms.hashTable + h, ht_enc(ms, SQZ_HT_LIVE));
                     sq_gst32(ms.liveList + ms.nLive + r, h);
                     bloom_add(h);
                 }
@@ -472,9 +567,9 @@ SQ_DEVFN void filter_mark(MatchState& ms, u32 n, bool first) {
             u32 const p = sq_gld32(ms.sched + i / 3) + (i % 3);
             if (p + 8 <= ms.chunkEndPos) {
                 h = hash4(sq_grd32(ms.base + p), hashLog);
-                u32 const v = sq_tld32(ms.hashTable + h);
+                u32 const v = ht_dec(ms, sq_tld32(ms.hashTable + h));
                 if (!(v & (SQZ_HT_LIVE | SQZ_HT_PEND))) {
-                    sq_gst32(ms.hashTable + h, v | SQZ_HT_PEND);
+                    sq_gst32(ms.hashTable + h, ht_enc(ms, v | SQZ_HT_PEND));
                     fresh = true;
                 }
             }
@@ -495,15 +590,15 @@ SQ_DEVFN void filter_mark(MatchState& ms, u32 n, bool first) {
         u32 const p = ms.sched[i / 3] + (i % 3);
         if (p + 8 > ms.chunkEndPos) continue;
         u32 const h = hash4(sq_rd32(ms.base + p), hashLog);
-        u32 const v = ms.hashTable[h];
+        u32 const v = ht_dec(ms, ms.hashTable[h]);
         if (first) {
-            ms.hashTable[h] = SQZ_HT_LIVE;
+            ms.hashTable[h] = ht_enc(ms, SQZ_HT_LIVE);
             ms.liveList[ms.nLive++] = h;
             bloom_add(h);
             continue;
         }
         if (!(v & (SQZ_HT_LIVE | SQZ_HT_PEND))) {
-            ms.hashTable[h] = v | SQZ_HT_PEND;
+            ms.hashTable[h] = ht_enc(ms, v | SQZ_HT_PEND);
             ms.liveList[ms.nLive++] = h;
             bloom_add(h);
         }
@@ -515,14 +610,14 @@ SQ_DEVFN void filter_finalize(MatchState& ms, u32 start) {
 #if SQ_ON_DEVICE
     for (u32 i = start + wv_lane(); i < ms.nLive; i += 64) {
         u32 const h = sq_gld32(ms.liveList + i);
-        u32 const v = sq_tld32(ms.hashTable + h);
-        sq_gst32(ms.hashTable + h, (v & ~SQZ_HT_PEND) | SQZ_HT_LIVE);
+        u32 const v = ht_dec(ms, sq_tld32(ms.hashTable + h));
+        sq_gst32(ms.hashTable + h, ht_enc(ms, (v & ~SQZ_HT_PEND) | SQZ_HT_LIVE));
     }
     wv_mem_sync();
 #else
     for (u32 i = start; i < ms.nLive; i++) {
         u32 const h = ms.liveList[i];
-        ms.hashTable[h] = (ms.hashTable[h] & ~SQZ_HT_PEND) | SQZ_HT_LIVE;
+        ms.hashTable[h] = ht_enc(ms, (ht_dec(ms, ms.hashTable[h]) & ~SQZ_HT_PEND) | SQZ_HT_LIVE);
     }
 #endif
 }
@@ -536,7 +631,7 @@ SQ_DEVFN void filter_repair(MatchState& ms, u32 pos, u32 anc, bool first) {
         }
         ms.nRepairs++;
     }
-    u32 const n = filter_predict(ms, pos, anc);
+    u32 const n = filter_predict(ms, pos, anc, ms.sched);
     if (ms.nLive + 3 * n > SQZ_LIVE_CAP) {
         filter_go_eager(ms);
         return;
@@ -545,8 +640,251 @@ SQ_DEVFN void filter_repair(MatchState& ms, u32 pos, u32 anc, bool first) {
     filter_mark(ms, n, first);
     if (!first && ms.nLive > start) {
         if (ms.nextToUpdate > SQZ_WINDOW_START) dubt_replay<1>(ms, ms.nextToUpdate);
+        cert_mark_deferred<1>(ms);
         filter_finalize(ms, start);
     }
+}
+
+// ---------------------------------------------------------------- no-match certificate
+// On incompressible data every scheduled search fails and the parser emits no sequence at all: the
+// whole tree machinery produces nothing observable.  A search of the lazy parser at position s can
+// only return a match (length >= 4) if some EARLIER position p holds the same 4 bytes as s, or if
+// the repcode test at s+1 fires.  Both are properties of the bytes, not of the tree.  So before
+// any table is built, one streaming pass decides, for the predicted no-match schedule S of the
+// whole chunk, the first scheduled position s* for which such a p (or a repcode hit) exists:
+//   build : table[hash(s)] = s for s in S (generation-tagged words in the hash-table area, the 4
+//           bytes of s in the chain-table area), Bloom filter over hash(s) in LDS; the few s that
+//           share a bucket with another s go to a small overflow list;
+//   scan  : every position p < certEnd is hashed and Bloom-tested (64 per instruction); the ~3 %
+//           positives gather their table entry and compare bytes; a hit at (p, s), p < s, lowers
+//           certEnd to s.
+// Searches at positions < certEnd certainly fail: the parser skips them (they are remembered as
+// deferred searches, like those of a speculative epoch) and resumes the exact code at certEnd.
+// Blocks that are certified entirely cost no search, no insertion and no table traffic at all.
+// The certificate is conservative (p is not required to be reachable within nbCompares), so a
+// "maybe" only means the exact code decides; results are identical to libzstd's either way.
+#define SQZ_CERT_DUP SQZ_HT_PEND // table-word flag: another scheduled position shares this bucket
+#define SQZ_CERT_OVF_CAP 64u
+
+SQ_DEVFN void cert_compute(MatchState& ms) {
+    u32* const T = ms.hashTable;
+    u32* const V = ms.chainTable;
+    const u8* const base = ms.base;
+    u32 const hashLog = ms.cp.hashLog;
+    u32 const nCert = ms.nCert;
+    u32 certEnd = ms.chunkEndPos;
+    u32 nOvf = 0;
+    wv_zero_lds(g_lds.u.bloom, SQZ_BLOOM_WORDS);
+#if SQ_ON_DEVICE
+    u32 const lane = wv_lane();
+    u64 const below = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+    SQ_L u32* const ovf = (SQ_L u32*)&g_lds.ent[ms.nxEnt & 1];
+    SQ_L u32* const stage = (SQ_L u32*)g_lds.grp;
+    u32 vmin = 0xFFFFFFFFu; // lane-local minimum of the violating scheduled positions
+    PROF_T0(t_bld);
+    // ---- build, pass A: every s claims its bucket (one of several claimants wins), repcode test
+    for (u32 i0 = 0; i0 < nCert; i0 += 64) {
+        u32 const i = i0 + lane;
+        if (i < nCert) {
+            u32 const sp = sq_gld32(ms.certSched + i);
+            u32 const v = sq_grd32(base + sp);
+            u32 const h = hash4(v, hashLog);
+            sq_gst32(T + h, ht_enc(ms, sp));
+            bloom_add(h);
+            if (sq_grd32(base + sp + 1) == v && sp < vmin) vmin = sp; // offset_1 == 1 repcode at s+1
+        }
+    }
+    wv_mem_sync();
+    // ---- build, pass B: the winner of a bucket deposits its 4 bytes, the others go to the overflow list
+    for (u32 i0 = 0; i0 < nCert; i0 += 64) {
+        u32 const i = i0 + lane;
+        bool loser = false;
+        u32 sp = 0, v = 0;
+        if (i < nCert) {
+            sp = sq_gld32(ms.certSched + i);
+            v = sq_grd32(base + sp);
+            u32 const h = hash4(v, hashLog);
+            u32 const t = ht_dec(ms, sq_tld32(T + h));
+            if ((t & SQZ_HT_IDX) == sp)
+                sq_gst32(V + h, v);
+            else {
+                loser = true;
+                sq_gst32(T + h, ht_enc(ms, t | SQZ_CERT_DUP));
+            }
+        }
+        u64 const m = wv_ballot(loser);
+        if (m) {
+            if (loser) {
+                u32 const slot = nOvf + (u32)__popcll(m & below);
+                if (slot < SQZ_CERT_OVF_CAP) {
+                    ovf[2 * slot] = sp;
+                    ovf[2 * slot + 1] = v;
+                } else if (sp < vmin)
+                    vmin = sp; // no room to remember it: the certificate ends there
+            }
+            nOvf += (u32)__popcll(m);
+        }
+    }
+    if (nOvf > SQZ_CERT_OVF_CAP) nOvf = SQZ_CERT_OVF_CAP;
+    wv_mem_sync();
+    {
+        u32 x = vmin;
+        for (int sft = 32; sft >= 1; sft >>= 1) {
+            u32 const y = (u32)__shfl_xor((int)x, sft, 64);
+            x = y < x ? y : x;
+        }
+        x = wv_uni(x);
+        if (x < certEnd) certEnd = x;
+        SQ_TRACE(43, x);
+    }
+    PROF_ADD(25, t_bld);
+    // ---- scan: positions [2, min(certEnd, last position with 4 readable bytes])
+    u32 const pEnd = ms.chunkEndPos - 3; // one past the last p with p + 4 <= chunkEnd
+    const SQ_L u32* const B = (const SQ_L u32*)g_lds.u.bloom;
+    // super-batch length: the schedule is dense at a block start (every position of its first 256
+    // bytes, every second of the next 512, ...) and scheduled positions are candidates themselves,
+    // so the length adapts to keep the candidate list within its 256 entries
+    u32 sb = 256;
+    for (u32 idx0 = SQZ_WINDOW_START; idx0 < certEnd && idx0 < pEnd;) {
+        u32 const stop = certEnd < pEnd ? certEnd : pEnd;
+        u32 const lim = (stop - idx0 < sb) ? stop - idx0 : sb;
+        u32 const lastPos = idx0 + lim - 1;
+        u32 cnt = 0;
+        PROF_T0(t_s1);
+#pragma unroll 1
+        for (u32 r = 0; r < 2; r++) {
+            if (1024 * r >= lim) break;
+            u32 const rl = lim - 1024 * r;
+            u32 w[16];
+#pragma unroll
+            for (u32 u = 0; u < 16; u++) {
+                u32 const pz = idx0 + 1024 * r + 64 * u + lane;
+                w[u] = sq_grd32(base + (pz < lastPos ? pz : lastPos));
+            }
+#pragma unroll
+            for (u32 q = 0; q < 4; q++) {
+                if (256 * q >= rl) break;
+                u32 p1[4], p2[4];
+#pragma unroll
+                for (u32 k = 0; k < 4; k++) {
+                    u32 const h = hash4(w[4 * q + k], hashLog);
+                    w[4 * q + k] = h;
+                    p1[k] = B[(h & 0xFFFFu) >> 5];
+                    p2[k] = B[(h * 0x9E3779B1u) >> 21];
+                }
+#pragma unroll
+                for (u32 k = 0; k < 4; k++) {
+                    u32 const h = w[4 * q + k];
+                    u32 const u = 4 * q + k;
+                    bool const c = (64 * u + lane < rl) & (((p1[k] >> (h & 31)) & (p2[k] >> (((h * 0x9E3779B1u) >> 16) & 31)) & 1u) != 0);
+                    u64 const m = wv_ballot(c);
+                    u32 const slot = cnt + (u32)__popcll(m & below);
+                    if (c && slot < 256) {
+                        stage[2 * slot] = idx0 + 1024 * r + 64 * u + lane;
+                        stage[2 * slot + 1] = h;
+                    }
+                    cnt += (u32)__popcll(m);
+                }
+            }
+            wv_fence();
+        }
+        PROF_ADD(26, t_s1);
+        if (cnt > 256) {
+            if (sb > 128) {
+                sb >>= 1;
+                continue;
+            }
+            // degenerate data (one value everywhere): positions >= idx0 stay unverified, which
+            // only matters to searches beyond idx0
+            if (idx0 + 1 < certEnd) certEnd = idx0 + 1;
+            break;
+        }
+        if (cnt <= 96 && sb < 2048) sb <<= 1;
+        wv_fence();
+        // candidates: table word + the winner's bytes + own bytes, one round trip
+        PROF_T0(t_s2);
+        u32 viol = 0xFFFFFFFFu;
+#pragma unroll
+        for (u32 g = 0; g < 4; g++) {
+            u32 const j = 64 * g + lane;
+            if (64 * g < cnt) {
+                u32 p = 0, t = 0, tv = 0, vp = 1;
+                if (j < cnt) {
+                    p = stage[2 * j];
+                    u32 const h = stage[2 * j + 1];
+                    t = ht_dec(ms, sq_tld32(T + h));
+                    tv = sq_tld32(V + h);
+                    vp = sq_grd32(base + p);
+                }
+                if (t) {
+                    u32 const sw = t & SQZ_HT_IDX & ~SQZ_CERT_DUP;
+                    if (p < sw && vp == tv && sw < viol) viol = sw;
+                    if (t & SQZ_CERT_DUP)
+                        for (u32 e = 0; e < nOvf; e++) {
+                            u32 const so = ovf[2 * e], vo = ovf[2 * e + 1];
+                            if (vp == vo && p < so && so < viol) viol = so;
+                        }
+                }
+            }
+        }
+        if (wv_ballot(viol != 0xFFFFFFFFu)) {
+            u32 x = viol;
+            for (int sft = 32; sft >= 1; sft >>= 1) {
+                u32 const y = (u32)__shfl_xor((int)x, sft, 64);
+                x = y < x ? y : x;
+            }
+            x = wv_uni(x);
+            if (x < certEnd) certEnd = x;
+        }
+        PROF_ADD(27, t_s2);
+        idx0 += lim;
+    }
+    wv_fence();
+#else
+    // scalar twin: same tables, same rule
+    u32 ovfS[SQZ_CERT_OVF_CAP], ovfV[SQZ_CERT_OVF_CAP];
+    for (u32 i = 0; i < nCert; i++) {
+        u32 const sp = ms.certSched[i];
+        u32 const v = sq_rd32(base + sp);
+        u32 const h = hash4(v, hashLog);
+        T[h] = ht_enc(ms, sp); // the last claimant wins
+        bloom_add(h);
+        if (sq_rd32(base + sp + 1) == v && sp < certEnd) certEnd = sp;
+    }
+    for (u32 i = 0; i < nCert; i++) {
+        u32 const sp = ms.certSched[i];
+        u32 const v = sq_rd32(base + sp);
+        u32 const h = hash4(v, hashLog);
+        u32 const t = ht_dec(ms, T[h]);
+        if ((t & SQZ_HT_IDX) == sp)
+            V[h] = v;
+        else {
+            T[h] = ht_enc(ms, t | SQZ_CERT_DUP);
+            if (nOvf < SQZ_CERT_OVF_CAP) {
+                ovfS[nOvf] = sp;
+                ovfV[nOvf] = v;
+                nOvf++;
+            } else if (sp < certEnd)
+                certEnd = sp;
+        }
+    }
+    u32 const pEnd = ms.chunkEndPos - 3;
+    for (u32 p = SQZ_WINDOW_START; p < certEnd && p < pEnd; p++) {
+        u32 const vp = sq_rd32(base + p);
+        u32 const h = hash4(vp, hashLog);
+        if (!bloom_test(h)) continue;
+        u32 const t = ht_dec(ms, T[h]);
+        if (!t) continue;
+        u32 const sw = t & SQZ_HT_IDX & ~SQZ_CERT_DUP;
+        if (p < sw && vp == V[h] && sw < certEnd) certEnd = sw;
+        if (t & SQZ_CERT_DUP)
+            for (u32 e = 0; e < nOvf; e++)
+                if (vp == ovfV[e] && p < ovfS[e] && ovfS[e] < certEnd) certEnd = ovfS[e];
+    }
+#endif
+    ms.certEnd = certEnd;
+    SQ_TRACE(40, certEnd);
+    SQ_TRACE(41, nOvf);
 }
 
 // ZSTD_updateDUBT
@@ -761,16 +1099,16 @@ SQ_DEVFN u32 dubt_find(MatchState& ms, const u8* const ip, const u8* const iend,
     u32* const hashTable = ms.hashTable;
     u32 const h = hash4(srd32(ip), ms.cp.hashLog);
     u32 const curr = (u32)(ip - ms.base);
-    u32 headWord = gld32(hashTable + h);
+    u32 headWord = ht_dec(ms, gld32(hashTable + h));
     if (!ms.eager && !(headWord & SQZ_HT_LIVE)) { // the schedule changed: make this bucket exact
         filter_repair(ms, curr, ms.anchorPos, false);
-        headWord = gld32(hashTable + h);
+        headWord = ht_dec(ms, gld32(hashTable + h));
     }
     u32 const headIndex = headWord & SQZ_HT_IDX;
     dubt_materialize(ms, headIndex);
     u32 matchEndIdx = curr + 9;
     u32 const bestLength = dubt_search_core(ms, curr, iend, headIndex, offBasePtr, &matchEndIdx);
-    gst32(hashTable + h, curr | (headWord & ~SQZ_HT_IDX));
+    gst32(hashTable + h, ht_enc(ms, curr | (headWord & ~SQZ_HT_IDX)));
     wv_mem_sync();
     if (matchEndIdx - 8 > curr + 1) filter_add_skip(ms, curr + 1, matchEndIdx - 8);
     ms.nextToUpdate = matchEndIdx - 8;
@@ -801,11 +1139,11 @@ SQ_DEVFN void dubt_rollback(MatchState& ms, u32 from, u32 to) {
         if (idx < to) {
             u32 const h = hash4(sq_grd32(ms.base + idx), hashLog);
             if (all || bloom_test(h)) {
-                u32 const hw = sq_tld32(hashTable + h);
+                u32 const hw = ht_dec(ms, sq_tld32(hashTable + h));
                 if ((all || (hw & SQZ_HT_LIVE)) && (hw & SQZ_HT_IDX) >= from) {
                     u32 cur = hw & SQZ_HT_IDX;
                     while (cur >= from) cur = sq_tld32(bt + 2 * (cur & btMask));
-                    sq_gst32(hashTable + h, cur | (hw & ~SQZ_HT_IDX));
+                    sq_gst32(hashTable + h, ht_enc(ms, cur | (hw & ~SQZ_HT_IDX)));
                 }
             }
         }
@@ -815,18 +1153,19 @@ SQ_DEVFN void dubt_rollback(MatchState& ms, u32 from, u32 to) {
     for (u32 idx = from; idx < to; idx++) {
         u32 const h = hash4(sq_rd32(ms.base + idx), hashLog);
         if (!all && !bloom_test(h)) continue;
-        u32 const hw = hashTable[h];
+        u32 const hw = ht_dec(ms, hashTable[h]);
         if (!(all || (hw & SQZ_HT_LIVE))) continue;
         u32 cur = hw & SQZ_HT_IDX;
         while (cur >= from) cur = bt[2 * (cur & btMask)];
-        hashTable[h] = cur | (hw & ~SQZ_HT_IDX);
+        hashTable[h] = ht_enc(ms, cur | (hw & ~SQZ_HT_IDX));
     }
 #endif
 }
 
 // Returns how many scheduled searches, starting at pos0, certainly fail; *nextPos = where the
-// parser continues (the first unproven position, or the position after the last proven one).
-SQ_DEVFN u32 spec_epoch(MatchState& ms, u32 pos0, u32 anc, u32 off1, u32 ilimitPos, u32* nextPos) {
+// parser continues (the first unproven position, or the position after the last proven one);
+// *stopped = 1 when a "maybe" ended the epoch, i.e. *nextPos must be searched by the exact code.
+SQ_DEVFN u32 spec_epoch(MatchState& ms, u32 pos0, u32 anc, u32 off1, u32 ilimitPos, u32* nextPos, u32* stopped) {
     u32* const hashTable = ms.hashTable;
     u32* const bt = ms.chainTable;
     u32 const btMask = (1u << (ms.cp.chainLog - 1)) - 1;
@@ -844,7 +1183,7 @@ SQ_DEVFN u32 spec_epoch(MatchState& ms, u32 pos0, u32 anc, u32 off1, u32 ilimitP
         p += ((p - anc) >> 8) + 1;
     }
     u32 const nextAfter = p;
-    if (K < 8) return 0;
+    if (K < SQZ_EPOCH_MIN_K) return 0;
     PROF_T0(t_bulk);
     if (lastPos + 1 > ms.nextToUpdate) {
         dubt_insert_range<0>(ms, ms.nextToUpdate, lastPos + 1);
@@ -859,7 +1198,7 @@ SQ_DEVFN u32 spec_epoch(MatchState& ms, u32 pos0, u32 anc, u32 off1, u32 ilimitP
         if (off1 > 0 && sq_grd32(base + myPos + 1 - off1) == sq_grd32(base + myPos + 1)) hit = true;
         if (!hit && myPos >= n2u0) { // below nextToUpdate: "skipped area", the search is not even run
             u32 const h = hash4(w, hashLog);
-            u32 const hw = sq_tld32(hashTable + h);
+            u32 const hw = ht_dec(ms, sq_tld32(hashTable + h));
             if (!all && !(hw & SQZ_HT_LIVE)) hit = true;
             u32 idx = hw & SQZ_HT_IDX, steps = 0;
             while (!hit && idx > SQZ_WINDOW_START) {
@@ -887,8 +1226,10 @@ SQ_DEVFN u32 spec_epoch(MatchState& ms, u32 pos0, u32 anc, u32 off1, u32 ilimitP
         PROF_ADD(11, t_rb);
         ms.nextToUpdate = keep;
         *nextPos = firstPos;
+        *stopped = 1;
     } else {
         *nextPos = nextAfter;
+        *stopped = 0;
     }
     return first;
 #else
@@ -899,7 +1240,7 @@ SQ_DEVFN u32 spec_epoch(MatchState& ms, u32 pos0, u32 anc, u32 off1, u32 ilimitP
         p += ((p - anc) >> 8) + 1;
     }
     u32 const nextAfter = p;
-    if (K < 8) return 0;
+    if (K < SQZ_EPOCH_MIN_K) return 0;
     u32 const lastPos = pos[K - 1];
     if (lastPos + 1 > ms.nextToUpdate) {
         dubt_insert_range<0>(ms, ms.nextToUpdate, lastPos + 1);
@@ -913,7 +1254,7 @@ SQ_DEVFN u32 spec_epoch(MatchState& ms, u32 pos0, u32 anc, u32 off1, u32 ilimitP
         if (off1 > 0 && sq_rd32(base + myPos + 1 - off1) == sq_rd32(base + myPos + 1)) hit = true;
         if (!hit && myPos >= n2u0) {
             u32 const h = hash4(w, hashLog);
-            u32 const hw = hashTable[h];
+            u32 const hw = ht_dec(ms, hashTable[h]);
             if (!all && !(hw & SQZ_HT_LIVE)) hit = true;
             u32 idx = hw & SQZ_HT_IDX, steps = 0;
             while (!hit && idx > SQZ_WINDOW_START) {
@@ -938,8 +1279,10 @@ SQ_DEVFN u32 spec_epoch(MatchState& ms, u32 pos0, u32 anc, u32 off1, u32 ilimitP
         if (lastPos + 1 > keep) dubt_rollback(ms, keep, lastPos + 1);
         ms.nextToUpdate = keep;
         *nextPos = firstPos;
+        *stopped = 1;
     } else {
         *nextPos = nextAfter;
+        *stopped = 0;
     }
     return first;
 #endif
@@ -951,6 +1294,7 @@ SQ_DEV u32 bt_find_best(MatchState& ms, const u8* ip, const u8* iLimit, u32* off
     dubt_update(ms, (u32)(ip - ms.base));
     PROF_ADD(2, t_u);
     PROF_T0(t_f);
+    PROF_CNT(23, 1);
     u32 const r = dubt_find(ms, ip, iLimit, offBasePtr);
     PROF_ADD(3, t_f);
     return r;
@@ -1172,16 +1516,47 @@ SQ_DEVFN u32 compressBlock_lazy(MatchState& ms, SeqStore& ss, u32* rep, const u8
     }
     ms.lazySkipping = 0;
 
+    if (!ROW && ms.certEnd) {
+        // No-match certificate (cert_compute): the scheduled searches of this block at positions
+        // below certEnd certainly fail.  Skip them: what remains of them is the parser state (ip,
+        // nextToUpdate) and their deferred tree updates (cert_mark_deferred).
+        u32 const blk = (u32)(istart - base), ipPos = (u32)(ip - base), ilimPos = (u32)(ilimit - base);
+        u32 const predEnd = (ms.chunkEndPos - blk < SQZ_BLOCKSIZE_MAX) ? ms.chunkEndPos : blk + SQZ_BLOCKSIZE_MAX;
+        bool const asPredicted = ((blk - SQZ_WINDOW_START) % SQZ_BLOCKSIZE_MAX == 0) && (blk + srcSize == predEnd) &&
+                                 (offset_1 == 1) && (ss.nseq == 0);
+        if (!asPredicted || ms.certEnd <= ipPos || ilimit <= ip) {
+            if (!asPredicted || ms.certEnd <= ipPos) ms.certEnd = 0; // the certificate ends here
+        } else {
+            PROF_T0(t_bw);
+            u32 pz = ipPos, last = 0, cnt = 0;
+            while (pz < ilimPos && pz < ms.certEnd) {
+                last = pz;
+                cnt++;
+                pz += ((pz - blk) >> 8) + 1;
+            }
+            PROF_ADD(28, t_bw);
+            ms.nCertDone += cnt;
+            if (last + 1 > ms.nextToUpdate) ms.nextToUpdate = last + 1;
+            ip = base + pz;
+            failStreak = SQZ_EPOCH_AFTER_FAILS;
+            if (pz < ilimPos) { // the exact code takes over at the first position that is not certified
+                exactAt = pz;
+                ms.certEnd = 0;
+            }
+        }
+    }
+
     while (ip < ilimit) {
         u32 matchLength = 0;
         u32 offBase = 1; // REPCODE1_TO_OFFBASE
         const u8* start = ip + 1;
         ms.anchorPos = (u32)(anchor - base);
-        if (!ROW && !ms.specOff && failStreak >= 16 && (u32)(ip - base) != exactAt) {
-            u32 nextPos = 0;
-            u32 const f = spec_epoch(ms, (u32)(ip - base), ms.anchorPos, offset_1, (u32)(ilimit - base), &nextPos);
+        if (!ROW && !ms.specOff && failStreak >= SQZ_EPOCH_AFTER_FAILS && (u32)(ip - base) != exactAt) {
+            u32 nextPos = 0, stopped = 1;
+            u32 const f = spec_epoch(ms, (u32)(ip - base), ms.anchorPos, offset_1, (u32)(ilimit - base), &nextPos, &stopped);
             if (ms.fault) break;
-            exactAt = nextPos; // if a "maybe" stopped the epoch, that position is done by the exact code
+            // a "maybe" stopped the epoch (or it was too short to run): the exact code does that position
+            exactAt = stopped ? (f ? nextPos : (u32)(ip - base)) : 0;
             ms.nEpoch++;
             ms.nSpecFail += f;
             if (f) {

@@ -14,14 +14,35 @@ extern "C" size_t sim_compress_chunk(const uint8_t* src, size_t n, uint8_t* dst,
     memset(ws, poison ? 0xA5 : 0, L.total + 256);
     memset(&sqz::g_lds, poison ? 0x5A : 0, sizeof(sqz::g_lds));
     u8* wsa = (u8*)(((uintptr_t)ws + 255) & ~(uintptr_t)255);
-    u32 r = sqz::compress_frame_wave(src, (u32)n, dst, (u32)cap, wsa, L);
+    sqz::TableGen tg = {0, 0};
+    u32 r = sqz::compress_frame_wave(src, (u32)n, dst, (u32)cap, wsa, L, tg);
     if (getenv("SQ_SIM_STATS")) {
         const u32* t = (const u32*)(wsa + L.dummy) + 8;
-        fprintf(stderr, "[sim] n=%zu eager=%u repairs=%u live=%u skips=%u epochs=%u specfail=%u replays=%u\n", n, t[30],
-                t[31], t[32], t[33], t[34], t[35], t[36]);
+        fprintf(stderr, "[sim] n=%zu eager=%u repairs=%u live=%u skips=%u epochs=%u specfail=%u replays=%u certified=%u\n", n, t[30],
+                t[31], t[32], t[33], t[34], t[35], t[36], t[37]);
     }
     free(ws);
     return r;
+}
+// Same, but with ONE workspace and ONE table-generation state kept across calls, as a persistent
+// wave of k_compress_batch keeps them across the chunks it pulls from the queue.
+static u8* g_ws = nullptr;
+static sqz::TableGen g_tg = {0, 0};
+extern "C" void sim_persistent_reset(void) {
+    free(g_ws);
+    g_ws = nullptr;
+    g_tg.gen = g_tg.windowLog = 0;
+}
+extern "C" unsigned sim_persistent_gen(void) { return g_tg.gen; }
+extern "C" size_t sim_compress_persistent(const uint8_t* src, size_t n, uint8_t* dst, size_t cap) {
+    if (!g_ws) {
+        size_t const tot = sqz::workspace_bytes(2u << 20) + 512;
+        g_ws = (u8*)malloc(tot);
+        memset(g_ws, 0xC3, tot);
+    }
+    u8* wsa = (u8*)(((uintptr_t)g_ws + 255) & ~(uintptr_t)255);
+    sqz::WsLayout L = sqz::ws_layout((u32)n); // per-chunk layout inside the pool slot, as compress_one does
+    return sqz::compress_frame_wave(src, (u32)n, dst, (u32)cap, wsa, L, g_tg);
 }
 extern "C" size_t sim_workspace_bytes(size_t n) { return sqz::workspace_bytes((u32)n); }
 extern "C" size_t sim_lds_bytes(void) { return sizeof(sqz::LdsState); }

@@ -198,3 +198,21 @@ def test_scale_compressible_sampled_decode(gpu_store, oracle):
         assert fb[i] == refb[k], i
     for i in range(96):
         assert fb[i] == fb[i % 12]          # identical inputs -> identical frames, whichever wave
+
+
+def test_persistent_waves_many_chunks_per_wave(oracle):
+    """4 compressor waves, 60 chunks of mixed classes: every wave keeps ONE workspace across ~15
+    chunks, so hash-table generation tags (no clear between chunks of one size class), the forced
+    clear on a class / strategy change and the no-match certificate's own generation are all
+    exercised on the device.  Every frame must equal the oracle's."""
+    import squishrs_amd
+    st = squishrs_amd.ChunkStore(device=0, dedup_capacity=1 << 12, compress_waves=4)
+    kinds = ["random", "text", "planted0", "mixed", "planted3", "records", "random", "planted6", "skewed", "runs"]
+    sizes = [262144, 262144, 200000, 262144, 70000, 131072, 262144, 262144, 40000, 262144, 9000, 600000]
+    chunks = [corpus.make(kinds[i % len(kinds)], 100 + i, sizes[(i * 7) % len(sizes)]) for i in range(60)]
+    try:
+        frames = _batch_compress(st, chunks)
+    finally:
+        st.close()
+    for i, (c, f) in enumerate(zip(chunks, frames)):
+        assert f == oracle.compress_chunk(c), (i, kinds[i % len(kinds)], len(c))

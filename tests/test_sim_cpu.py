@@ -51,3 +51,42 @@ def test_sim_matches_oracle(sim, oracle, kind, seed, n):
 def test_lds_budget_allows_8_waves_per_cu(sim):
     # 160 KiB of LDS per CU, one wave per workgroup
     assert sim.sim_lds_bytes() * 8 <= 160 * 1024
+
+
+def test_sim_persistent_wave_table_generations(sim, oracle):
+    """One workspace across many chunks, as a persistent wave sees it: consecutive btlazy2 chunks of
+    one size class reuse the hash table through generation tags (no clear), a chunk of another class
+    or strategy in between forces a clear.  Every frame must still equal the oracle's."""
+    sim.sim_compress_persistent.restype = ctypes.c_size_t
+    sim.sim_compress_persistent.argtypes = [ctypes.c_char_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_size_t]
+    sim.sim_persistent_gen.restype = ctypes.c_uint
+    sim.sim_persistent_reset()
+    seq = [("text", 1, 262144), ("random", 2, 262144), ("mixed", 3, 200000), ("records", 4, 262144),   # one class
+           ("text", 5, 70000), ("skewed", 6, 100000),                                                # class change
+           ("mixed", 7, 600000),                                                                     # row hash
+           ("runs", 8, 262144), ("text", 9, 140000),                                                 # back to btlazy2
+           ("text", 10, 9000),                                                                       # btopt
+           ("mixed", 11, 262144), ("mixed", 12, 262144), ("zeros", 0, 262144), ("text", 13, 262144)]
+    gens = []
+    for kind, seed, n in seq:
+        d = corpus.make(kind, seed, n)
+        cap = n + (n >> 8) + 1024
+        dst = ctypes.create_string_buffer(cap)
+        r = sim.sim_compress_persistent(d, n, dst, cap)
+        assert dst.raw[:r] == oracle.compress_chunk(d), (kind, seed, n)
+        gens.append(sim.sim_persistent_gen())
+    # two generations per btlazy2 chunk: the no-match certificate's table words, then the finder's
+    assert gens == [2, 4, 6, 8, 2, 4, 0, 2, 4, 0, 2, 4, 6, 8]
+    sim.sim_persistent_reset()
+
+
+PLANTED = [(v, s, n) for v in range(8) for s, n in ((1, 262144), (2, 200000), (3, 50000))]
+
+
+@pytest.mark.parametrize("variant,seed,n", PLANTED)
+def test_sim_no_match_certificate_handover(sim, oracle, variant, seed, n):
+    """Incompressible chunks with planted repeats at / beside the positions the lazy parser searches:
+    the certificate must stop exactly where a search can succeed and the exact code must take over
+    with the tree state libzstd would have (deferred searches replayed)."""
+    d = corpus.planted(seed, n, variant)
+    assert _sim_compress(sim, d) == oracle.compress_chunk(d)

@@ -177,5 +177,65 @@ GENERATORS = {
 }
 
 
+def lazy_schedule(nbytes: int, block: int = 128 << 10):
+    """Positions (offsets into the chunk) the zstd lazy parser searches while it finds nothing:
+    step = ((ip - anchor) >> 8) + 1, restarted at every 128 KiB block; the first block starts at 1."""
+    out = []
+    start = 0
+    while start < nbytes:
+        end = min(start + block, nbytes)
+        p = start + (1 if start == 0 else 0)
+        while p < end - 8:
+            out.append(p)
+            p += ((p - start) >> 8) + 1
+        start = end
+    return out
+
+
+def planted(seed: int, nbytes: int, variant: int = 0) -> bytes:
+    """Incompressible bytes with a few planted repeats, aimed at (or deliberately beside) the
+    positions the lazy parser searches on incompressible data.  Exercises the compressor's
+    no-match certificate: where it must stop, the hand-over to the exact search code, and the
+    deferred tree updates of the searches it skipped."""
+    b = bytearray(random_bytes(77, seed, nbytes))
+    sched = lazy_schedule(nbytes)
+    rnd = xoshiro_bytes(seed * 7919 + variant, 64)
+    pick = lambda k, lo, hi: lo + int.from_bytes(rnd[4 * k:4 * k + 4], "little") % max(1, hi - lo)
+
+    def copy(dst, src, ln):
+        b[dst:dst + ln] = b[src:src + ln]
+
+    if not sched:
+        return bytes(b)
+    mid = sched[pick(0, len(sched) // 3, 2 * len(sched) // 3)]
+    late = sched[pick(1, 3 * len(sched) // 4, len(sched) - 1)]
+    if variant == 0:      # a 40-byte repeat exactly at a searched position
+        copy(mid, pick(2, 0, mid - 64), 40)
+    elif variant == 1:    # only 4 equal bytes at a searched position (a length-4 match)
+        copy(mid, pick(2, 0, mid - 64), 4)
+    elif variant == 2:    # a repeat that starts one byte after a searched position (found at depth 0 only via s+1..)
+        copy(mid + 1, pick(2, 0, mid - 64), 24)
+    elif variant == 3:    # a run of equal bytes over a searched position: the repcode (offset 1) test fires
+        b[mid - 2:mid + 30] = bytes([b[mid]]) * 32
+    elif variant == 4:    # two plants, the later one first in memory order of the source
+        copy(late, pick(2, 0, mid - 64), 300)
+        copy(mid, pick(3, 0, mid - 64), 17)
+    elif variant == 5:    # repeat of a LATER region at an earlier searched position: nothing to find there,
+        src = min(nbytes - 64, late + 100)   # but the later region then matches the earlier one
+        copy(mid, src, 33)
+    elif variant == 6:    # three searched positions share their 4 bytes (bucket shared inside the schedule)
+        a, c, d = sched[len(sched) // 5], sched[len(sched) // 2], sched[len(sched) - 3]
+        copy(c, a, 4)
+        copy(d, a, 9)
+    elif variant == 7:    # plant in the last block only, source in the first block
+        last_start = ((nbytes - 1) // (128 << 10)) * (128 << 10)
+        tail = [x for x in sched if x >= last_start]
+        t = tail[len(tail) // 2] if tail else mid
+        copy(t, pick(2, 0, max(65, min(t, 128 << 10)) - 64), 64)
+    return bytes(b)
+
+
 def make(kind: str, seed: int, nbytes: int) -> bytes:
+    if kind.startswith("planted"):
+        return planted(seed, nbytes, int(kind[7:] or 0))
     return GENERATORS[kind](seed, nbytes)

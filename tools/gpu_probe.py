@@ -51,10 +51,11 @@ for kind, seed, n, rep in cases:
     host = comp.cpu().numpy()
     ok = 0
     t1 = time.time()
-    for i, c in enumerate(chunks[:4]):
+    ncheck = rep if os.environ.get("SQ_PROBE_CHECK") == "all" else min(4, rep)
+    for i, c in enumerate(chunks[:ncheck]):
         f = host[int(coff[i]):int(coff[i + 1])].tobytes()
         ok += (f == o.compress_chunk(c))
-    cpu = (time.time() - t1) / min(4, rep)
-    log(f"  done {dt * 1e3:.1f} ms wall, kernel {st.timings().compress_ms:.1f} ms; parity {ok}/{min(4, rep)};"
+    cpu = (time.time() - t1) / ncheck
+    log(f"  done {dt * 1e3:.1f} ms wall, kernel {st.timings().compress_ms:.1f} ms; parity {ok}/{ncheck};"
         f" clen0={int(coff[1] - coff[0])}; oracle cpu {cpu * 1e3:.1f} ms/chunk")
 st.close()
