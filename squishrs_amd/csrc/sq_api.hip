@@ -82,6 +82,7 @@ struct sq_ctx {
     DevBuf b_off, b_len, b_slot_off, b_frame_len, b_out_off, b_isnew, b_hashes, b_stage_in,
         b_stage_out, b_slots, b_ws, b_misc;
     void* h_pinned = nullptr; // small pinned host mirror (total sizes etc.)
+    u32* d_sched_tab = nullptr; // constant no-match schedule tables of the compressor (sched_tab_fill)
 
     sq_timings last = {0, 0, 0, 0};
 };
@@ -174,6 +175,17 @@ int sq_ctx_create(const sq_config* cfg_in, sq_ctx** out) {
         sq_ctx_destroy(c);
         return SQ_E_DEVICE;
     }
+#ifndef SQ_NO_COMPRESS
+    {
+        std::vector<u32> tab(SQZ_SCHEDTAB_WORDS, 0);
+        sqz::sched_tab_fill(tab.data());
+        if (hipMalloc((void**)&c->d_sched_tab, tab.size() * 4) != hipSuccess ||
+            hipMemcpy(c->d_sched_tab, tab.data(), tab.size() * 4, hipMemcpyHostToDevice) != hipSuccess) {
+            sq_ctx_destroy(c);
+            return SQ_E_NOMEM;
+        }
+    }
+#endif
     *out = c;
     return SQ_OK;
 }
@@ -189,6 +201,7 @@ void sq_ctx_destroy(sq_ctx* c) {
     if (c->d_keys) (void)hipFree(c->d_keys);
     if (c->d_unique) (void)hipFree(c->d_unique);
     if (c->h_pinned) (void)hipHostFree(c->h_pinned);
+    if (c->d_sched_tab) (void)hipFree(c->d_sched_tab);
     for (auto& e : c->ev)
         if (e) (void)hipEventDestroy(e);
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
@@ -377,7 +390,8 @@ static int compress_async(sq_ctx* c, const u8* d_data, const u64* h_off, const u
         hipLaunchKernelGGL(sqz::k_compress_batch, grid, block, 0, c->stream, d_data, (const u64*)c->b_off.p,
                            (const u32*)c->b_len.p, d_select, n, (u8*)c->b_slots.p,
                            (const u64*)c->b_slot_off.p, (u32*)c->b_frame_len.p, (u8*)c->b_ws.p,
-                           (u64)ws_each, (u32*)c->b_misc.p /*queue*/, (u32*)c->b_misc.p + 16 /*err*/);
+                           (u64)ws_each, (u32*)c->b_misc.p /*queue*/, (u32*)c->b_misc.p + 16 /*err*/,
+                           (const u32*)c->d_sched_tab);
         HIPCHK(hipGetLastError());
     }
     HIPCHK(hipEventRecord(c->ev[5], c->stream));

@@ -25,7 +25,7 @@ struct Fingerprint {
 
 struct WsLayout {
     size_t hashTable, table2, hashTable3, seqs, lits, llCode, ofCode, mlCode, optState, fp, sched, liveList,
-        skipList, blockTab, certSched, dummy, total;
+        skipList, blockTab, dummy, total;
 };
 
 #if SQ_ON_DEVICE
@@ -99,14 +99,26 @@ SQ_HD WsLayout ws_layout(u32 max_len) {
     o += ws_align((size_t)SQZ_SKIP_CAP * 8);
     L.blockTab = o;
     o += ws_align((size_t)SQZ_BLOCKTAB_CAP * 8);
-    L.certSched = o;
-    o += ws_align((size_t)SQZ_SCHED_CAP * 4);
     L.dummy = o;
     o += 256;
     L.total = o;
     return L;
 }
-SQ_HD size_t workspace_bytes(u32 max_len) { return ws_layout(max_len).total; }
+SQ_HD size_t workspace_bytes(u32 max_len) { return ws_layout(max_len).total + 1024; } // + debug / profiling tail
+
+// The constant no-match schedule tables (layout: see "no-match schedule tables" in sq_zstd_match.h);
+// filled once by the host (SQZ_SCHEDTAB_WORDS words).
+SQ_HD void sched_tab_fill(u32* tab) {
+    for (u32 variant = 0; variant < 2; variant++) {
+        u32* const e = tab + 2 + variant * SQZ_SCHEDTAB_N;
+        u32 n = 0, p = (variant == 0) ? 1u : 0u;
+        while (p < SQZ_BLOCKSIZE_MAX - 8 && n < SQZ_SCHEDTAB_N) {
+            e[n++] = p;
+            p += (p >> 8) + 1;
+        }
+        tab[variant] = n;
+    }
+}
 
 // ---------------------------------------------------------------- pre-block splitter (1.5.7)
 SQ_DEV u32 ps_hash2_10(const u8* p) { return ((u32)sq_grd16(p) * 0x9e3779b9U) >> 22; }
@@ -277,12 +289,22 @@ SQ_DEVFN u32 compressBlock_internal(MatchState& ms, SeqStore& ss, BlockState& bs
         }
         SQ_TRACE(0, 7);
         SQ_TRACE(4, ss.nseq);
-        PROF_T0(t_ll);
-        if (lastLLSize) wv_memcpy(ss.lits + ss.nlits, src + srcSize - lastLLSize, lastLLSize);
-        PROF_ADD(7, t_ll);
-        ss.nlits += lastLLSize;
-        wv_mem_sync_inv(); // sequence records / literals written by other lanes have landed
-        cSize = entropy_compress_seqstore(ss, &g_lds.ent[p], &g_lds.ent[nx], ms.cp.strategy, dst, dstCap, srcSize);
+        if (ss.nseq == 0 && ss.nlits == 0 && lastLLSize == srcSize) {
+            // no sequence at all: the literals ARE the block; the entropy stage reads them in place
+            SeqStore whole = ss;
+            whole.lits = const_cast<u8*>(src);
+            whole.nlits = srcSize;
+            ss.nlits = srcSize;
+            wv_mem_sync_inv();
+            cSize = entropy_compress_seqstore(whole, &g_lds.ent[p], &g_lds.ent[nx], ms.cp.strategy, dst, dstCap, srcSize);
+        } else {
+            PROF_T0(t_ll);
+            if (lastLLSize) wv_memcpy(ss.lits + ss.nlits, src + srcSize - lastLLSize, lastLLSize);
+            PROF_ADD(7, t_ll);
+            ss.nlits += lastLLSize;
+            wv_mem_sync_inv(); // sequence records / literals written by other lanes have landed
+            cSize = entropy_compress_seqstore(ss, &g_lds.ent[p], &g_lds.ent[nx], ms.cp.strategy, dst, dstCap, srcSize);
+        }
         SQ_TRACE(0, 9);
         SQ_TRACE(5, cSize);
         if (is_err(cSize)) return cSize;
@@ -306,7 +328,8 @@ struct TableGen {
 };
 
 // Returns the frame length, 0 on error.
-SQ_DEVFN u32 compress_frame_wave(const u8* src, u32 n, u8* dst, u32 cap, u8* ws, const WsLayout& L, TableGen& tg) {
+SQ_DEVFN u32 compress_frame_wave(const u8* src, u32 n, u8* dst, u32 cap, u8* ws, const WsLayout& L, TableGen& tg,
+                                 const u32* schedTab) {
     MatchState ms;
     SeqStore ss;
     BlockState bs;
@@ -364,7 +387,8 @@ SQ_DEVFN u32 compress_frame_wave(const u8* src, u32 n, u8* dst, u32 cap, u8* ws,
     ms.liveList = (u32*)(ws + L.liveList);
     ms.skipList = (u32*)(ws + L.skipList);
     ms.blockTab = (u32*)(ws + L.blockTab);
-    ms.certSched = (u32*)(ws + L.certSched);
+    ms.schedTab = schedTab;
+    ms.certCnt0 = 0;
     ms.nCert = ms.nCertDone = ms.certEnd = 0;
     ms.nLive = ms.nSkip = ms.nBlocks = 0;
     ms.specOff = 0;
@@ -420,10 +444,15 @@ SQ_DEVFN u32 compress_frame_wave(const u8* src, u32 n, u8* dst, u32 cap, u8* ws,
         // whole-chunk no-match certificate first (it borrows the table areas under its own
         // generation; the next generation makes its words read as empty again)
         PROF_T0(t_pr);
-        u32 const nS = filter_predict(ms, SQZ_WINDOW_START + 1, SQZ_WINDOW_START, ms.certSched);
+        // a chunk of this strategy has at most two blocks; their schedules are table prefixes
+        u32 const len0 = n < SQZ_BLOCKSIZE_MAX ? n : SQZ_BLOCKSIZE_MAX;
+        u32 const len1 = n - len0;
+        u32 const full0 = gld32(schedTab), full1 = gld32(schedTab + 1);
+        ms.certCnt0 = (len0 == SQZ_BLOCKSIZE_MAX) ? full0 : sched_count(schedTab + 2, full0, len0 - 8);
+        u32 const cnt1 = (len1 < 9) ? 0u : (len1 == SQZ_BLOCKSIZE_MAX) ? full1 : sched_count(schedTab + 2 + SQZ_SCHEDTAB_N, full1, len1 - 8);
+        ms.nCert = ms.certCnt0 + cnt1;
         PROF_ADD(24, t_pr);
-        if (nS > 0 && nS < SQZ_SCHED_CAP) {
-            ms.nCert = nS;
+        if (ms.nCert > 0) {
             cert_compute(ms);
             tg.gen++;
             ms.genBits = tg.gen << SQZ_HT_GEN_SHIFT;
@@ -506,11 +535,11 @@ SQ_DEVFN u32 compress_frame_wave(const u8* src, u32 n, u8* dst, u32 cap, u8* ws,
 #if SQ_ON_DEVICE
 // One chunk -> one frame in its output slot (kept out of line: keeps the queue loop simple).
 __device__ __noinline__ void compress_one(const u8* data, const u64* off, const u32* len, u32 idx, u8* slots,
-                                          const u64* slot_off, u32* frame_len, u8* ws, u32* err, TableGen& tg) {
+                                          const u64* slot_off, u32* frame_len, u8* ws, u32* err, TableGen& tg, const u32* schedTab) {
     u32 const L = len[idx];
     WsLayout const lay = ws_layout(L); // offsets for this length are <= the pool's
     u32 const cap = (u32)(slot_off[idx + 1] - slot_off[idx]);
-    u32 const r = compress_frame_wave(data + off[idx], L, slots + slot_off[idx], cap, ws, lay, tg);
+    u32 const r = compress_frame_wave(data + off[idx], L, slots + slot_off[idx], cap, ws, lay, tg, schedTab);
     if (wv_lane() == 0) {
         frame_len[idx] = r;
         if (r == 0) atomicOr(err, 1u);
@@ -521,7 +550,8 @@ __device__ __noinline__ void compress_one(const u8* data, const u64* off, const 
 // indices from *queue until exhausted; every wave reaches the exit condition (idx >= n).
 __global__ void __launch_bounds__(64, 2) // 2 waves per SIMD: <= 256 registers, 8 waves per CU (LDS: 8 x 19 KiB)
 k_compress_batch(const u8* data, const u64* off, const u32* len, const u8* select, u32 n, u8* slots,
-                 const u64* slot_off, u32* frame_len, u8* ws_pool, u64 ws_each, u32* queue, u32* err) {
+                 const u64* slot_off, u32* frame_len, u8* ws_pool, u64 ws_each, u32* queue, u32* err,
+                 const u32* schedTab) {
     u8* const ws = ws_pool + (u64)blockIdx.x * ws_each;
     u32* const dbg = (u32*)(ws + ws_each - 256) + 8; // wave-level progress words for the watchdog
     u32 iter = 0;
@@ -543,7 +573,7 @@ k_compress_batch(const u8* data, const u64* off, const u32* len, const u8* selec
         if (idx >= n) break;
         bool const take = (select == nullptr) || (select[idx] != 0);
         PROF_T0(t_all);
-        if (take) compress_one(data, off, len, idx, slots, slot_off, frame_len, ws, err, tg);
+        if (take) compress_one(data, off, len, idx, slots, slot_off, frame_len, ws, err, tg, schedTab);
         PROF_ADD(0, t_all);
     }
     if (wv_lane() == 0) dbg[11] = 777;

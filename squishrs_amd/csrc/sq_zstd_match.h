@@ -96,9 +96,10 @@ struct MatchState {
     u32 nxEnt;       // index of the entropy-table slot that is scratch during match finding
     u32 nEpoch, nSpecFail, nReplay; // statistics (trace words 34..36)
     // ---- whole-chunk no-match certificate (see cert_build / cert_scan)
-    u32* certSched;  // the schedule the certificate was computed for (workspace)
-    u32 nCert;       // entries in certSched
-    u32 nCertDone;   // leading entries whose searches were skipped as certainly failing
+    const u32* schedTab; // constant no-match schedules of a 128 KiB block (sched_tab_fill)
+    u32 certCnt0;    // scheduled searches in block 0 of this chunk
+    u32 nCert;       // scheduled searches in the whole chunk (blocks 0 and 1)
+    u32 nCertDone;   // leading ones that were skipped as certainly failing
     u32 certEnd;     // every scheduled search at a position < certEnd certainly fails; 0 = no certificate
     u32 sbMax;       // current super-batch length of the filtered insertion stream (256..2048)
     u32 genBits;     // btlazy2 hash-table generation tag of this chunk, in place (bits 19..29)
@@ -226,6 +227,62 @@ SQ_DEVFN void bloom_rebuild(MatchState& ms) {
     PROF_ADD(15, t_br);
 }
 
+#if SQ_ON_DEVICE
+// Phase 1 of the filtered position stream, shared by the insertion sweep and the certificate scan:
+// hash `lim` (<= 2048) consecutive positions starting at idx0, test them against the Bloom filter
+// in LDS and leave the positives as (position, hash) pairs, in position order, in the 256-entry
+// staging list (g_lds.grp).  Returns the number of positives (only the first 256 are stored).
+// Rounds of 16 coalesced loads, then per group of 4 loads: hashes, all 8 Bloom probes issued back
+// to back, ballot compaction.  FULL = exactly 2048 positions: no address clamping, no tail masks.
+template <bool FULL>
+SQ_DEV u32 filter_phase1(const u8* const base, u32 const idx0, u32 const lim, u32 const hashLog) {
+    u32 const lane = wv_lane();
+    u64 const below = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+    SQ_L u32* const stage = (SQ_L u32*)g_lds.grp;
+    const SQ_L u32* const B = (const SQ_L u32*)g_lds.u.bloom;
+    u32 const lastPos = idx0 + lim - 1;
+    u32 cnt = 0;
+#pragma unroll 1
+    for (u32 r = 0; r < 2; r++) {
+        if (!FULL && 1024 * r >= lim) break;
+        u32 const rl = FULL ? 1024u : lim - 1024 * r; // positions of this round (may exceed 1024)
+        u32 w[16];
+#pragma unroll
+        for (u32 u = 0; u < 16; u++) {
+            u32 const pz = idx0 + 1024 * r + 64 * u + lane;
+            w[u] = sq_grd32(base + ((FULL || pz < lastPos) ? pz : lastPos));
+        }
+#pragma unroll
+        for (u32 q = 0; q < 4; q++) {
+            if (!FULL && 256 * q >= rl) break;
+            u32 p1[4], p2[4];
+#pragma unroll
+            for (u32 k = 0; k < 4; k++) {
+                u32 const h = hash4(w[4 * q + k], hashLog);
+                w[4 * q + k] = h;
+                p1[k] = B[(h & 0xFFFFu) >> 5];
+                p2[k] = B[(h * 0x9E3779B1u) >> 21];
+            }
+#pragma unroll
+            for (u32 k = 0; k < 4; k++) {
+                u32 const h = w[4 * q + k];
+                u32 const u = 4 * q + k;
+                bool const c = (FULL || (64 * u + lane < rl)) & (((p1[k] >> (h & 31)) & (p2[k] >> (((h * 0x9E3779B1u) >> 16) & 31)) & 1u) != 0);
+                u64 const m = wv_ballot(c);
+                u32 const slot = cnt + (u32)__popcll(m & below);
+                if (c && slot < 256) {
+                    stage[2 * slot] = idx0 + 1024 * r + 64 * u + lane;
+                    stage[2 * slot + 1] = h;
+                }
+                cnt += (u32)__popcll(m);
+            }
+        }
+        wv_fence();
+    }
+    return cnt;
+}
+#endif
+
 // Insert positions [from, to) as unsorted candidates (ZSTD_updateDUBT) into the buckets selected
 // by MODE: 0 = regular update (live buckets; all buckets in eager mode), 1 = repair replay
 // (PENDING buckets), 2 = go-eager replay (every bucket that is not LIVE).
@@ -258,50 +315,8 @@ SQ_DEVFN void dubt_insert_range(MatchState& ms, u32 from, u32 to) {
             // super-batch length: adapts downwards when the Bloom filter has become dense enough
             // (after schedule repairs) to overflow the 256-entry candidate list
             u32 const lim = (to - idx0 < ms.sbMax) ? to - idx0 : ms.sbMax;
-            u32 const lastPos = idx0 + lim - 1;
-            u32 cnt = 0;
             PROF_T0(t_p1);
-            // phase 1: rounds of 16 coalesced loads (addresses clamped to the range, no branches),
-            // then per group of 4 loads: hashes, all 8 Bloom probes issued back to back, candidate
-            // compaction in position order
-            const SQ_L u32* const B = (const SQ_L u32*)g_lds.u.bloom;
-#pragma unroll 1
-            for (u32 r = 0; r < 2; r++) {
-                if (1024 * r >= lim) break;
-                u32 const rl = lim - 1024 * r; // positions of this round (may exceed 1024)
-                u32 w[16];
-#pragma unroll
-                for (u32 u = 0; u < 16; u++) {
-                    u32 const pz = idx0 + 1024 * r + 64 * u + lane;
-                    w[u] = sq_grd32(base + (pz < lastPos ? pz : lastPos));
-                }
-#pragma unroll
-                for (u32 q = 0; q < 4; q++) {
-                    if (256 * q >= rl) break;
-                    u32 p1[4], p2[4];
-#pragma unroll
-                    for (u32 v = 0; v < 4; v++) {
-                        u32 const h = hash4(w[4 * q + v], hashLog);
-                        w[4 * q + v] = h;
-                        p1[v] = B[(h & 0xFFFFu) >> 5];
-                        p2[v] = B[(h * 0x9E3779B1u) >> 21];
-                    }
-#pragma unroll
-                    for (u32 v = 0; v < 4; v++) {
-                        u32 const h = w[4 * q + v];
-                        u32 const u = 4 * q + v;
-                        bool const c = (64 * u + lane < rl) & (((p1[v] >> (h & 31)) & (p2[v] >> (((h * 0x9E3779B1u) >> 16) & 31)) & 1u) != 0);
-                        u64 const m = wv_ballot(c);
-                        u32 const slot = cnt + (u32)__popcll(m & below);
-                        if (c && slot < 256) {
-                            stage[2 * slot] = idx0 + 1024 * r + 64 * u + lane;
-                            stage[2 * slot + 1] = h;
-                        }
-                        cnt += (u32)__popcll(m);
-                    }
-                }
-                wv_fence();
-            }
+            u32 const cnt = (lim == 2048) ? filter_phase1<true>(base, idx0, lim, hashLog) : filter_phase1<false>(base, idx0, lim, hashLog);
             PROF_ADD(12, t_p1);
             PROF_CNT(18, 1);
             PROF_CNT(19, cnt);
@@ -442,6 +457,36 @@ SQ_DEVFN void dubt_replay(MatchState& ms, u32 to) {
     if (pos < to) dubt_insert_range<MODE>(ms, pos, to);
 }
 
+// ---------------------------------------------------------------- no-match schedule tables
+// While the lazy parser finds nothing, the positions it searches in a block depend only on where
+// the block starts relative to the anchor: step = ((ip - anchor) >> 8) + 1.  Two constant tables
+// (relative positions, ascending) describe any block of a chunk: "first" (the search starts one
+// byte into the frame's first block) and "later"; a shorter block uses a prefix.  Layout (u32):
+// [0] entries of "first", [1] entries of "later", then the two tables, SQZ_SCHEDTAB_N slots each.
+#define SQZ_SCHEDTAB_N 2048u
+#define SQZ_SCHEDTAB_WORDS (2u + 2u * SQZ_SCHEDTAB_N)
+
+// number of table entries < limit (entries ascending); whole wave, ~28 coalesced loads per lane
+SQ_DEVFN u32 sched_count(const u32* const entries, u32 const nEntries, u32 const limit) {
+#if SQ_ON_DEVICE
+    u32 c = 0;
+    for (u32 i = wv_lane(); i < nEntries; i += 64) c += (sq_gld32(entries + i) < limit) ? 1u : 0u;
+    for (int sft = 32; sft >= 1; sft >>= 1) c += (u32)__shfl_xor((int)c, sft, 64);
+    return wv_uni(c);
+#else
+    u32 c = 0;
+    while (c < nEntries && entries[c] < limit) c++;
+    return c;
+#endif
+}
+// position (index) of the i-th scheduled search of the chunk, i < ms.nCert (a chunk of this
+// strategy has at most two blocks)
+SQ_DEV u32 cert_pos(const MatchState& ms, u32 i) { // one load, no branch
+    bool const first = i < ms.certCnt0;
+    u32 const slot = first ? i : SQZ_SCHEDTAB_N + (i - ms.certCnt0);
+    return sq_gld32(ms.schedTab + 2 + slot) + (first ? SQZ_WINDOW_START : SQZ_WINDOW_START + SQZ_BLOCKSIZE_MAX);
+}
+
 // Searches skipped under the no-match certificate were never executed, so the buckets they would
 // have re-sorted hold them (after a replay) as plain unsorted nodes.  Give them the mark of a
 // deferred search, exactly what a speculative epoch leaves behind; dubt_materialize replays them if
@@ -454,7 +499,7 @@ SQ_DEVFN void cert_mark_deferred(MatchState& ms) {
     u32 const btMask = (1u << (ms.cp.chainLog - 1)) - 1;
 #if SQ_ON_DEVICE
     for (u32 i = wv_lane(); i < ms.nCertDone; i += 64) {
-        u32 const s = sq_gld32(ms.certSched + i);
+        u32 const s = cert_pos(ms, i);
         if (s >= ms.nextToUpdate) continue; // not inserted yet (cannot happen: the search inserts it)
         u32 const h = hash4(sq_grd32(ms.base + s), ms.cp.hashLog);
         u32 const v = ht_dec(ms, sq_tld32(ms.hashTable + h));
@@ -464,7 +509,7 @@ SQ_DEVFN void cert_mark_deferred(MatchState& ms) {
     wv_mem_sync();
 #else
     for (u32 i = 0; i < ms.nCertDone; i++) {
-        u32 const s = ms.certSched[i];
+        u32 const s = cert_pos(ms, i);
         if (s >= ms.nextToUpdate) continue;
         u32 const h = hash4(sq_rd32(ms.base + s), ms.cp.hashLog);
         u32 const v = ht_dec(ms, ms.hashTable[h]);
@@ -663,6 +708,20 @@ SQ_DEVFN void filter_repair(MatchState& ms, u32 pos, u32 anc, bool first) {
 // Blocks that are certified entirely cost no search, no insertion and no table traffic at all.
 // The certificate is conservative (p is not required to be reachable within nbCompares), so a
 // "maybe" only means the exact code decides; results are identical to libzstd's either way.
+// Bloom filter of the certificate scan: keyed by the 4 BYTES themselves (probe 1 from the low
+// half, probe 2 from the high half), so a scanned position costs no multiplication; only the few
+// positives are hashed.
+SQ_DEV void vbloom_add(u32 v) {
+    u32 const w1 = (v & 0xFFFFu) >> 5, m1 = 1u << (v & 31), w2 = v >> 21, m2 = 1u << ((v >> 16) & 31);
+#if SQ_ON_DEVICE
+    SQ_L u32* const B = (SQ_L u32*)g_lds.u.bloom;
+    __hip_atomic_fetch_or(&B[w1], m1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    __hip_atomic_fetch_or(&B[w2], m2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#else
+    g_lds.u.bloom[w1] |= m1;
+    g_lds.u.bloom[w2] |= m2;
+#endif
+}
 #define SQZ_CERT_DUP SQZ_HT_PEND // table-word flag: another scheduled position shares this bucket
 #define SQZ_CERT_OVF_CAP 64u
 
@@ -679,50 +738,67 @@ SQ_DEVFN void cert_compute(MatchState& ms) {
     u32 const lane = wv_lane();
     u64 const below = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
     SQ_L u32* const ovf = (SQ_L u32*)&g_lds.ent[ms.nxEnt & 1];
-    SQ_L u32* const stage = (SQ_L u32*)g_lds.grp;
     u32 vmin = 0xFFFFFFFFu; // lane-local minimum of the violating scheduled positions
     PROF_T0(t_bld);
-    // ---- build, pass A: every s claims its bucket (one of several claimants wins), repcode test
-    for (u32 i0 = 0; i0 < nCert; i0 += 64) {
-        u32 const i = i0 + lane;
-        if (i < nCert) {
-            u32 const sp = sq_gld32(ms.certSched + i);
-            u32 const v = sq_grd32(base + sp);
-            u32 const h = hash4(v, hashLog);
-            sq_gst32(T + h, ht_enc(ms, sp));
-            bloom_add(h);
-            if (sq_grd32(base + sp + 1) == v && sp < vmin) vmin = sp; // offset_1 == 1 repcode at s+1
+    // ---- build, pass A: every s claims its bucket (one of several claimants wins), repcode test.
+    // 256 scheduled positions per step, all loads unconditional (indices clamped) so that the
+    // dependent loads (table entry -> bytes) of the four groups overlap; only the effects are masked.
+    u32 const iLast = nCert - 1;
+    for (u32 i0 = 0; i0 < nCert; i0 += 256) {
+        u32 sp[4], v[4], v1[4];
+#pragma unroll
+        for (u32 g = 0; g < 4; g++) {
+            u32 const i = i0 + 64 * g + lane;
+            sp[g] = cert_pos(ms, i < nCert ? i : iLast);
+        }
+#pragma unroll
+        for (u32 g = 0; g < 4; g++) {
+            v[g] = sq_grd32(base + sp[g]);
+            v1[g] = sq_grd32(base + sp[g] + 1);
+        }
+#pragma unroll
+        for (u32 g = 0; g < 4; g++) {
+            if (i0 + 64 * g + lane < nCert) {
+                u32 const h = hash4(v[g], hashLog);
+                sq_gst32(T + h, ht_enc(ms, sp[g]));
+                vbloom_add(v[g]);
+                if (v1[g] == v[g] && sp[g] < vmin) vmin = sp[g]; // offset_1 == 1 repcode at s+1
+            }
         }
     }
     wv_mem_sync();
     // ---- build, pass B: the winner of a bucket deposits its 4 bytes, the others go to the overflow list
-    for (u32 i0 = 0; i0 < nCert; i0 += 64) {
-        u32 const i = i0 + lane;
-        bool loser = false;
-        u32 sp = 0, v = 0;
-        if (i < nCert) {
-            sp = sq_gld32(ms.certSched + i);
-            v = sq_grd32(base + sp);
-            u32 const h = hash4(v, hashLog);
-            u32 const t = ht_dec(ms, sq_tld32(T + h));
-            if ((t & SQZ_HT_IDX) == sp)
-                sq_gst32(V + h, v);
-            else {
-                loser = true;
-                sq_gst32(T + h, ht_enc(ms, t | SQZ_CERT_DUP));
-            }
+    for (u32 i0 = 0; i0 < nCert; i0 += 256) {
+        u32 sp[4], v[4], t[4];
+#pragma unroll
+        for (u32 g = 0; g < 4; g++) {
+            u32 const i = i0 + 64 * g + lane;
+            sp[g] = cert_pos(ms, i < nCert ? i : iLast);
         }
-        u64 const m = wv_ballot(loser);
-        if (m) {
-            if (loser) {
-                u32 const slot = nOvf + (u32)__popcll(m & below);
-                if (slot < SQZ_CERT_OVF_CAP) {
-                    ovf[2 * slot] = sp;
-                    ovf[2 * slot + 1] = v;
-                } else if (sp < vmin)
-                    vmin = sp; // no room to remember it: the certificate ends there
+#pragma unroll
+        for (u32 g = 0; g < 4; g++) v[g] = sq_grd32(base + sp[g]);
+#pragma unroll
+        for (u32 g = 0; g < 4; g++) t[g] = sq_tld32(T + hash4(v[g], hashLog));
+#pragma unroll
+        for (u32 g = 0; g < 4; g++) {
+            bool const valid = i0 + 64 * g + lane < nCert;
+            u32 const td = ht_dec(ms, t[g]);
+            bool const loser = valid && (td & SQZ_HT_IDX) != sp[g];
+            u32 const h = hash4(v[g], hashLog);
+            if (valid && !loser) sq_gst32(V + h, v[g]);
+            if (loser) sq_gst32(T + h, ht_enc(ms, td | SQZ_CERT_DUP));
+            u64 const m = wv_ballot(loser);
+            if (m) {
+                if (loser) {
+                    u32 const slot = nOvf + (u32)__popcll(m & below);
+                    if (slot < SQZ_CERT_OVF_CAP) {
+                        ovf[2 * slot] = sp[g];
+                        ovf[2 * slot + 1] = v[g];
+                    } else if (sp[g] < vmin)
+                        vmin = sp[g]; // no room to remember it: the certificate ends there
+                }
+                nOvf += (u32)__popcll(m);
             }
-            nOvf += (u32)__popcll(m);
         }
     }
     if (nOvf > SQZ_CERT_OVF_CAP) nOvf = SQZ_CERT_OVF_CAP;
@@ -735,98 +811,36 @@ SQ_DEVFN void cert_compute(MatchState& ms) {
         }
         x = wv_uni(x);
         if (x < certEnd) certEnd = x;
-        SQ_TRACE(43, x);
     }
     PROF_ADD(25, t_bld);
-    // ---- scan: positions [2, min(certEnd, last position with 4 readable bytes])
+    // ---- scan: positions [2, min(certEnd, last position with 4 readable bytes]), as one software
+    // pipeline over rounds of 1024 positions.  The kernel is latency-bound (2 waves per SIMD), so
+    // every memory access of the scan is issued at least one round before its result is used:
+    //   round k+2 : its 16 coalesced loads are issued
+    //   round k   : Bloom tests -> candidate positions (LDS); their bytes are re-loaded   (stage A)
+    //   round k-1 : candidates hashed, table word + winner's bytes loaded                 (stage B)
+    //   round k-2 : candidates judged                                                     (stage C)
     u32 const pEnd = ms.chunkEndPos - 3; // one past the last p with p + 4 <= chunkEnd
+    u32 const lastValid = pEnd - 1;
+    SQ_L u32* const cand = (SQ_L u32*)&g_lds.ent[ms.nxEnt & 1] + 2 * SQZ_CERT_OVF_CAP; // 1024 positions
     const SQ_L u32* const B = (const SQ_L u32*)g_lds.u.bloom;
-    // super-batch length: the schedule is dense at a block start (every position of its first 256
-    // bytes, every second of the next 512, ...) and scheduled positions are candidates themselves,
-    // so the length adapts to keep the candidate list within its 256 entries
-    u32 sb = 256;
-    for (u32 idx0 = SQZ_WINDOW_START; idx0 < certEnd && idx0 < pEnd;) {
-        u32 const stop = certEnd < pEnd ? certEnd : pEnd;
-        u32 const lim = (stop - idx0 < sb) ? stop - idx0 : sb;
-        u32 const lastPos = idx0 + lim - 1;
-        u32 cnt = 0;
-        PROF_T0(t_s1);
-#pragma unroll 1
-        for (u32 r = 0; r < 2; r++) {
-            if (1024 * r >= lim) break;
-            u32 const rl = lim - 1024 * r;
-            u32 w[16];
-#pragma unroll
-            for (u32 u = 0; u < 16; u++) {
-                u32 const pz = idx0 + 1024 * r + 64 * u + lane;
-                w[u] = sq_grd32(base + (pz < lastPos ? pz : lastPos));
-            }
-#pragma unroll
-            for (u32 q = 0; q < 4; q++) {
-                if (256 * q >= rl) break;
-                u32 p1[4], p2[4];
-#pragma unroll
-                for (u32 k = 0; k < 4; k++) {
-                    u32 const h = hash4(w[4 * q + k], hashLog);
-                    w[4 * q + k] = h;
-                    p1[k] = B[(h & 0xFFFFu) >> 5];
-                    p2[k] = B[(h * 0x9E3779B1u) >> 21];
+    u32 aP[2] = {0, 0}, aV[2] = {0, 0}, aN = 0;                                 // stage A registers
+    u32 bP[2] = {0, 0}, bV[2] = {0, 0}, bT[2] = {0, 0}, bTV[2] = {0, 0}, bN = 0; // stage B registers
+    u32 pos = SQZ_WINDOW_START;
+
+    auto judge = [&](u32 p, u32 vp, u32 traw, u32 tv, bool valid, u32& viol) {
+        u32 const t = ht_dec(ms, traw);
+        if (valid && t) {
+            u32 const sw = t & SQZ_HT_IDX;
+            if (p < sw && vp == tv && sw < viol) viol = sw;
+            if (t & SQZ_CERT_DUP)
+                for (u32 e = 0; e < nOvf; e++) {
+                    u32 const so = ovf[2 * e], vo = ovf[2 * e + 1];
+                    if (vp == vo && p < so && so < viol) viol = so;
                 }
-#pragma unroll
-                for (u32 k = 0; k < 4; k++) {
-                    u32 const h = w[4 * q + k];
-                    u32 const u = 4 * q + k;
-                    bool const c = (64 * u + lane < rl) & (((p1[k] >> (h & 31)) & (p2[k] >> (((h * 0x9E3779B1u) >> 16) & 31)) & 1u) != 0);
-                    u64 const m = wv_ballot(c);
-                    u32 const slot = cnt + (u32)__popcll(m & below);
-                    if (c && slot < 256) {
-                        stage[2 * slot] = idx0 + 1024 * r + 64 * u + lane;
-                        stage[2 * slot + 1] = h;
-                    }
-                    cnt += (u32)__popcll(m);
-                }
-            }
-            wv_fence();
         }
-        PROF_ADD(26, t_s1);
-        if (cnt > 256) {
-            if (sb > 128) {
-                sb >>= 1;
-                continue;
-            }
-            // degenerate data (one value everywhere): positions >= idx0 stay unverified, which
-            // only matters to searches beyond idx0
-            if (idx0 + 1 < certEnd) certEnd = idx0 + 1;
-            break;
-        }
-        if (cnt <= 96 && sb < 2048) sb <<= 1;
-        wv_fence();
-        // candidates: table word + the winner's bytes + own bytes, one round trip
-        PROF_T0(t_s2);
-        u32 viol = 0xFFFFFFFFu;
-#pragma unroll
-        for (u32 g = 0; g < 4; g++) {
-            u32 const j = 64 * g + lane;
-            if (64 * g < cnt) {
-                u32 p = 0, t = 0, tv = 0, vp = 1;
-                if (j < cnt) {
-                    p = stage[2 * j];
-                    u32 const h = stage[2 * j + 1];
-                    t = ht_dec(ms, sq_tld32(T + h));
-                    tv = sq_tld32(V + h);
-                    vp = sq_grd32(base + p);
-                }
-                if (t) {
-                    u32 const sw = t & SQZ_HT_IDX & ~SQZ_CERT_DUP;
-                    if (p < sw && vp == tv && sw < viol) viol = sw;
-                    if (t & SQZ_CERT_DUP)
-                        for (u32 e = 0; e < nOvf; e++) {
-                            u32 const so = ovf[2 * e], vo = ovf[2 * e + 1];
-                            if (vp == vo && p < so && so < viol) viol = so;
-                        }
-                }
-            }
-        }
+    };
+    auto settle = [&](u32 viol) { // wave minimum of the violations -> certEnd
         if (wv_ballot(viol != 0xFFFFFFFFu)) {
             u32 x = viol;
             for (int sft = 32; sft >= 1; sft >>= 1) {
@@ -836,23 +850,138 @@ SQ_DEVFN void cert_compute(MatchState& ms) {
             x = wv_uni(x);
             if (x < certEnd) certEnd = x;
         }
+    };
+    auto stageC = [&]() {
+        if (!bN) return;
+        u32 viol = 0xFFFFFFFFu;
+#pragma unroll
+        for (u32 g = 0; g < 2; g++)
+            if (64 * g < bN) judge(bP[g], bV[g], bT[g], bTV[g], 64 * g + lane < bN, viol);
+        settle(viol);
+        bN = 0;
+    };
+    auto stageB = [&]() {
+#pragma unroll
+        for (u32 g = 0; g < 2; g++) {
+            bP[g] = aP[g];
+            bV[g] = aV[g];
+            bT[g] = bTV[g] = 0;
+            if (64 * g < aN) {
+                u32 const h = hash4(aV[g], hashLog);
+                bT[g] = sq_tld32(T + h);
+                bTV[g] = sq_tld32(V + h);
+            }
+        }
+        bN = aN;
+        aN = 0;
+    };
+    auto loadRound = [&](u32(&w)[16], u32 p0) {
+#pragma unroll
+        for (u32 u = 0; u < 16; u++) {
+            u32 const pz = p0 + 64 * u + lane;
+            w[u] = sq_grd32(base + (pz < lastValid ? pz : lastValid));
+        }
+    };
+    // one round on the loaded words `w` (positions pos .. pos+1023); returns false when the scan is over
+    auto round = [&](const u32(&w)[16]) -> bool {
+        u32 const stop = certEnd < pEnd ? certEnd : pEnd;
+        PROF_T0(t_s1);
+        u32 cm = 0; // bit u: position pos + 64 * u + lane is a candidate
+#pragma unroll
+        for (u32 q = 0; q < 4; q++) {
+            u32 p1[4], p2[4];
+#pragma unroll
+            for (u32 k = 0; k < 4; k++) {
+                u32 const v = w[4 * q + k];
+                p1[k] = B[(v & 0xFFFFu) >> 5];
+                p2[k] = B[v >> 21];
+            }
+#pragma unroll
+            for (u32 k = 0; k < 4; k++) {
+                u32 const v = w[4 * q + k];
+                u32 const u = 4 * q + k;
+                u32 c = (p1[k] >> (v & 31)) & (p2[k] >> ((v >> 16) & 31)) & 1u;
+                c = (pos + 64 * u + lane < stop) ? c : 0u;
+                cm |= c << u;
+            }
+        }
+        u32 cnt = 0;
+        for (;;) { // compaction: one candidate per lane and turn
+            u64 const m = wv_ballot(cm != 0);
+            if (!m) break;
+            if (cm) {
+                u32 const bpos = (u32)__builtin_ctz(cm);
+                cm &= cm - 1;
+                u32 const slot = cnt + (u32)__popcll(m & below);
+                if (slot < 1024) cand[slot] = pos + 64 * bpos + lane;
+            }
+            cnt += (u32)__popcll(m);
+        }
+        wv_fence();
+        PROF_ADD(26, t_s1);
+        PROF_T0(t_s2);
+        stageC();
+        stageB();
+        // stage A: the first 128 candidates of this round
+        aN = cnt < 128 ? cnt : 128;
+        if (aN) {
+            u32 const p0 = cand[0];
+#pragma unroll
+            for (u32 g = 0; g < 2; g++) {
+                aP[g] = (64 * g + lane < aN) ? cand[64 * g + lane] : p0;
+                aV[g] = sq_grd32(base + aP[g]);
+            }
+        }
+        if (cnt > 128) { // dense part of the schedule (block start): the rest right away, 64 at a time
+            u32 viol = 0xFFFFFFFFu;
+            u32 const lim = cnt < 1024 ? cnt : 1024;
+            for (u32 j0 = 128; j0 < lim; j0 += 64) {
+                bool const valid = j0 + lane < lim;
+                u32 const p = valid ? cand[j0 + lane] : cand[0];
+                u32 const vp = sq_grd32(base + p);
+                u32 const h = hash4(vp, hashLog);
+                judge(p, vp, sq_tld32(T + h), sq_tld32(V + h), valid, viol);
+            }
+            settle(viol);
+            // more candidates than positions can only mean a broken filter: stay conservative
+            if (cnt > 1024 && pos + 1 < certEnd) certEnd = pos + 1;
+        }
         PROF_ADD(27, t_s2);
-        idx0 += lim;
+        pos += 1024;
+        return pos < certEnd && pos < pEnd;
+    };
+
+    if (pos < certEnd && pos < pEnd) {
+        u32 wA[16], wB[16], wC[16];
+        loadRound(wA, pos);
+        loadRound(wB, pos + 1024);
+        for (;;) {
+            loadRound(wC, pos + 2048);
+            if (!round(wA)) break;
+            loadRound(wA, pos + 2048);
+            if (!round(wB)) break;
+            loadRound(wB, pos + 2048);
+            if (!round(wC)) break;
+        }
     }
+    // drain the pipeline
+    stageC();
+    stageB();
+    stageC();
     wv_fence();
 #else
     // scalar twin: same tables, same rule
     u32 ovfS[SQZ_CERT_OVF_CAP], ovfV[SQZ_CERT_OVF_CAP];
     for (u32 i = 0; i < nCert; i++) {
-        u32 const sp = ms.certSched[i];
+        u32 const sp = cert_pos(ms, i);
         u32 const v = sq_rd32(base + sp);
         u32 const h = hash4(v, hashLog);
         T[h] = ht_enc(ms, sp); // the last claimant wins
-        bloom_add(h);
+        vbloom_add(v);
         if (sq_rd32(base + sp + 1) == v && sp < certEnd) certEnd = sp;
     }
     for (u32 i = 0; i < nCert; i++) {
-        u32 const sp = ms.certSched[i];
+        u32 const sp = cert_pos(ms, i);
         u32 const v = sq_rd32(base + sp);
         u32 const h = hash4(v, hashLog);
         u32 const t = ht_dec(ms, T[h]);
@@ -871,8 +1000,8 @@ SQ_DEVFN void cert_compute(MatchState& ms) {
     u32 const pEnd = ms.chunkEndPos - 3;
     for (u32 p = SQZ_WINDOW_START; p < certEnd && p < pEnd; p++) {
         u32 const vp = sq_rd32(base + p);
+        if (!((g_lds.u.bloom[(vp & 0xFFFFu) >> 5] >> (vp & 31)) & (g_lds.u.bloom[vp >> 21] >> ((vp >> 16) & 31)) & 1u)) continue;
         u32 const h = hash4(vp, hashLog);
-        if (!bloom_test(h)) continue;
         u32 const t = ht_dec(ms, T[h]);
         if (!t) continue;
         u32 const sw = t & SQZ_HT_IDX & ~SQZ_CERT_DUP;
@@ -1522,21 +1651,22 @@ SQ_DEVFN u32 compressBlock_lazy(MatchState& ms, SeqStore& ss, u32* rep, const u8
         // nextToUpdate) and their deferred tree updates (cert_mark_deferred).
         u32 const blk = (u32)(istart - base), ipPos = (u32)(ip - base), ilimPos = (u32)(ilimit - base);
         u32 const predEnd = (ms.chunkEndPos - blk < SQZ_BLOCKSIZE_MAX) ? ms.chunkEndPos : blk + SQZ_BLOCKSIZE_MAX;
-        bool const asPredicted = ((blk - SQZ_WINDOW_START) % SQZ_BLOCKSIZE_MAX == 0) && (blk + srcSize == predEnd) &&
+        bool const asPredicted = (blk == SQZ_WINDOW_START || blk == SQZ_WINDOW_START + SQZ_BLOCKSIZE_MAX) && (blk + srcSize == predEnd) &&
                                  (offset_1 == 1) && (ss.nseq == 0);
         if (!asPredicted || ms.certEnd <= ipPos || ilimit <= ip) {
             if (!asPredicted || ms.certEnd <= ipPos) ms.certEnd = 0; // the certificate ends here
         } else {
             PROF_T0(t_bw);
-            u32 pz = ipPos, last = 0, cnt = 0;
-            while (pz < ilimPos && pz < ms.certEnd) {
-                last = pz;
-                cnt++;
-                pz += ((pz - blk) >> 8) + 1;
-            }
+            // this block's part of the schedule is a prefix of one of the two tables
+            bool const second = blk != SQZ_WINDOW_START;
+            const u32* const ent = ms.schedTab + 2 + (second ? SQZ_SCHEDTAB_N : 0u);
+            u32 const nEnt = second ? ms.nCert - ms.certCnt0 : ms.certCnt0;
+            u32 const cnt = (ms.certEnd >= ilimPos) ? nEnt : sched_count(ent, nEnt, ms.certEnd - blk);
+            u32 const last = cnt ? blk + gld32(ent + cnt - 1) : 0u;
+            u32 const pz = (cnt < nEnt) ? blk + gld32(ent + cnt) : ilimPos;
             PROF_ADD(28, t_bw);
             ms.nCertDone += cnt;
-            if (last + 1 > ms.nextToUpdate) ms.nextToUpdate = last + 1;
+            if (cnt && last + 1 > ms.nextToUpdate) ms.nextToUpdate = last + 1;
             ip = base + pz;
             failStreak = SQZ_EPOCH_AFTER_FAILS;
             if (pz < ilimPos) { // the exact code takes over at the first position that is not certified

@@ -7,15 +7,25 @@
 #include <stdio.h>
 #include <stdlib.h>
 
+static const u32* sched_tab() {
+    static u32 tab[SQZ_SCHEDTAB_WORDS];
+    static bool done = false;
+    if (!done) {
+        sqz::sched_tab_fill(tab);
+        done = true;
+    }
+    return tab;
+}
+
 extern "C" size_t sim_compress_chunk(const uint8_t* src, size_t n, uint8_t* dst, size_t cap, int poison) {
     sqz::WsLayout L = sqz::ws_layout((u32)n);
-    u8* ws = (u8*)malloc(L.total + 256);
+    u8* ws = (u8*)malloc(L.total + 256 + 1024);
     // poison the workspace: the kernel must not depend on anything it did not initialise itself
-    memset(ws, poison ? 0xA5 : 0, L.total + 256);
+    memset(ws, poison ? 0xA5 : 0, L.total + 256 + 1024);
     memset(&sqz::g_lds, poison ? 0x5A : 0, sizeof(sqz::g_lds));
     u8* wsa = (u8*)(((uintptr_t)ws + 255) & ~(uintptr_t)255);
     sqz::TableGen tg = {0, 0};
-    u32 r = sqz::compress_frame_wave(src, (u32)n, dst, (u32)cap, wsa, L, tg);
+    u32 r = sqz::compress_frame_wave(src, (u32)n, dst, (u32)cap, wsa, L, tg, sched_tab());
     if (getenv("SQ_SIM_STATS")) {
         const u32* t = (const u32*)(wsa + L.dummy) + 8;
         fprintf(stderr, "[sim] n=%zu eager=%u repairs=%u live=%u skips=%u epochs=%u specfail=%u replays=%u certified=%u\n", n, t[30],
@@ -42,7 +52,7 @@ extern "C" size_t sim_compress_persistent(const uint8_t* src, size_t n, uint8_t*
     }
     u8* wsa = (u8*)(((uintptr_t)g_ws + 255) & ~(uintptr_t)255);
     sqz::WsLayout L = sqz::ws_layout((u32)n); // per-chunk layout inside the pool slot, as compress_one does
-    return sqz::compress_frame_wave(src, (u32)n, dst, (u32)cap, wsa, L, g_tg);
+    return sqz::compress_frame_wave(src, (u32)n, dst, (u32)cap, wsa, L, g_tg, sched_tab());
 }
 extern "C" size_t sim_workspace_bytes(size_t n) { return sqz::workspace_bytes((u32)n); }
 extern "C" size_t sim_lds_bytes(void) { return sizeof(sqz::LdsState); }
