@@ -399,8 +399,10 @@ SQ_DEVFN u32 compress_frame_wave(const u8* src, u32 n, u8* dst, u32 cap, u8* ws,
     PROF_T0(t_clr);
     ms.genBits = 0;
     if (cp.strategy == STRAT_BTLAZY2) {
-        if (tg.gen == 0 || tg.gen + 2 > SQZ_HT_GEN_MAX || tg.windowLog != cp.windowLog) { // a chunk uses up to 2
+        if (tg.gen == 0 || tg.gen >= SQZ_HT_GEN_MAX || tg.windowLog != cp.windowLog) {
             wv_fill32(ms.hashTable, 0, (size_t)1 << cp.hashLog);
+            // the chain-table area hosts the no-match certificate's tagged entries (cert_compute)
+            wv_fill32(ms.chainTable, 0, (size_t)1 << cp.chainLog);
             tg.gen = 0;
             tg.windowLog = cp.windowLog;
         }
@@ -441,8 +443,8 @@ SQ_DEVFN u32 compress_frame_wave(const u8* src, u32 n, u8* dst, u32 cap, u8* ws,
     wv_mem_sync();
     if (!ms.eager && n >= 9) { // btlazy2: predict the no-match search schedule, make its buckets live
         PROF_T0(t_fs);
-        // whole-chunk no-match certificate first (it borrows the table areas under its own
-        // generation; the next generation makes its words read as empty again)
+        // whole-chunk no-match certificate first (its table lives in the chain-table area, which
+        // the finder only ever reads through heads it wrote itself)
         PROF_T0(t_pr);
         // a chunk of this strategy has at most two blocks; their schedules are table prefixes
         u32 const len0 = n < SQZ_BLOCKSIZE_MAX ? n : SQZ_BLOCKSIZE_MAX;
@@ -454,8 +456,6 @@ SQ_DEVFN u32 compress_frame_wave(const u8* src, u32 n, u8* dst, u32 cap, u8* ws,
         PROF_ADD(24, t_pr);
         if (ms.nCert > 0) {
             cert_compute(ms);
-            tg.gen++;
-            ms.genBits = tg.gen << SQZ_HT_GEN_SHIFT;
         }
         wv_zero_lds(g_lds.u.bloom, SQZ_BLOOM_WORDS);
         if (ms.certEnd <= SQZ_WINDOW_START + 1) {

@@ -697,9 +697,9 @@ SQ_DEVFN void filter_repair(MatchState& ms, u32 pos, u32 anc, bool first) {
 // the repcode test at s+1 fires.  Both are properties of the bytes, not of the tree.  So before
 // any table is built, one streaming pass decides, for the predicted no-match schedule S of the
 // whole chunk, the first scheduled position s* for which such a p (or a repcode hit) exists:
-//   build : table[hash(s)] = s for s in S (generation-tagged words in the hash-table area, the 4
-//           bytes of s in the chain-table area), Bloom filter over hash(s) in LDS; the few s that
-//           share a bucket with another s go to a small overflow list;
+//   build : table[hash(s)] = (s, its 4 bytes) for s in S (8-byte entries, position word generation-
+//           tagged, in the chain-table area), Bloom filter over the 4-byte values in LDS; the few s
+//           that share an entry with another s go to a small overflow list;
 //   scan  : every position p < certEnd is hashed and Bloom-tested (64 per instruction); the ~3 %
 //           positives gather their table entry and compare bytes; a hit at (p, s), p < s, lowers
 //           certEnd to s.
@@ -726,10 +726,11 @@ SQ_DEV void vbloom_add(u32 v) {
 #define SQZ_CERT_OVF_CAP 64u
 
 SQ_DEVFN void cert_compute(MatchState& ms) {
-    u32* const T = ms.hashTable;
-    u32* const V = ms.chainTable;
+    // certificate table: 2^eLog entries of (position | generation tag [| DUP], the 4 bytes there),
+    // 8 bytes each, in the chain-table area (which the finder only reads through valid heads)
+    u32* const E = ms.chainTable;
+    u32 const eLog = ms.cp.chainLog - 1;
     const u8* const base = ms.base;
-    u32 const hashLog = ms.cp.hashLog;
     u32 const nCert = ms.nCert;
     u32 certEnd = ms.chunkEndPos;
     u32 nOvf = 0;
@@ -740,9 +741,9 @@ SQ_DEVFN void cert_compute(MatchState& ms) {
     SQ_L u32* const ovf = (SQ_L u32*)&g_lds.ent[ms.nxEnt & 1];
     u32 vmin = 0xFFFFFFFFu; // lane-local minimum of the violating scheduled positions
     PROF_T0(t_bld);
-    // ---- build, pass A: every s claims its bucket (one of several claimants wins), repcode test.
+    // ---- build, pass A: every s claims its entry (one of several claimants wins), repcode test.
     // 256 scheduled positions per step, all loads unconditional (indices clamped) so that the
-    // dependent loads (table entry -> bytes) of the four groups overlap; only the effects are masked.
+    // dependent loads (schedule table -> bytes) of the four groups overlap; only the effects are masked.
     u32 const iLast = nCert - 1;
     for (u32 i0 = 0; i0 < nCert; i0 += 256) {
         u32 sp[4], v[4], v1[4];
@@ -759,15 +760,14 @@ SQ_DEVFN void cert_compute(MatchState& ms) {
 #pragma unroll
         for (u32 g = 0; g < 4; g++) {
             if (i0 + 64 * g + lane < nCert) {
-                u32 const h = hash4(v[g], hashLog);
-                sq_gst32(T + h, ht_enc(ms, sp[g]));
+                sq_gst64v(E + 2 * hash4(v[g], eLog), ht_enc(ms, sp[g]), v[g]);
                 vbloom_add(v[g]);
                 if (v1[g] == v[g] && sp[g] < vmin) vmin = sp[g]; // offset_1 == 1 repcode at s+1
             }
         }
     }
     wv_mem_sync();
-    // ---- build, pass B: the winner of a bucket deposits its 4 bytes, the others go to the overflow list
+    // ---- build, pass B: those that did not win their entry go to the overflow list
     for (u32 i0 = 0; i0 < nCert; i0 += 256) {
         u32 sp[4], v[4], t[4];
 #pragma unroll
@@ -778,15 +778,13 @@ SQ_DEVFN void cert_compute(MatchState& ms) {
 #pragma unroll
         for (u32 g = 0; g < 4; g++) v[g] = sq_grd32(base + sp[g]);
 #pragma unroll
-        for (u32 g = 0; g < 4; g++) t[g] = sq_tld32(T + hash4(v[g], hashLog));
+        for (u32 g = 0; g < 4; g++) t[g] = sq_tld32(E + 2 * hash4(v[g], eLog));
 #pragma unroll
         for (u32 g = 0; g < 4; g++) {
             bool const valid = i0 + 64 * g + lane < nCert;
             u32 const td = ht_dec(ms, t[g]);
             bool const loser = valid && (td & SQZ_HT_IDX) != sp[g];
-            u32 const h = hash4(v[g], hashLog);
-            if (valid && !loser) sq_gst32(V + h, v[g]);
-            if (loser) sq_gst32(T + h, ht_enc(ms, td | SQZ_CERT_DUP));
+            if (loser) sq_gst32(E + 2 * hash4(v[g], eLog), ht_enc(ms, td | SQZ_CERT_DUP));
             u64 const m = wv_ballot(loser);
             if (m) {
                 if (loser) {
@@ -814,28 +812,36 @@ SQ_DEVFN void cert_compute(MatchState& ms) {
     }
     PROF_ADD(25, t_bld);
     // ---- scan: positions [2, min(certEnd, last position with 4 readable bytes]), as one software
-    // pipeline over rounds of 1024 positions.  The kernel is latency-bound (2 waves per SIMD), so
-    // every memory access of the scan is issued at least one round before its result is used:
-    //   round k+2 : its 16 coalesced loads are issued
-    //   round k   : Bloom tests -> candidate positions (LDS); their bytes are re-loaded   (stage A)
-    //   round k-1 : candidates hashed, table word + winner's bytes loaded                 (stage B)
-    //   round k-2 : candidates judged                                                     (stage C)
+    // pipeline over rounds of 1024 bytes.  The kernel is latency-bound (2 waves per SIMD), so every
+    // memory access of the scan is issued at least one round before its result is used:
+    //   round k+2 : its load is issued: ONE 16-byte aligned load per lane = 1024 contiguous bytes
+    //   round k   : lane l owns the 16 positions of its 16 bytes (+3 from lane l+1): Bloom tests
+    //               -> candidate positions (LDS); their bytes are re-loaded                 (stage A)
+    //   round k-1 : candidates hashed, their table entry loaded (8 bytes)                   (stage B)
+    //   round k-2 : candidates judged                                                       (stage C)
     u32 const pEnd = ms.chunkEndPos - 3; // one past the last p with p + 4 <= chunkEnd
-    u32 const lastValid = pEnd - 1;
     SQ_L u32* const cand = (SQ_L u32*)&g_lds.ent[ms.nxEnt & 1] + 2 * SQZ_CERT_OVF_CAP; // 1024 positions
     const SQ_L u32* const B = (const SQ_L u32*)g_lds.u.bloom;
-    u32 aP[2] = {0, 0}, aV[2] = {0, 0}, aN = 0;                                 // stage A registers
-    u32 bP[2] = {0, 0}, bV[2] = {0, 0}, bT[2] = {0, 0}, bTV[2] = {0, 0}, bN = 0; // stage B registers
-    u32 pos = SQZ_WINDOW_START;
+    // the stream starts at the 16-byte boundary at or below the first source byte (same page, so
+    // readable) and never reads beyond the 16-byte block that holds the chunk's last byte
+    const u8* const src0 = base + SQZ_WINDOW_START;
+    const u8* const a0 = src0 - ((size_t)src0 & 15);
+    s32 const p0 = (s32)SQZ_WINDOW_START - (s32)(src0 - a0); // position of a0 (may be negative)
+    const u8* const lastByte = base + ms.chunkEndPos - 1;
+    const u8* const aLast = lastByte - ((size_t)lastByte & 15);
+    u32 aP[2] = {0, 0}, aV[2] = {0, 0}, aN = 0;             // stage A registers
+    u32 bP[2] = {0, 0}, bV[2] = {0, 0}, bN = 0;             // stage B registers
+    sq_v2u bE[2] = {{0, 0}, {0, 0}};
+    s32 pos = p0; // position of the current round's first byte
 
-    auto judge = [&](u32 p, u32 vp, u32 traw, u32 tv, bool valid, u32& viol) {
-        u32 const t = ht_dec(ms, traw);
+    auto judge = [&](u32 p, u32 vp, sq_v2u e, bool valid, u32& viol) {
+        u32 const t = ht_dec(ms, e.x);
         if (valid && t) {
             u32 const sw = t & SQZ_HT_IDX;
-            if (p < sw && vp == tv && sw < viol) viol = sw;
+            if (p < sw && vp == e.y && sw < viol) viol = sw;
             if (t & SQZ_CERT_DUP)
-                for (u32 e = 0; e < nOvf; e++) {
-                    u32 const so = ovf[2 * e], vo = ovf[2 * e + 1];
+                for (u32 k = 0; k < nOvf; k++) {
+                    u32 const so = ovf[2 * k], vo = ovf[2 * k + 1];
                     if (vp == vo && p < so && so < viol) viol = so;
                 }
         }
@@ -851,12 +857,16 @@ SQ_DEVFN void cert_compute(MatchState& ms) {
             if (x < certEnd) certEnd = x;
         }
     };
+    auto loadEntry = [&](u32 vp) -> sq_v2u {
+        u64 const raw = __hip_atomic_load((const SQ_G u64*)(E + 2 * hash4(vp, eLog)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return (sq_v2u){(u32)raw, (u32)(raw >> 32)};
+    };
     auto stageC = [&]() {
         if (!bN) return;
         u32 viol = 0xFFFFFFFFu;
 #pragma unroll
         for (u32 g = 0; g < 2; g++)
-            if (64 * g < bN) judge(bP[g], bV[g], bT[g], bTV[g], 64 * g + lane < bN, viol);
+            if (64 * g < bN) judge(bP[g], bV[g], bE[g], 64 * g + lane < bN, viol);
         settle(viol);
         bN = 0;
     };
@@ -865,46 +875,53 @@ SQ_DEVFN void cert_compute(MatchState& ms) {
         for (u32 g = 0; g < 2; g++) {
             bP[g] = aP[g];
             bV[g] = aV[g];
-            bT[g] = bTV[g] = 0;
-            if (64 * g < aN) {
-                u32 const h = hash4(aV[g], hashLog);
-                bT[g] = sq_tld32(T + h);
-                bTV[g] = sq_tld32(V + h);
-            }
+            bE[g] = (sq_v2u){0, 0};
+            if (64 * g < aN) bE[g] = loadEntry(aV[g]);
         }
         bN = aN;
         aN = 0;
     };
-    auto loadRound = [&](u32(&w)[16], u32 p0) {
-#pragma unroll
-        for (u32 u = 0; u < 16; u++) {
-            u32 const pz = p0 + 64 * u + lane;
-            w[u] = sq_grd32(base + (pz < lastValid ? pz : lastValid));
-        }
+    auto loadRound = [&](s32 rp) -> sq_v4u { // bytes of the round that starts at position rp
+        const u8* ad = a0 + (size_t)(u32)(rp - p0) + 16 * lane;
+        return sq_grd128(ad < aLast ? ad : aLast);
     };
-    // one round on the loaded words `w` (positions pos .. pos+1023); returns false when the scan is over
-    auto round = [&](const u32(&w)[16]) -> bool {
+    // one round on the loaded bytes `w` (`wn` = the next round's, for lane 63's last 3 positions);
+    // returns false when the scan is over
+    auto round = [&](sq_v4u w, sq_v4u wn) -> bool {
         u32 const stop = certEnd < pEnd ? certEnd : pEnd;
         PROF_T0(t_s1);
-        u32 cm = 0; // bit u: position pos + 64 * u + lane is a candidate
+        u32 d[5] = {w.x, w.y, w.z, w.w, 0};
+        {
+            u32 const nx = (u32)__builtin_amdgcn_update_dpp(0, (int)w.x, 0x130 /* wave_shl:1 */, 0xF, 0xF, false);
+            u32 const n63 = wv_uni(wn.x);
+            d[4] = (lane == 63) ? n63 : nx;
+        }
+        // valid positions of this lane: bit j <-> position lo + j in [2, stop)
+        s32 const lo = pos + (s32)(16 * lane);
+        s32 f = (s32)SQZ_WINDOW_START - lo, l = (s32)stop - lo;
+        f = f < 0 ? 0 : (f > 16 ? 16 : f);
+        l = l < 0 ? 0 : (l > 16 ? 16 : l);
+        u32 const okMask = ((1u << l) - 1u) & ~((1u << f) - 1u);
+        u32 cm = 0; // bit j: position lo + j is a candidate
 #pragma unroll
         for (u32 q = 0; q < 4; q++) {
-            u32 p1[4], p2[4];
+            u32 v[4], p1[4], p2[4];
+            v[0] = d[q];
+            v[1] = __builtin_amdgcn_alignbyte(d[q + 1], d[q], 1);
+            v[2] = __builtin_amdgcn_alignbyte(d[q + 1], d[q], 2);
+            v[3] = __builtin_amdgcn_alignbyte(d[q + 1], d[q], 3);
 #pragma unroll
             for (u32 k = 0; k < 4; k++) {
-                u32 const v = w[4 * q + k];
-                p1[k] = B[(v & 0xFFFFu) >> 5];
-                p2[k] = B[v >> 21];
+                p1[k] = B[(v[k] & 0xFFFFu) >> 5];
+                p2[k] = B[v[k] >> 21];
             }
 #pragma unroll
             for (u32 k = 0; k < 4; k++) {
-                u32 const v = w[4 * q + k];
-                u32 const u = 4 * q + k;
-                u32 c = (p1[k] >> (v & 31)) & (p2[k] >> ((v >> 16) & 31)) & 1u;
-                c = (pos + 64 * u + lane < stop) ? c : 0u;
-                cm |= c << u;
+                u32 const c = (p1[k] >> (v[k] & 31)) & (p2[k] >> ((v[k] >> 16) & 31)) & 1u;
+                cm |= c << (4 * q + k);
             }
         }
+        cm &= okMask;
         u32 cnt = 0;
         for (;;) { // compaction: one candidate per lane and turn
             u64 const m = wv_ballot(cm != 0);
@@ -913,7 +930,7 @@ SQ_DEVFN void cert_compute(MatchState& ms) {
                 u32 const bpos = (u32)__builtin_ctz(cm);
                 cm &= cm - 1;
                 u32 const slot = cnt + (u32)__popcll(m & below);
-                if (slot < 1024) cand[slot] = pos + 64 * bpos + lane;
+                if (slot < 1024) cand[slot] = (u32)(lo + (s32)bpos);
             }
             cnt += (u32)__popcll(m);
         }
@@ -925,10 +942,10 @@ SQ_DEVFN void cert_compute(MatchState& ms) {
         // stage A: the first 128 candidates of this round
         aN = cnt < 128 ? cnt : 128;
         if (aN) {
-            u32 const p0 = cand[0];
+            u32 const c0 = cand[0];
 #pragma unroll
             for (u32 g = 0; g < 2; g++) {
-                aP[g] = (64 * g + lane < aN) ? cand[64 * g + lane] : p0;
+                aP[g] = (64 * g + lane < aN) ? cand[64 * g + lane] : c0;
                 aV[g] = sq_grd32(base + aP[g]);
             }
         }
@@ -939,29 +956,24 @@ SQ_DEVFN void cert_compute(MatchState& ms) {
                 bool const valid = j0 + lane < lim;
                 u32 const p = valid ? cand[j0 + lane] : cand[0];
                 u32 const vp = sq_grd32(base + p);
-                u32 const h = hash4(vp, hashLog);
-                judge(p, vp, sq_tld32(T + h), sq_tld32(V + h), valid, viol);
+                judge(p, vp, loadEntry(vp), valid, viol);
             }
             settle(viol);
-            // more candidates than positions can only mean a broken filter: stay conservative
-            if (cnt > 1024 && pos + 1 < certEnd) certEnd = pos + 1;
         }
         PROF_ADD(27, t_s2);
         pos += 1024;
-        return pos < certEnd && pos < pEnd;
+        return pos < (s32)certEnd && pos < (s32)pEnd;
     };
 
-    if (pos < certEnd && pos < pEnd) {
-        u32 wA[16], wB[16], wC[16];
-        loadRound(wA, pos);
-        loadRound(wB, pos + 1024);
+    if (pos < (s32)certEnd && pos < (s32)pEnd) {
+        sq_v4u wA = loadRound(pos), wB = loadRound(pos + 1024), wC;
         for (;;) {
-            loadRound(wC, pos + 2048);
-            if (!round(wA)) break;
-            loadRound(wA, pos + 2048);
-            if (!round(wB)) break;
-            loadRound(wB, pos + 2048);
-            if (!round(wC)) break;
+            wC = loadRound(pos + 2048);
+            if (!round(wA, wB)) break;
+            wA = loadRound(pos + 2048);
+            if (!round(wB, wC)) break;
+            wB = loadRound(pos + 2048);
+            if (!round(wC, wA)) break;
         }
     }
     // drain the pipeline
@@ -970,25 +982,24 @@ SQ_DEVFN void cert_compute(MatchState& ms) {
     stageC();
     wv_fence();
 #else
-    // scalar twin: same tables, same rule
+    // scalar twin: same table, same rule
     u32 ovfS[SQZ_CERT_OVF_CAP], ovfV[SQZ_CERT_OVF_CAP];
     for (u32 i = 0; i < nCert; i++) {
         u32 const sp = cert_pos(ms, i);
         u32 const v = sq_rd32(base + sp);
-        u32 const h = hash4(v, hashLog);
-        T[h] = ht_enc(ms, sp); // the last claimant wins
+        u32 const h = hash4(v, eLog);
+        E[2 * h] = ht_enc(ms, sp); // the last claimant wins
+        E[2 * h + 1] = v;
         vbloom_add(v);
         if (sq_rd32(base + sp + 1) == v && sp < certEnd) certEnd = sp;
     }
     for (u32 i = 0; i < nCert; i++) {
         u32 const sp = cert_pos(ms, i);
         u32 const v = sq_rd32(base + sp);
-        u32 const h = hash4(v, hashLog);
-        u32 const t = ht_dec(ms, T[h]);
-        if ((t & SQZ_HT_IDX) == sp)
-            V[h] = v;
-        else {
-            T[h] = ht_enc(ms, t | SQZ_CERT_DUP);
+        u32 const h = hash4(v, eLog);
+        u32 const t = ht_dec(ms, E[2 * h]);
+        if ((t & SQZ_HT_IDX) != sp) {
+            E[2 * h] = ht_enc(ms, t | SQZ_CERT_DUP);
             if (nOvf < SQZ_CERT_OVF_CAP) {
                 ovfS[nOvf] = sp;
                 ovfV[nOvf] = v;
@@ -1001,14 +1012,14 @@ SQ_DEVFN void cert_compute(MatchState& ms) {
     for (u32 p = SQZ_WINDOW_START; p < certEnd && p < pEnd; p++) {
         u32 const vp = sq_rd32(base + p);
         if (!((g_lds.u.bloom[(vp & 0xFFFFu) >> 5] >> (vp & 31)) & (g_lds.u.bloom[vp >> 21] >> ((vp >> 16) & 31)) & 1u)) continue;
-        u32 const h = hash4(vp, hashLog);
-        u32 const t = ht_dec(ms, T[h]);
+        u32 const h = hash4(vp, eLog);
+        u32 const t = ht_dec(ms, E[2 * h]);
         if (!t) continue;
-        u32 const sw = t & SQZ_HT_IDX & ~SQZ_CERT_DUP;
-        if (p < sw && vp == V[h] && sw < certEnd) certEnd = sw;
+        u32 const sw = t & SQZ_HT_IDX;
+        if (p < sw && vp == E[2 * h + 1] && sw < certEnd) certEnd = sw;
         if (t & SQZ_CERT_DUP)
-            for (u32 e = 0; e < nOvf; e++)
-                if (vp == ovfV[e] && p < ovfS[e] && ovfS[e] < certEnd) certEnd = ovfS[e];
+            for (u32 k = 0; k < nOvf; k++)
+                if (vp == ovfV[k] && p < ovfS[k] && ovfS[k] < certEnd) certEnd = ovfS[k];
     }
 #endif
     ms.certEnd = certEnd;

@@ -75,8 +75,7 @@ def test_sim_persistent_wave_table_generations(sim, oracle):
         r = sim.sim_compress_persistent(d, n, dst, cap)
         assert dst.raw[:r] == oracle.compress_chunk(d), (kind, seed, n)
         gens.append(sim.sim_persistent_gen())
-    # two generations per btlazy2 chunk: the no-match certificate's table words, then the finder's
-    assert gens == [2, 4, 6, 8, 2, 4, 0, 2, 4, 0, 2, 4, 6, 8]
+    assert gens == [1, 2, 3, 4, 1, 2, 0, 1, 2, 0, 1, 2, 3, 4]
     sim.sim_persistent_reset()
 
 
