@@ -235,14 +235,13 @@ SQ_DEV void wv_memcpy(u8* dst, const u8* src, u32 n) {
 #if SQ_ON_DEVICE
     const u32 lane = wv_lane();
     u32 pos = lane * 16;
-    // 4 KiB per iteration: four independent 16 B/lane loads in flight before the stores
-    for (; pos + 3 * 1024 + 16 <= n; pos += 4096) {
-        sq_v4u v0 = sq_grd128(src + pos), v1 = sq_grd128(src + pos + 1024), v2 = sq_grd128(src + pos + 2048),
-               v3 = sq_grd128(src + pos + 3072);
-        sq_gwr128(dst + pos, v0);
-        sq_gwr128(dst + pos + 1024, v1);
-        sq_gwr128(dst + pos + 2048, v2);
-        sq_gwr128(dst + pos + 3072, v3);
+    // 8 KiB per iteration: eight independent 16 B/lane loads in flight before the stores
+    for (; pos + 7 * 1024 + 16 <= n; pos += 8192) {
+        sq_v4u v[8];
+#pragma unroll
+        for (u32 k = 0; k < 8; k++) v[k] = sq_grd128(src + pos + 1024 * k);
+#pragma unroll
+        for (u32 k = 0; k < 8; k++) sq_gwr128(dst + pos + 1024 * k, v[k]);
     }
     for (; pos + 16 <= n; pos += 1024) sq_gwr128(dst + pos, sq_grd128(src + pos));
     if (pos < n)
@@ -259,7 +258,22 @@ SQ_DEV u32 wv_is_rle(const u8* src, u32 n) {
     const u64 pat = 0x0101010101010101ull * b0;
     bool bad = false;
     u32 pos = wv_lane() * 8;
-    for (; pos + 8 <= n; pos += 512) bad |= (sq_grd64(src + pos) != pat);
+    // like ZSTD_isRLE, give up at the first difference: look at the first 512 bytes alone, then
+    // 2 KiB per step
+    if (pos + 8 <= n) {
+        bad = sq_grd64(src + pos) != pat;
+        pos += 512;
+    }
+    if (wv_ballot(bad)) return 0;
+    while (wv_ballot(pos + 8 <= n)) {
+#pragma unroll
+        for (u32 k = 0; k < 4; k++)
+            if (pos + 8 <= n) {
+                bad |= (sq_grd64(src + pos) != pat);
+                pos += 512;
+            }
+        if (wv_ballot(bad)) return 0;
+    }
     if (pos < n)
         for (u32 k = pos; k < n; k++) bad |= (sq_grd8(src + k) != b0);
     return wv_ballot(bad) == 0;
@@ -286,25 +300,29 @@ SQ_DEV void wv_hist_bytes(u32* count /*LDS*/, const u8* src, u32 n) {
     const u32 lane = wv_lane();
     SQ_L u32* const lc = (SQ_L u32*)count;
     u32 pos = lane * 16;
-    // 16 B per lane per load, two loads in flight
-    for (; pos + 1024 + 16 <= n; pos += 2048) {
+    // 16 B per lane per load; the next two loads are issued before the current two are counted
+    auto count16 = [&](sq_v4u q) {
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            u32 w = q[k];
+            __hip_atomic_fetch_add(&lc[w & 0xFF], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            __hip_atomic_fetch_add(&lc[(w >> 8) & 0xFF], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            __hip_atomic_fetch_add(&lc[(w >> 16) & 0xFF], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            __hip_atomic_fetch_add(&lc[w >> 24], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+    };
+    if (pos + 1024 + 16 <= n) {
         sq_v4u a = sq_grd128(src + pos), b = sq_grd128(src + pos + 1024);
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-            u32 w = a[k];
-            __hip_atomic_fetch_add(&lc[w & 0xFF], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            __hip_atomic_fetch_add(&lc[(w >> 8) & 0xFF], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            __hip_atomic_fetch_add(&lc[(w >> 16) & 0xFF], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            __hip_atomic_fetch_add(&lc[w >> 24], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        pos += 2048;
+        for (; pos + 1024 + 16 <= n; pos += 2048) {
+            sq_v4u const na = sq_grd128(src + pos), nb = sq_grd128(src + pos + 1024);
+            count16(a);
+            count16(b);
+            a = na;
+            b = nb;
         }
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-            u32 w = b[k];
-            __hip_atomic_fetch_add(&lc[w & 0xFF], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            __hip_atomic_fetch_add(&lc[(w >> 8) & 0xFF], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            __hip_atomic_fetch_add(&lc[(w >> 16) & 0xFF], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            __hip_atomic_fetch_add(&lc[w >> 24], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        }
+        count16(a);
+        count16(b);
     }
     for (; pos + 16 <= n; pos += 1024) {
         sq_v4u a = sq_grd128(src + pos);

@@ -897,9 +897,12 @@ SQ_DEV u32 lit_header_basic(u8* dst, u32 n, u32 type /*0 raw, 1 rle*/) {
     }
     return flSize;
 }
-SQ_DEVFN u32 noCompressLiterals(u8* dst, u32 cap, const u8* src, u32 n) {
+// `discard`: the caller already knows that a raw literals section makes the block a raw block (a
+// block without sequences: section + 1 > block size), so only the size matters, not the bytes.
+SQ_DEVFN u32 noCompressLiterals(u8* dst, u32 cap, const u8* src, u32 n, u32 discard) {
     u32 const flSize = 1 + (n > 31) + (n > 4095);
     if (n + flSize > cap) return SQZ_ERR;
+    if (discard) return n + flSize;
     lit_header_basic(dst, n, 0);
     wv_memcpy(dst + flSize, src, n);
     return n + flSize;
@@ -908,7 +911,7 @@ SQ_DEVFN u32 noCompressLiterals(u8* dst, u32 cap, const u8* src, u32 n) {
 // ZSTD_compressLiterals + HUF_compress_internal.  Wave-level function.
 // prev/next: entropy tables in LDS.  Returns section size or SQZ_ERR.
 SQ_DEVFN u32 compressLiterals(u8* dst, u32 dstCap, const u8* src, u32 srcSize, const Entropy* prev,
-                              Entropy* next, u32 strategy, u32 suspectUncompressible) {
+                              Entropy* next, u32 strategy, u32 suspectUncompressible, u32 discardRaw) {
     u32 const lhSize = 3 + (srcSize >= 1024) + (srcSize >= 16384);
     u32 const singleStream = srcSize < 256;
     // nextHuf = prevHuf (table + repeat mode)
@@ -920,7 +923,7 @@ SQ_DEVFN u32 compressLiterals(u8* dst, u32 dstCap, const u8* src, u32 srcSize, c
     {
         int const shift = (9 - (int)strategy) < 3 ? (9 - (int)strategy) : 3;
         u32 const mintc = (prev->huf_repeat == REP_VALID) ? 6u : (8u << shift);
-        if (srcSize < mintc) return noCompressLiterals(dst, dstCap, src, srcSize);
+        if (srcSize < mintc) return noCompressLiterals(dst, dstCap, src, srcSize, discardRaw);
     }
     if (dstCap < lhSize + 1) return SQZ_ERR;
 
@@ -1054,7 +1057,7 @@ SQ_DEVFN u32 compressLiterals(u8* dst, u32 dstCap, const u8* src, u32 srcSize, c
     }
     wv_mem_sync();
     u32 const mode = g_lds.ret[0], cLitSize = g_lds.ret[1];
-    if (mode == 0) return noCompressLiterals(dst, dstCap, src, srcSize);
+    if (mode == 0) return noCompressLiterals(dst, dstCap, src, srcSize, discardRaw);
     if (mode == 1) { // ZSTD_compressRleLiteralsBlock
         u32 const fl = lit_header_basic(dst, srcSize, 1);
         WV_SERIAL { dst[fl] = src[0]; }
@@ -1273,7 +1276,10 @@ SQ_DEVFN u32 entropy_compress_seqstore(const SeqStore& ss, const Entropy* prev, 
     {
         u32 const litSize = ss.nlits;
         u32 const suspect = (nbSeq == 0) || (litSize / nbSeq >= 20);
-        litSectionSize = compressLiterals(dst, dstCap, ss.lits, litSize, prev, next, strategy, suspect);
+        // without sequences the literals are the whole block: stored raw they cannot beat a raw block
+        // (section = litSize + 3, + 1 for the sequence count > blockSize - minGain), so skip the copy
+        u32 const discardRaw = (nbSeq == 0) && (litSize == blockSize) && (litSize > 4095);
+        litSectionSize = compressLiterals(dst, dstCap, ss.lits, litSize, prev, next, strategy, suspect, discardRaw);
         if (is_err(litSectionSize)) return (blockSize <= dstCap) ? 0 : SQZ_ERR;
     }
     SQ_TRACE(0, 81);

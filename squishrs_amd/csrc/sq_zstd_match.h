@@ -814,7 +814,7 @@ SQ_DEVFN void cert_compute(MatchState& ms) {
     // ---- scan: positions [2, min(certEnd, last position with 4 readable bytes]), as one software
     // pipeline over rounds of 1024 bytes.  The kernel is latency-bound (2 waves per SIMD), so every
     // memory access of the scan is issued at least one round before its result is used:
-    //   round k+2 : its load is issued: ONE 16-byte aligned load per lane = 1024 contiguous bytes
+    //   round k+4 : its load is issued: ONE 16-byte aligned load per lane = 1024 contiguous bytes
     //   round k   : lane l owns the 16 positions of its 16 bytes (+3 from lane l+1): Bloom tests
     //               -> candidate positions (LDS); their bytes are re-loaded                 (stage A)
     //   round k-1 : candidates hashed, their table entry loaded (8 bytes)                   (stage B)
@@ -965,15 +965,19 @@ SQ_DEVFN void cert_compute(MatchState& ms) {
         return pos < (s32)certEnd && pos < (s32)pEnd;
     };
 
-    if (pos < (s32)certEnd && pos < (s32)pEnd) {
-        sq_v4u wA = loadRound(pos), wB = loadRound(pos + 1024), wC;
+    if (pos < (s32)certEnd && pos < (s32)pEnd) { // 5 KiB of the stream in flight per wave
+        sq_v4u wA = loadRound(pos), wB = loadRound(pos + 1024), wC = loadRound(pos + 2048), wD = loadRound(pos + 3072), wE;
         for (;;) {
-            wC = loadRound(pos + 2048);
+            wE = loadRound(pos + 4096);
             if (!round(wA, wB)) break;
-            wA = loadRound(pos + 2048);
+            wA = loadRound(pos + 4096);
             if (!round(wB, wC)) break;
-            wB = loadRound(pos + 2048);
-            if (!round(wC, wA)) break;
+            wB = loadRound(pos + 4096);
+            if (!round(wC, wD)) break;
+            wC = loadRound(pos + 4096);
+            if (!round(wD, wE)) break;
+            wD = loadRound(pos + 4096);
+            if (!round(wE, wA)) break;
         }
     }
     // drain the pipeline
