@@ -2,7 +2,9 @@
 """bench.py -- pack-path throughput on MI355X (BASELINE.json metric).
 
 A "step" is one pass of the hot path (XXH3-128 hash -> [all-gather of hashes] -> dedup ->
-zstd-12 compress -> frame compaction) over one batch that is already resident in HBM.
+zstd-12 compress) over one batch that is already resident in HBM.  Output layout "slots" (default):
+every frame stays in the slot it was produced in (offset + length per chunk), as the reference hands
+its writer one buffer per chunk; "packed" adds the pass that moves the frames back to back.
 Workload at N=1: BASELINE.json configs[1], "100k x 256 KiB unique random chunks" (per GPU; for
 N>1 every rank holds its own 100k globally-unique chunks => weak scaling, and the hash all-gather
 over RCCL is inside the timed region).
@@ -23,6 +25,20 @@ sys.path.insert(0, os.path.join(ROOT, "tools"))
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 
+def _pmc_traffic(n, L):
+    """HBM traffic of one k_compress_batch launch (bytes), from the committed rocprofv3 PMC passes
+    (FETCH_SIZE and WRITE_SIZE collected in separate runs of this same script, see
+    tools/profile_r1.sh and profiles/): counters cannot be read from inside the process.  None when
+    no committed measurement matches this workload."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
+            t = json.load(f)
+        e = t.get(f"{n}x{L}")
+        return None if e is None else float(e["fetch_bytes"] + e["write_bytes"])
+    except (OSError, ValueError, KeyError):
+        return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -33,6 +49,7 @@ def main():
     ap.add_argument("--waves", type=int, default=0, help="persistent compressor waves (0 = auto)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--layout", choices=("slots", "packed"), default="slots")
     a = ap.parse_args()
 
     import torch
@@ -65,13 +82,14 @@ def main():
     hashes = torch.zeros(n * 16, dtype=torch.uint8, device="cuda")
     is_new = torch.zeros(n, dtype=torch.uint8, device="cuda")
     bound = squishrs_amd.compress_bound(L)
-    comp = torch.empty(n * (bound + 16), dtype=torch.uint8, device="cuda")
+    slots = a.layout == "slots"
+    comp = torch.empty(store.slots_bound(lens) if slots else n * (bound + 16), dtype=torch.uint8, device="cuda")
     torch.cuda.synchronize()
     gen_s = time.time() - t0
 
     def step():
         store.reset()
-        return packer.pack(data, offs, lens, hashes, is_new, comp)
+        return packer.pack(data, offs, lens, hashes, is_new, comp, layout=a.layout)
 
     def barrier():
         if world > 1:
@@ -100,7 +118,13 @@ def main():
 
     # ---- outside the timed region: parity sample against the CPU oracle, roofline, CPU baseline
     unique = store.len()
-    clen_total = int(comp_off[-1])
+    if slots:
+        comp_off, comp_len = comp_off
+        frame_end = comp_off + comp_len.astype(np.uint64)
+        clen_total = int(comp_len.astype(np.uint64).sum())
+    else:
+        frame_end = comp_off[1:]
+        clen_total = int(comp_off[-1])
     out = None
     if rank == 0:
         import corpus
@@ -113,7 +137,7 @@ def main():
         for i in sorted(set([0, 1, n // 2, n - 1])):
             c = corpus.random_bytes(1, rank * n + i, L)
             ok &= hh[i].tobytes() == o.hash_chunk(c)
-            fr = cc[int(comp_off[i]):int(comp_off[i + 1])].cpu().numpy().tobytes()
+            fr = cc[int(comp_off[i]):int(frame_end[i])].cpu().numpy().tobytes()
             ok &= bool(nn[i]) and fr == o.compress_chunk(c)
         assert ok, "bench sample is not bit-exact vs the oracle"
 
@@ -127,7 +151,7 @@ def main():
         bw_probe_ms = min(store.read_bw_ms(data) for _ in range(3))
         roof = {"bound": "hbm", "kernel": "sqz::k_compress_batch",
                 "achieved": comp_bytes / (cms / 1e3) / 1e9, "peak": 8000.0, "unit": "GB/s",
-                "frac": comp_bytes / (cms / 1e3) / 1e9 / 8000.0, "traffic": None,
+                "frac": comp_bytes / (cms / 1e3) / 1e9 / 8000.0, "traffic": _pmc_traffic(n, L),
                 "kernel_ms": cms,
                 "hash_kernel": {"kernel": "sqx::k_xxh3_128_batch", "ms": hms,
                                 "achieved": hash_bytes / (hms / 1e3) / 1e9,
@@ -157,6 +181,7 @@ def main():
                                       f"(BASELINE configs[1]), xoshiro256** seeded, resident in HBM",
                           "chunks_per_gpu": n, "chunk_bytes": L, "unique_chunks": int(unique),
                           "compressed_bytes_rank0": clen_total, "parallelism": f"shard{world}",
+                          "output_layout": a.layout,
                           "parity_sample": "bit-exact vs oracle", "gen_seconds": gen_s},
                "roofline": roof, "cpu_baseline": cpu}
         print(json.dumps(out), flush=True)

@@ -111,6 +111,20 @@ int sq_compress_batch(sq_ctx* ctx, const uint8_t* d_data, const uint64_t* h_off,
                       const uint32_t* h_len, uint32_t n, const uint8_t* d_select, uint8_t* d_comp,
                       uint64_t comp_cap, uint64_t* h_comp_off);
 
+/* compress stage without the packing pass: every frame stays in the slot it was produced in.
+ * Frame i = d_comp[h_comp_off[i] .. h_comp_off[i] + h_comp_len[i]); h_comp_len[i] == 0 for chunks
+ * that were not selected.  Slots are disjoint, ascending and 16-byte aligned; slot i holds
+ * sq_compress_bound(h_len[i]) + 32 bytes rounded up to 16, so d_comp needs sq_slots_bound(h_len, n)
+ * bytes (SQ_E_CAP otherwise).  The reference hands each frame to its writer as a separate buffer
+ * (InsertReturn.compressed_data, src/util/chunk.rs:60-64; writer.rs:255-262), which interleaves
+ * them with 32-byte chunk-record headers, so nothing downstream needs them back to back; this saves
+ * one read and one write of every frame. */
+int sq_compress_batch_slots(sq_ctx* ctx, const uint8_t* d_data, const uint64_t* h_off,
+                            const uint32_t* h_len, uint32_t n, const uint8_t* d_select,
+                            uint8_t* d_comp, uint64_t comp_cap, uint64_t* h_comp_off,
+                            uint32_t* h_comp_len);
+uint64_t sq_slots_bound(const uint32_t* h_len, uint32_t n);
+
 /* HBM read-bandwidth calibration (a trivial 16 B/lane streaming read over d_buf): returns the
  * kernel time in ms through *ms.  bench.py reports it beside the 8 TB/s nominal peak. */
 int sq_calibrate_read_bw(sq_ctx* ctx, const uint8_t* d_buf, uint64_t nbytes, float* ms);

@@ -18,7 +18,7 @@ EXPORTS = [
     "sq_abi_version", "sq_strerror", "sq_compress_bound", "sq_ctx_create", "sq_ctx_destroy",
     "sq_ctx_set_stream", "sq_ctx_synchronize", "sq_hash_chunk", "sq_compress_chunk",
     "sq_pack_batch", "sq_unique_count", "sq_hash_batch", "sq_dedup_global", "sq_compress_batch",
-    "sq_calibrate_read_bw", "sq_last_timings", "sq_dedup_reset",
+    "sq_calibrate_read_bw", "sq_last_timings", "sq_dedup_reset", "sq_compress_batch_slots", "sq_slots_bound",
 ]
 
 
@@ -78,6 +78,9 @@ def load():
     L.sq_hash_batch.argtypes = [vp, u8p, vp, vp, ctypes.c_uint32, u8p]
     L.sq_dedup_global.argtypes = [vp, u8p, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_uint32, u8p]
     L.sq_compress_batch.argtypes = [vp, u8p, vp, vp, ctypes.c_uint32, u8p, u8p, ctypes.c_uint64, vp]
+    L.sq_compress_batch_slots.argtypes = [vp, u8p, vp, vp, ctypes.c_uint32, u8p, u8p, ctypes.c_uint64, vp, vp]
+    L.sq_slots_bound.restype = ctypes.c_uint64
+    L.sq_slots_bound.argtypes = [vp, ctypes.c_uint32]
     L.sq_calibrate_read_bw.argtypes = [vp, u8p, ctypes.c_uint64, ctypes.POINTER(ctypes.c_float)]
     L.sq_last_timings.argtypes = [vp, ctypes.POINTER(SqTimings)]
     L.sq_dedup_reset.argtypes = [vp]

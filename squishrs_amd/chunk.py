@@ -140,6 +140,19 @@ class ChunkStore:
                                         comp.data_ptr(), comp.numel(), comp_off.ctypes.data))
         return comp_off
 
+    def compress_device_slots(self, data, offs: np.ndarray, lens: np.ndarray, select, comp):
+        """sq_compress_batch_slots: frames stay in their slots of `comp`; returns (offsets[n], lengths[n])."""
+        comp_off = np.zeros(len(lens), dtype=np.uint64)
+        comp_len = np.zeros(len(lens), dtype=np.uint32)
+        check(self._L.sq_compress_batch_slots(self._h, data.data_ptr(), offs.ctypes.data, lens.ctypes.data,
+                                              len(lens), select.data_ptr() if select is not None else None,
+                                              comp.data_ptr(), comp.numel(), comp_off.ctypes.data,
+                                              comp_len.ctypes.data))
+        return comp_off, comp_len
+
+    def slots_bound(self, lens: np.ndarray) -> int:
+        return int(self._L.sq_slots_bound(lens.ctypes.data, len(lens)))
+
     def pack_device(self, data, offs: np.ndarray, lens: np.ndarray, hashes, is_new, comp) -> np.ndarray:
         """sq_pack_batch with every buffer resident in HBM (nothing crosses PCIe but offsets)."""
         comp_off = np.zeros(len(lens) + 1, dtype=np.uint64)

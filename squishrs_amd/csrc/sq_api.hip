@@ -338,13 +338,17 @@ int sq_calibrate_read_bw(sq_ctx* c, const uint8_t* d_buf, uint64_t nbytes, float
 }
 
 #ifndef SQ_NO_COMPRESS
-// Frames are produced into per-chunk slots (bound(len) bytes, 16-byte aligned), then packed.
+// Frames are produced into per-chunk slots (bound(len) bytes, 16-byte aligned).  h_comp_len ==
+// nullptr: the slots are a scratch buffer and the frames are then packed back to back into d_comp
+// (h_comp_off: n + 1 offsets).  Otherwise the slots ARE d_comp and the frames stay where they were
+// produced (h_comp_off: n slot offsets, h_comp_len: n frame lengths): no packing pass.
 static int compress_async(sq_ctx* c, const u8* d_data, const u64* h_off, const u32* h_len, u32 n,
-                          const u8* d_select, u8* d_comp, u64 comp_cap, u64* h_comp_off) {
+                          const u8* d_select, u8* d_comp, u64 comp_cap, u64* h_comp_off, u32* h_comp_len) {
     (void)h_off;
     int r;
+    const bool in_place = h_comp_len != nullptr;
     if (n == 0) {
-        h_comp_off[0] = 0;
+        if (!in_place) h_comp_off[0] = 0;
         return SQ_OK;
     }
     // slot offsets on the host (prefix sum of bounds)
@@ -361,7 +365,11 @@ static int compress_async(sq_ctx* c, const u8* d_data, const u64* h_off, const u
     if ((r = c->b_slot_off.ensure(((size_t)n + 1) * 8))) return r;
     if ((r = c->b_frame_len.ensure((size_t)n * 4))) return r;
     if ((r = c->b_out_off.ensure(((size_t)n + 1) * 8))) return r;
-    if ((r = c->b_slots.ensure(acc))) return r;
+    if (in_place) {
+        if (acc > comp_cap) return SQ_E_CAP;
+    } else if ((r = c->b_slots.ensure(acc)))
+        return r;
+    u8* const d_slots = in_place ? d_comp : (u8*)c->b_slots.p;
     HIPCHK(hipMemcpyAsync(c->b_slot_off.p, slot_off.data(), ((size_t)n + 1) * 8, hipMemcpyHostToDevice,
                           c->stream));
     HIPCHK(hipMemsetAsync(c->b_frame_len.p, 0, (size_t)n * 4, c->stream));
@@ -388,7 +396,7 @@ static int compress_async(sq_ctx* c, const u8* d_data, const u64* h_off, const u
     {
         dim3 block(64), grid(waves);
         hipLaunchKernelGGL(sqz::k_compress_batch, grid, block, 0, c->stream, d_data, (const u64*)c->b_off.p,
-                           (const u32*)c->b_len.p, d_select, n, (u8*)c->b_slots.p,
+                           (const u32*)c->b_len.p, d_select, n, d_slots,
                            (const u64*)c->b_slot_off.p, (u32*)c->b_frame_len.p, (u8*)c->b_ws.p,
                            (u64)ws_each, (u32*)c->b_misc.p /*queue*/, (u32*)c->b_misc.p + 16 /*err*/,
                            (const u32*)c->d_sched_tab);
@@ -423,11 +431,16 @@ static int compress_async(sq_ctx* c, const u8* d_data, const u64* h_off, const u
             _exit(3);
         }
     }
-    hipLaunchKernelGGL(sqd::k_scan_lengths, dim3(1), dim3(1024), 0, c->stream, (const u32*)c->b_frame_len.p,
-                       n, (u64*)c->b_out_off.p);
-    HIPCHK(hipGetLastError());
-    HIPCHK(hipMemcpyAsync(h_comp_off, c->b_out_off.p, ((size_t)n + 1) * 8, hipMemcpyDeviceToHost,
-                          c->stream));
+    if (in_place) {
+        HIPCHK(hipMemcpyAsync(h_comp_len, c->b_frame_len.p, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));
+        for (u32 i = 0; i < n; i++) h_comp_off[i] = slot_off[i];
+    } else {
+        hipLaunchKernelGGL(sqd::k_scan_lengths, dim3(1), dim3(1024), 0, c->stream, (const u32*)c->b_frame_len.p,
+                           n, (u64*)c->b_out_off.p);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipMemcpyAsync(h_comp_off, c->b_out_off.p, ((size_t)n + 1) * 8, hipMemcpyDeviceToHost,
+                              c->stream));
+    }
     u32* h_err = (u32*)c->h_pinned;
     HIPCHK(hipMemcpyAsync(h_err, (u32*)c->b_misc.p + 16, 4, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
@@ -475,6 +488,10 @@ static int compress_async(sq_ctx* c, const u8* d_data, const u64* h_off, const u
         }
     }
     if (*h_err) return SQ_E_COMPRESS;
+    if (in_place) {
+        c->last.compact_ms = 0;
+        return SQ_OK;
+    }
     if (h_comp_off[n] > comp_cap) return SQ_E_CAP;
     HIPCHK(hipEventRecord(c->ev[6], c->stream));
     {
@@ -504,8 +521,30 @@ int sq_compress_batch(sq_ctx* c, const uint8_t* d_data, const uint64_t* h_off, c
     HIPCHK(hipSetDevice(c->device));
     int r;
     if ((r = upload_off_len(c, h_off, h_len, n))) return r;
-    return compress_async(c, d_data, h_off, h_len, n, d_select, d_comp, comp_cap, h_comp_off);
+    return compress_async(c, d_data, h_off, h_len, n, d_select, d_comp, comp_cap, h_comp_off, nullptr);
 #endif
+}
+
+int sq_compress_batch_slots(sq_ctx* c, const uint8_t* d_data, const uint64_t* h_off, const uint32_t* h_len,
+                            uint32_t n, const uint8_t* d_select, uint8_t* d_comp, uint64_t comp_cap,
+                            uint64_t* h_comp_off, uint32_t* h_comp_len) {
+#ifdef SQ_NO_COMPRESS
+    (void)c; (void)d_data; (void)h_off; (void)h_len; (void)n; (void)d_select; (void)d_comp;
+    (void)comp_cap; (void)h_comp_off; (void)h_comp_len;
+    return SQ_E_COMPRESS;
+#else
+    if (!c || (n && (!d_data || !h_off || !h_len || !d_comp || !h_comp_off || !h_comp_len))) return SQ_E_INVAL;
+    HIPCHK(hipSetDevice(c->device));
+    int r;
+    if ((r = upload_off_len(c, h_off, h_len, n))) return r;
+    return compress_async(c, d_data, h_off, h_len, n, d_select, d_comp, comp_cap, h_comp_off, h_comp_len);
+#endif
+}
+
+uint64_t sq_slots_bound(const uint32_t* h_len, uint32_t n) {
+    u64 acc = 0;
+    for (u32 i = 0; i < n; i++) acc += (sq_compress_bound(h_len[i]) + 32 + 15) & ~(u64)15;
+    return acc;
 }
 
 int sq_pack_batch(sq_ctx* c, const uint8_t* data, const uint64_t* off, const uint32_t* len, uint32_t n,
@@ -553,7 +592,7 @@ int sq_pack_batch(sq_ctx* c, const uint8_t* data, const uint64_t* off, const uin
     if ((r = launch_hash(c, d_data, n, d_hashes))) return r;
     const u64 seen_before = c->n_seen;
     if ((r = dedup_async(c, d_hashes, n, 0, n, d_isnew))) return r;
-    r = compress_async(c, d_data, use_off, len, n, d_isnew, d_comp, comp_cap, comp_off);
+    r = compress_async(c, d_data, use_off, len, n, d_isnew, d_comp, comp_cap, comp_off, nullptr);
     (void)seen_before;
     if (r) return r;
     HIPCHK(hipEventElapsedTime(&c->last.hash_ms, c->ev[0], c->ev[1]));

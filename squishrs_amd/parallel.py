@@ -53,10 +53,15 @@ class ShardedPacker:
         parts = [recv[r * n_max * 16: r * n_max * 16 + int(counts_h[r]) * 16] for r in range(self.world)]
         return torch.cat(parts), n_total, my_first
 
-    def pack(self, data, offs: np.ndarray, lens: np.ndarray, hashes, is_new, comp):
-        """hash -> all-gather -> global dedup -> compress own new chunks.  Returns comp_off."""
+    def pack(self, data, offs: np.ndarray, lens: np.ndarray, hashes, is_new, comp, layout: str = "packed"):
+        """hash -> all-gather -> global dedup -> compress own new chunks.
+        layout "packed": frames back to back in `comp`, returns comp_off[n + 1];
+        layout "slots" : frames left in their slots of `comp` (no packing pass), returns
+                         (comp_off[n], comp_len[n])."""
         n = len(lens)
         self.stages.hash_device(data, offs, lens, hashes)
         all_hashes, n_total, my_first = self.gather_hashes(hashes, n)
         self.stages.dedup_device(all_hashes, n_total, my_first, n, is_new)
+        if layout == "slots":
+            return self.stages.compress_device_slots(data, offs, lens, is_new, comp)
         return self.stages.compress_device(data, offs, lens, is_new, comp)

@@ -216,3 +216,39 @@ def test_persistent_waves_many_chunks_per_wave(oracle):
         st.close()
     for i, (c, f) in enumerate(zip(chunks, frames)):
         assert f == oracle.compress_chunk(c), (i, kinds[i % len(kinds)], len(c))
+
+
+def test_slots_layout_equals_packed(gpu_store, oracle):
+    """sq_compress_batch_slots leaves every frame in its slot: same frames as the packed layout,
+    length 0 for chunks that were not selected, slots disjoint and ascending."""
+    import torch
+    import squishrs_amd
+    chunks = [corpus.make(k, 40 + i, n) for i, (k, n) in enumerate(
+        [("random", 262144), ("text", 50000), ("planted1", 200000), ("zeros", 4096), ("mixed", 300000),
+         ("random", 262144), ("records", 17000), ("text", 11)])]
+    packed = _batch_compress(gpu_store, chunks)
+    lens = np.array([len(c) for c in chunks], dtype=np.uint32)
+    offs = np.zeros(len(chunks), dtype=np.uint64)
+    pos = 0
+    for i, c in enumerate(chunks):
+        offs[i] = pos
+        pos += (len(c) + 255) // 256 * 256
+    buf = np.zeros(pos + 256, dtype=np.uint8)
+    for i, c in enumerate(chunks):
+        buf[int(offs[i]):int(offs[i]) + len(c)] = np.frombuffer(c, dtype=np.uint8)
+    d = torch.from_numpy(buf).cuda()
+    select = torch.tensor([1, 1, 0, 1, 1, 1, 0, 1], dtype=torch.uint8, device="cuda")
+    comp = torch.zeros(gpu_store.slots_bound(lens), dtype=torch.uint8, device="cuda")
+    coff, clen = gpu_store.compress_device_slots(d, offs, lens, select, comp)
+    host = comp.cpu().numpy()
+    end = 0
+    for i, c in enumerate(chunks):
+        assert int(coff[i]) >= end and int(coff[i]) % 16 == 0
+        end = int(coff[i]) + squishrs_amd.compress_bound(len(c))
+        if int(select[i]):
+            assert host[int(coff[i]):int(coff[i]) + int(clen[i])].tobytes() == packed[i] == oracle.compress_chunk(c)
+        else:
+            assert clen[i] == 0
+    # too small an output buffer is refused, not overrun
+    with pytest.raises(squishrs_amd.SquishError):
+        gpu_store.compress_device_slots(d, offs, lens, select, comp[:1000])
