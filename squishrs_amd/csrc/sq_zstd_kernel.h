@@ -389,13 +389,14 @@ SQ_DEVFN u32 compress_frame_wave(const u8* src, u32 n, u8* dst, u32 cap, u8* ws,
     ms.blockTab = (u32*)(ws + L.blockTab);
     ms.schedTab = schedTab;
     ms.certCnt0 = 0;
-    ms.nCert = ms.nCertDone = ms.certEnd = 0;
+    ms.nCert = ms.nCertDone = ms.certEnd = ms.certEnd1 = 0;
     ms.nLive = ms.nSkip = ms.nBlocks = 0;
     ms.specOff = 0;
     ms.sbMax = 256;
     ms.nxEnt = 1;
     ms.nEpoch = ms.nSpecFail = ms.nReplay = 0;
     SQ_TRACE(0, 2);
+    SQ_TRACE(38, 0);
     PROF_T0(t_clr);
     ms.genBits = 0;
     if (cp.strategy == STRAT_BTLAZY2) {

@@ -100,7 +100,8 @@ struct MatchState {
     u32 certCnt0;    // scheduled searches in block 0 of this chunk
     u32 nCert;       // scheduled searches in the whole chunk (blocks 0 and 1)
     u32 nCertDone;   // leading ones that were skipped as certainly failing
-    u32 certEnd;     // every scheduled search at a position < certEnd certainly fails; 0 = no certificate
+    u32 certEnd;     // every scheduled search of block 0 at a position < certEnd certainly fails; 0 = none
+    u32 certEnd1;    // the same for block 1 (given that block 1 starts with repcode offset 1)
     u32 sbMax;       // current super-batch length of the filtered insertion stream (256..2048)
     u32 genBits;     // btlazy2 hash-table generation tag of this chunk, in place (bits 19..29)
     CParams cp;
@@ -732,55 +733,63 @@ SQ_DEVFN void cert_compute(MatchState& ms) {
     u32 const eLog = ms.cp.chainLog - 1;
     const u8* const base = ms.base;
     u32 const nCert = ms.nCert;
-    u32 certEnd = ms.chunkEndPos;
+    // one certificate per block: a match in block 0 changes that block's schedule, not block 1's
+    u32 const blk1 = (nCert > ms.certCnt0) ? SQZ_WINDOW_START + SQZ_BLOCKSIZE_MAX : 0xFFFFFFFFu;
+    u32 certEnd = ms.chunkEndPos, certEnd1 = ms.chunkEndPos;
     u32 nOvf = 0;
     wv_zero_lds(g_lds.u.bloom, SQZ_BLOOM_WORDS);
 #if SQ_ON_DEVICE
     u32 const lane = wv_lane();
     u64 const below = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
     SQ_L u32* const ovf = (SQ_L u32*)&g_lds.ent[ms.nxEnt & 1];
-    u32 vmin = 0xFFFFFFFFu; // lane-local minimum of the violating scheduled positions
+    u32 vmin = 0xFFFFFFFFu, vmin1 = 0xFFFFFFFFu; // lane-local minima of the violating scheduled positions
+    auto note = [&](u32 sviol, u32& v0, u32& v1) { // a search at sviol may succeed
+        if (sviol < blk1)
+            v0 = sviol < v0 ? sviol : v0;
+        else
+            v1 = sviol < v1 ? sviol : v1;
+    };
     PROF_T0(t_bld);
     // ---- build, pass A: every s claims its entry (one of several claimants wins), repcode test.
-    // 256 scheduled positions per step, all loads unconditional (indices clamped) so that the
-    // dependent loads (schedule table -> bytes) of the four groups overlap; only the effects are masked.
+    // 512 scheduled positions per step, all loads unconditional (indices clamped) so that the
+    // dependent loads (schedule table -> bytes) of the eight groups overlap; only the effects are masked.
     u32 const iLast = nCert - 1;
-    for (u32 i0 = 0; i0 < nCert; i0 += 256) {
-        u32 sp[4], v[4], v1[4];
+    for (u32 i0 = 0; i0 < nCert; i0 += 512) {
+        u32 sp[8], v[8], v1[8];
 #pragma unroll
-        for (u32 g = 0; g < 4; g++) {
+        for (u32 g = 0; g < 8; g++) {
             u32 const i = i0 + 64 * g + lane;
             sp[g] = cert_pos(ms, i < nCert ? i : iLast);
         }
 #pragma unroll
-        for (u32 g = 0; g < 4; g++) {
+        for (u32 g = 0; g < 8; g++) {
             v[g] = sq_grd32(base + sp[g]);
             v1[g] = sq_grd32(base + sp[g] + 1);
         }
 #pragma unroll
-        for (u32 g = 0; g < 4; g++) {
+        for (u32 g = 0; g < 8; g++) {
             if (i0 + 64 * g + lane < nCert) {
                 sq_gst64v(E + 2 * hash4(v[g], eLog), ht_enc(ms, sp[g]), v[g]);
                 vbloom_add(v[g]);
-                if (v1[g] == v[g] && sp[g] < vmin) vmin = sp[g]; // offset_1 == 1 repcode at s+1
+                if (v1[g] == v[g]) note(sp[g], vmin, vmin1); // offset_1 == 1 repcode at s+1
             }
         }
     }
     wv_mem_sync();
     // ---- build, pass B: those that did not win their entry go to the overflow list
-    for (u32 i0 = 0; i0 < nCert; i0 += 256) {
-        u32 sp[4], v[4], t[4];
+    for (u32 i0 = 0; i0 < nCert; i0 += 512) {
+        u32 sp[8], v[8], t[8];
 #pragma unroll
-        for (u32 g = 0; g < 4; g++) {
+        for (u32 g = 0; g < 8; g++) {
             u32 const i = i0 + 64 * g + lane;
             sp[g] = cert_pos(ms, i < nCert ? i : iLast);
         }
 #pragma unroll
-        for (u32 g = 0; g < 4; g++) v[g] = sq_grd32(base + sp[g]);
+        for (u32 g = 0; g < 8; g++) v[g] = sq_grd32(base + sp[g]);
 #pragma unroll
-        for (u32 g = 0; g < 4; g++) t[g] = sq_tld32(E + 2 * hash4(v[g], eLog));
+        for (u32 g = 0; g < 8; g++) t[g] = sq_tld32(E + 2 * hash4(v[g], eLog));
 #pragma unroll
-        for (u32 g = 0; g < 4; g++) {
+        for (u32 g = 0; g < 8; g++) {
             bool const valid = i0 + 64 * g + lane < nCert;
             u32 const td = ht_dec(ms, t[g]);
             bool const loser = valid && (td & SQZ_HT_IDX) != sp[g];
@@ -792,8 +801,8 @@ SQ_DEVFN void cert_compute(MatchState& ms) {
                     if (slot < SQZ_CERT_OVF_CAP) {
                         ovf[2 * slot] = sp[g];
                         ovf[2 * slot + 1] = v[g];
-                    } else if (sp[g] < vmin)
-                        vmin = sp[g]; // no room to remember it: the certificate ends there
+                    } else
+                        note(sp[g], vmin, vmin1); // no room to remember it: the certificate ends there
                 }
                 nOvf += (u32)__popcll(m);
             }
@@ -801,26 +810,36 @@ SQ_DEVFN void cert_compute(MatchState& ms) {
     }
     if (nOvf > SQZ_CERT_OVF_CAP) nOvf = SQZ_CERT_OVF_CAP;
     wv_mem_sync();
-    {
-        u32 x = vmin;
-        for (int sft = 32; sft >= 1; sft >>= 1) {
-            u32 const y = (u32)__shfl_xor((int)x, sft, 64);
-            x = y < x ? y : x;
+    auto settle = [&](u32 v0, u32 v1) { // wave minima of the violations -> certEnd / certEnd1
+        if (wv_ballot((v0 & v1) != 0xFFFFFFFFu)) {
+            u32 x = v0, z = v1;
+            for (int sft = 32; sft >= 1; sft >>= 1) {
+                u32 const y = (u32)__shfl_xor((int)x, sft, 64), w = (u32)__shfl_xor((int)z, sft, 64);
+                x = y < x ? y : x;
+                z = w < z ? w : z;
+            }
+            x = wv_uni(x);
+            z = wv_uni(z);
+            if (x < certEnd) certEnd = x;
+            if (z < certEnd1) certEnd1 = z;
         }
-        x = wv_uni(x);
-        if (x < certEnd) certEnd = x;
-    }
+    };
+    settle(vmin, vmin1);
     PROF_ADD(25, t_bld);
     // ---- scan: positions [2, min(certEnd, last position with 4 readable bytes]), as one software
-    // pipeline over rounds of 1024 bytes.  The kernel is latency-bound (2 waves per SIMD), so every
-    // memory access of the scan is issued at least one round before its result is used:
+    // pipeline over rounds of 1024 bytes.  The kernel is latency-bound (2 waves per SIMD) and a
+    // wave's loads complete in order, so every load of the scan is issued >= 4 rounds (about one
+    // memory latency) before its first use and every round issues the same loads in the same order
+    // (which lets hipcc emit exact s_waitcnt vmcnt(n) values instead of draining to 0):
     //   round k+4 : its load is issued: ONE 16-byte aligned load per lane = 1024 contiguous bytes
-    //   round k   : lane l owns the 16 positions of its 16 bytes (+3 from lane l+1): Bloom tests
-    //               -> candidate positions (LDS); their bytes are re-loaded                 (stage A)
-    //   round k-1 : candidates hashed, their table entry loaded (8 bytes)                   (stage B)
-    //   round k-2 : candidates judged                                                       (stage C)
+    //   round k   : lane l owns the 16 positions of its 16 bytes (+3 from lane l+1): Bloom tests;
+    //               the positives (position, 4 bytes) are compacted into an LDS list, hashed, and
+    //               their 8-byte table entries are gathered into one of 5 register slots
+    //   round k+5 : that slot is judged, then refilled
+    // The first 4 KiB of a block, where the schedule itself is dense (every position, every 2nd, ...),
+    // are done by a simple round that judges each lane's positives in place.
     u32 const pEnd = ms.chunkEndPos - 3; // one past the last p with p + 4 <= chunkEnd
-    SQ_L u32* const cand = (SQ_L u32*)&g_lds.ent[ms.nxEnt & 1] + 2 * SQZ_CERT_OVF_CAP; // 1024 positions
+    SQ_L u32* const cand = (SQ_L u32*)g_lds.grp; // 128 x (position, bytes)
     const SQ_L u32* const B = (const SQ_L u32*)g_lds.u.bloom;
     // the stream starts at the 16-byte boundary at or below the first source byte (same page, so
     // readable) and never reads beyond the 16-byte block that holds the chunk's last byte
@@ -829,80 +848,59 @@ SQ_DEVFN void cert_compute(MatchState& ms) {
     s32 const p0 = (s32)SQZ_WINDOW_START - (s32)(src0 - a0); // position of a0 (may be negative)
     const u8* const lastByte = base + ms.chunkEndPos - 1;
     const u8* const aLast = lastByte - ((size_t)lastByte & 15);
-    u32 aP[2] = {0, 0}, aV[2] = {0, 0}, aN = 0;             // stage A registers
-    u32 bP[2] = {0, 0}, bV[2] = {0, 0}, bN = 0;             // stage B registers
-    sq_v2u bE[2] = {{0, 0}, {0, 0}};
     s32 pos = p0; // position of the current round's first byte
 
-    auto judge = [&](u32 p, u32 vp, sq_v2u e, bool valid, u32& viol) {
+    struct Slot { // candidates whose table entries are in flight
+        u32 p[2], v[2];
+        sq_v2u e[2];
+        u32 n;
+    };
+    auto judge = [&](u32 p, u32 vp, sq_v2u e, bool valid, u32& v0, u32& v1) {
         u32 const t = ht_dec(ms, e.x);
         if (valid && t) {
             u32 const sw = t & SQZ_HT_IDX;
-            if (p < sw && vp == e.y && sw < viol) viol = sw;
+            if (p < sw && vp == e.y) note(sw, v0, v1);
             if (t & SQZ_CERT_DUP)
                 for (u32 k = 0; k < nOvf; k++) {
                     u32 const so = ovf[2 * k], vo = ovf[2 * k + 1];
-                    if (vp == vo && p < so && so < viol) viol = so;
+                    if (vp == vo && p < so) note(so, v0, v1);
                 }
         }
     };
-    auto settle = [&](u32 viol) { // wave minimum of the violations -> certEnd
-        if (wv_ballot(viol != 0xFFFFFFFFu)) {
-            u32 x = viol;
-            for (int sft = 32; sft >= 1; sft >>= 1) {
-                u32 const y = (u32)__shfl_xor((int)x, sft, 64);
-                x = y < x ? y : x;
-            }
-            x = wv_uni(x);
-            if (x < certEnd) certEnd = x;
-        }
+    // positions that can still matter: below the end of the certificate of the last block
+    auto scanStop = [&]() -> u32 {
+        u32 const ce = (blk1 != 0xFFFFFFFFu) ? certEnd1 : certEnd;
+        return ce < pEnd ? ce : pEnd;
+    };
+    auto isDense = [&](s32 rp) -> bool { // does the round at rp touch the first 4 KiB of a block?
+        bool d = rp < (s32)(SQZ_WINDOW_START + 4096);
+        if (blk1 != 0xFFFFFFFFu) d = d || (rp + 1024 > (s32)blk1 && rp < (s32)(blk1 + 4096));
+        return d;
     };
     auto loadEntry = [&](u32 vp) -> sq_v2u {
         u64 const raw = __hip_atomic_load((const SQ_G u64*)(E + 2 * hash4(vp, eLog)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         return (sq_v2u){(u32)raw, (u32)(raw >> 32)};
     };
-    auto stageC = [&]() {
-        if (!bN) return;
-        u32 viol = 0xFFFFFFFFu;
-#pragma unroll
-        for (u32 g = 0; g < 2; g++)
-            if (64 * g < bN) judge(bP[g], bV[g], bE[g], 64 * g + lane < bN, viol);
-        settle(viol);
-        bN = 0;
-    };
-    auto stageB = [&]() {
-#pragma unroll
-        for (u32 g = 0; g < 2; g++) {
-            bP[g] = aP[g];
-            bV[g] = aV[g];
-            bE[g] = (sq_v2u){0, 0};
-            if (64 * g < aN) bE[g] = loadEntry(aV[g]);
-        }
-        bN = aN;
-        aN = 0;
-    };
     auto loadRound = [&](s32 rp) -> sq_v4u { // bytes of the round that starts at position rp
         const u8* ad = a0 + (size_t)(u32)(rp - p0) + 16 * lane;
         return sq_grd128(ad < aLast ? ad : aLast);
     };
-    // one round on the loaded bytes `w` (`wn` = the next round's, for lane 63's last 3 positions);
-    // returns false when the scan is over
-    auto round = [&](sq_v4u w, sq_v4u wn) -> bool {
-        u32 const stop = certEnd < pEnd ? certEnd : pEnd;
-        PROF_T0(t_s1);
-        u32 d[5] = {w.x, w.y, w.z, w.w, 0};
+    // Bloom tests of one round: returns the lane's candidate mask (bit j <-> position lo + j) and
+    // leaves the lane's 20 bytes in d[]
+    auto testRound = [&](sq_v4u w, sq_v4u wn, s32 rp, u32& d4) -> u32 {
         {
             u32 const nx = (u32)__builtin_amdgcn_update_dpp(0, (int)w.x, 0x130 /* wave_shl:1 */, 0xF, 0xF, false);
             u32 const n63 = wv_uni(wn.x);
-            d[4] = (lane == 63) ? n63 : nx;
+            d4 = (lane == 63) ? n63 : nx;
         }
-        // valid positions of this lane: bit j <-> position lo + j in [2, stop)
-        s32 const lo = pos + (s32)(16 * lane);
+        u32 const d[5] = {w.x, w.y, w.z, w.w, d4};
+        u32 const stop = scanStop();
+        s32 const lo = rp + (s32)(16 * lane);
         s32 f = (s32)SQZ_WINDOW_START - lo, l = (s32)stop - lo;
         f = f < 0 ? 0 : (f > 16 ? 16 : f);
         l = l < 0 ? 0 : (l > 16 ? 16 : l);
         u32 const okMask = ((1u << l) - 1u) & ~((1u << f) - 1u);
-        u32 cm = 0; // bit j: position lo + j is a candidate
+        u32 cm = 0;
 #pragma unroll
         for (u32 q = 0; q < 4; q++) {
             u32 v[4], p1[4], p2[4];
@@ -921,73 +919,133 @@ SQ_DEVFN void cert_compute(MatchState& ms) {
                 cm |= c << (4 * q + k);
             }
         }
-        cm &= okMask;
+        return cm & okMask;
+    };
+    // the 4 bytes at byte offset j of the lane's 20 (w, then d4); selects on registers, no array
+    auto valAt = [&](sq_v4u w, u32 d4, u32 j) -> u32 {
+        u32 const a = j >> 2;
+        u32 const lo = a == 0 ? w.x : a == 1 ? w.y : a == 2 ? w.z : w.w;
+        u32 const hi = a == 0 ? w.y : a == 1 ? w.z : a == 2 ? w.w : d4;
+        return __builtin_amdgcn_alignbyte(hi, lo, j & 3);
+    };
+    auto judgeSlot = [&](Slot& sl) {
+        u32 v0 = 0xFFFFFFFFu, v1 = 0xFFFFFFFFu;
+#pragma unroll
+        for (u32 g = 0; g < 2; g++) judge(sl.p[g], sl.v[g], sl.e[g], 64 * g + lane < sl.n, v0, v1);
+        settle(v0, v1);
+        sl.n = 0;
+    };
+    // a round of the pipelined part; returns false when the pipelined segment is over
+    auto round = [&](sq_v4u w, sq_v4u wn, Slot& sl) -> bool {
+        PROF_T0(t_s1);
+        u32 d4;
+        u32 cm = testRound(w, wn, pos, d4);
+        s32 const lo = pos + (s32)(16 * lane);
         u32 cnt = 0;
         for (;;) { // compaction: one candidate per lane and turn
             u64 const m = wv_ballot(cm != 0);
             if (!m) break;
             if (cm) {
-                u32 const bpos = (u32)__builtin_ctz(cm);
+                u32 const j = (u32)__builtin_ctz(cm);
                 cm &= cm - 1;
                 u32 const slot = cnt + (u32)__popcll(m & below);
-                if (slot < 1024) cand[slot] = (u32)(lo + (s32)bpos);
+                if (slot < 128) {
+                    cand[2 * slot] = (u32)(lo + (s32)j);
+                    cand[2 * slot + 1] = valAt(w, d4, j);
+                }
             }
             cnt += (u32)__popcll(m);
         }
         wv_fence();
         PROF_ADD(26, t_s1);
         PROF_T0(t_s2);
-        stageC();
-        stageB();
-        // stage A: the first 128 candidates of this round
-        aN = cnt < 128 ? cnt : 128;
-        if (aN) {
-            u32 const c0 = cand[0];
-#pragma unroll
-            for (u32 g = 0; g < 2; g++) {
-                aP[g] = (64 * g + lane < aN) ? cand[64 * g + lane] : c0;
-                aV[g] = sq_grd32(base + aP[g]);
-            }
+        judgeSlot(sl); // filled 5 rounds ago
+        if (cnt > 128) { // cannot happen outside the dense zones with a working filter: stay conservative
+            u32 const cut = (u32)(pos < (s32)SQZ_WINDOW_START ? (s32)SQZ_WINDOW_START : pos) + 1;
+            if (cut < certEnd) certEnd = cut;
+            if (cut < certEnd1) certEnd1 = cut;
+            cnt = 128;
         }
-        if (cnt > 128) { // dense part of the schedule (block start): the rest right away, 64 at a time
-            u32 viol = 0xFFFFFFFFu;
-            u32 const lim = cnt < 1024 ? cnt : 1024;
-            for (u32 j0 = 128; j0 < lim; j0 += 64) {
-                bool const valid = j0 + lane < lim;
-                u32 const p = valid ? cand[j0 + lane] : cand[0];
-                u32 const vp = sq_grd32(base + p);
-                judge(p, vp, loadEntry(vp), valid, viol);
-            }
-            settle(viol);
+        sl.n = cnt;
+#pragma unroll
+        for (u32 g = 0; g < 2; g++) { // always two LDS reads + two gathers: idle lanes re-read entry 0
+            u32 const j = (64 * g + lane < cnt) ? 64 * g + lane : 0u;
+            sl.p[g] = cand[2 * j];
+            sl.v[g] = cand[2 * j + 1];
+            sl.e[g] = loadEntry(sl.v[g]);
         }
         PROF_ADD(27, t_s2);
         pos += 1024;
-        return pos < (s32)certEnd && pos < (s32)pEnd;
+        return pos < (s32)scanStop() && !isDense(pos);
+    };
+    // a self-contained round: every lane judges its own positives, four at a time
+    auto roundSimple = [&]() {
+        u32 d4;
+        sq_v4u const w = loadRound(pos);
+        u32 cm = testRound(w, loadRound(pos + 1024), pos, d4);
+        s32 const lo = pos + (s32)(16 * lane);
+        u32 v0 = 0xFFFFFFFFu, v1 = 0xFFFFFFFFu;
+        while (wv_ballot(cm != 0)) {
+            u32 pj[4], vj[4];
+            sq_v2u ej[4];
+            bool ok[4];
+#pragma unroll
+            for (u32 k = 0; k < 4; k++) {
+                ok[k] = cm != 0;
+                u32 const j = ok[k] ? (u32)__builtin_ctz(cm) : 0u;
+                cm &= cm - 1; // 0 stays 0
+                pj[k] = (u32)(lo + (s32)j);
+                vj[k] = valAt(w, d4, j);
+                ej[k] = loadEntry(vj[k]);
+            }
+#pragma unroll
+            for (u32 k = 0; k < 4; k++) judge(pj[k], vj[k], ej[k], ok[k], v0, v1);
+        }
+        settle(v0, v1);
+        pos += 1024;
     };
 
-    if (pos < (s32)certEnd && pos < (s32)pEnd) { // 5 KiB of the stream in flight per wave
+    cand[0] = SQZ_WINDOW_START; // entry 0 is what idle lanes re-read
+    cand[1] = 0;
+    wv_fence();
+    while (pos < (s32)scanStop()) {
+        if (isDense(pos)) {
+            roundSimple();
+            continue;
+        }
+        Slot sA = {{0, 0}, {0, 0}, {{0, 0}, {0, 0}}, 0}, sB = sA, sC = sA, sD = sA, sE = sA;
         sq_v4u wA = loadRound(pos), wB = loadRound(pos + 1024), wC = loadRound(pos + 2048), wD = loadRound(pos + 3072), wE;
+        // 5 KiB of the stream and 5 slots of gathers in flight per wave.  (hipcc still drains vmcnt to 0
+        // at the head of this loop -- its wait-count analysis gives up across the back edge -- so one
+        // memory latency is paid per 5 rounds; a 10-round body measured no better.)
         for (;;) {
             wE = loadRound(pos + 4096);
-            if (!round(wA, wB)) break;
+            if (!round(wA, wB, sA)) break;
             wA = loadRound(pos + 4096);
-            if (!round(wB, wC)) break;
+            if (!round(wB, wC, sB)) break;
             wB = loadRound(pos + 4096);
-            if (!round(wC, wD)) break;
+            if (!round(wC, wD, sC)) break;
             wC = loadRound(pos + 4096);
-            if (!round(wD, wE)) break;
+            if (!round(wD, wE, sD)) break;
             wD = loadRound(pos + 4096);
-            if (!round(wE, wA)) break;
+            if (!round(wE, wA, sE)) break;
         }
+        judgeSlot(sA);
+        judgeSlot(sB);
+        judgeSlot(sC);
+        judgeSlot(sD);
+        judgeSlot(sE);
     }
-    // drain the pipeline
-    stageC();
-    stageB();
-    stageC();
     wv_fence();
 #else
     // scalar twin: same table, same rule
     u32 ovfS[SQZ_CERT_OVF_CAP], ovfV[SQZ_CERT_OVF_CAP];
+    auto note = [&](u32 sviol) { // a search at sviol may succeed
+        if (sviol < blk1)
+            certEnd = sviol < certEnd ? sviol : certEnd;
+        else
+            certEnd1 = sviol < certEnd1 ? sviol : certEnd1;
+    };
     for (u32 i = 0; i < nCert; i++) {
         u32 const sp = cert_pos(ms, i);
         u32 const v = sq_rd32(base + sp);
@@ -995,7 +1053,7 @@ SQ_DEVFN void cert_compute(MatchState& ms) {
         E[2 * h] = ht_enc(ms, sp); // the last claimant wins
         E[2 * h + 1] = v;
         vbloom_add(v);
-        if (sq_rd32(base + sp + 1) == v && sp < certEnd) certEnd = sp;
+        if (sq_rd32(base + sp + 1) == v) note(sp);
     }
     for (u32 i = 0; i < nCert; i++) {
         u32 const sp = cert_pos(ms, i);
@@ -1008,27 +1066,75 @@ SQ_DEVFN void cert_compute(MatchState& ms) {
                 ovfS[nOvf] = sp;
                 ovfV[nOvf] = v;
                 nOvf++;
-            } else if (sp < certEnd)
-                certEnd = sp;
+            } else
+                note(sp);
         }
     }
     u32 const pEnd = ms.chunkEndPos - 3;
-    for (u32 p = SQZ_WINDOW_START; p < certEnd && p < pEnd; p++) {
+    for (u32 p = SQZ_WINDOW_START; p < ((blk1 != 0xFFFFFFFFu) ? certEnd1 : certEnd) && p < pEnd; p++) {
         u32 const vp = sq_rd32(base + p);
         if (!((g_lds.u.bloom[(vp & 0xFFFFu) >> 5] >> (vp & 31)) & (g_lds.u.bloom[vp >> 21] >> ((vp >> 16) & 31)) & 1u)) continue;
         u32 const h = hash4(vp, eLog);
         u32 const t = ht_dec(ms, E[2 * h]);
         if (!t) continue;
         u32 const sw = t & SQZ_HT_IDX;
-        if (p < sw && vp == E[2 * h + 1] && sw < certEnd) certEnd = sw;
+        if (p < sw && vp == E[2 * h + 1]) note(sw);
         if (t & SQZ_CERT_DUP)
             for (u32 k = 0; k < nOvf; k++)
-                if (vp == ovfV[k] && p < ovfS[k] && ovfS[k] < certEnd) certEnd = ovfS[k];
+                if (vp == ovfV[k] && p < ovfS[k]) note(ovfS[k]);
     }
 #endif
     ms.certEnd = certEnd;
+    ms.certEnd1 = (blk1 != 0xFFFFFFFFu) ? certEnd1 : 0u;
     SQ_TRACE(40, certEnd);
     SQ_TRACE(41, nOvf);
+    SQ_TRACE(42, ms.certEnd1);
+}
+
+// Block 1 was certified under the assumption that it starts with repcode offset 1.  When block 0
+// ended with another offset (it had a match), redo the repcode test of block 1's scheduled
+// searches with the real one: returns the first scheduled position below `limit` where
+// read32(s + 1 - off1) == read32(s + 1), or `limit`.
+SQ_DEVFN u32 cert_rep_recheck(MatchState& ms, u32 off1, u32 limit) {
+    const u8* const base = ms.base;
+    u32 const first = ms.certCnt0, n = ms.nCert;
+    u32 best = limit;
+#if SQ_ON_DEVICE
+    u32 const lane = wv_lane();
+    u32 mine = limit;
+    for (u32 i0 = first; i0 < n; i0 += 256) {
+        u32 sp[4], a[4], b[4];
+#pragma unroll
+        for (u32 g = 0; g < 4; g++) {
+            u32 const i = i0 + 64 * g + lane;
+            sp[g] = cert_pos(ms, i < n ? i : n - 1);
+        }
+#pragma unroll
+        for (u32 g = 0; g < 4; g++) {
+            a[g] = sq_grd32(base + sp[g] + 1 - off1);
+            b[g] = sq_grd32(base + sp[g] + 1);
+        }
+#pragma unroll
+        for (u32 g = 0; g < 4; g++)
+            if (i0 + 64 * g + lane < n && a[g] == b[g] && sp[g] < mine) mine = sp[g];
+        if (wv_uni(sp[0]) >= limit) break; // the schedule is ascending: nothing below `limit` is left
+    }
+    for (int sft = 32; sft >= 1; sft >>= 1) {
+        u32 const y = (u32)__shfl_xor((int)mine, sft, 64);
+        mine = y < mine ? y : mine;
+    }
+    best = wv_uni(mine);
+#else
+    for (u32 i = first; i < n; i++) {
+        u32 const sp = cert_pos(ms, i);
+        if (sp >= limit) break;
+        if (sq_rd32(base + sp + 1 - off1) == sq_rd32(base + sp + 1)) {
+            best = sp;
+            break;
+        }
+    }
+#endif
+    return best < limit ? best : limit;
 }
 
 // ZSTD_updateDUBT
@@ -1660,23 +1766,39 @@ SQ_DEVFN u32 compressBlock_lazy(MatchState& ms, SeqStore& ss, u32* rep, const u8
     }
     ms.lazySkipping = 0;
 
-    if (!ROW && ms.certEnd) {
+    if (!ROW && (ms.certEnd | ms.certEnd1)) {
         // No-match certificate (cert_compute): the scheduled searches of this block at positions
-        // below certEnd certainly fail.  Skip them: what remains of them is the parser state (ip,
-        // nextToUpdate) and their deferred tree updates (cert_mark_deferred).
+        // below its certEnd certainly fail.  Skip them: what remains of them is the parser state
+        // (ip, nextToUpdate) and their deferred tree updates (cert_mark_deferred).
         u32 const blk = (u32)(istart - base), ipPos = (u32)(ip - base), ilimPos = (u32)(ilimit - base);
+        bool const second = blk != SQZ_WINDOW_START;
         u32 const predEnd = (ms.chunkEndPos - blk < SQZ_BLOCKSIZE_MAX) ? ms.chunkEndPos : blk + SQZ_BLOCKSIZE_MAX;
-        bool const asPredicted = (blk == SQZ_WINDOW_START || blk == SQZ_WINDOW_START + SQZ_BLOCKSIZE_MAX) && (blk + srcSize == predEnd) &&
-                                 (offset_1 == 1) && (ss.nseq == 0);
-        if (!asPredicted || ms.certEnd <= ipPos || ilimit <= ip) {
-            if (!asPredicted || ms.certEnd <= ipPos) ms.certEnd = 0; // the certificate ends here
+        bool const asPredicted = (blk == SQZ_WINDOW_START || blk == SQZ_WINDOW_START + SQZ_BLOCKSIZE_MAX) &&
+                                 (blk + srcSize == predEnd) && (ss.nseq == 0) && (second || offset_1 == 1);
+        bool const live = ms.eager || ms.nLive; // the finder holds tables that later searches will read
+        u32 ce = second ? ms.certEnd1 : ms.certEnd;
+        if (asPredicted && second && ce > ipPos && offset_1 > 1) // block 0 left another repcode behind
+            ce = cert_rep_recheck(ms, offset_1, ce);
+        if (!asPredicted || ce <= ipPos || ilimit <= ip || (live && ce < ilimPos)) {
+            // nothing to skip here (a partial certificate is only used while the finder is still
+            // asleep: otherwise the exact code simply does the whole block)
+            if (!asPredicted || ce <= ipPos || live) {
+                if (second)
+                    ms.certEnd1 = 0;
+                else
+                    ms.certEnd = 0;
+            }
+        } else if (live) {
+            // every search of this (last) block fails and nothing after it can observe the tables:
+            // no search, no insertion, no bookkeeping
+            ip = ilimit;
+            SQ_TRACE(38, 1);
         } else {
             PROF_T0(t_bw);
             // this block's part of the schedule is a prefix of one of the two tables
-            bool const second = blk != SQZ_WINDOW_START;
             const u32* const ent = ms.schedTab + 2 + (second ? SQZ_SCHEDTAB_N : 0u);
             u32 const nEnt = second ? ms.nCert - ms.certCnt0 : ms.certCnt0;
-            u32 const cnt = (ms.certEnd >= ilimPos) ? nEnt : sched_count(ent, nEnt, ms.certEnd - blk);
+            u32 const cnt = (ce >= ilimPos) ? nEnt : sched_count(ent, nEnt, ce - blk);
             u32 const last = cnt ? blk + gld32(ent + cnt - 1) : 0u;
             u32 const pz = (cnt < nEnt) ? blk + gld32(ent + cnt) : ilimPos;
             PROF_ADD(28, t_bw);
@@ -1686,7 +1808,10 @@ SQ_DEVFN u32 compressBlock_lazy(MatchState& ms, SeqStore& ss, u32* rep, const u8
             failStreak = SQZ_EPOCH_AFTER_FAILS;
             if (pz < ilimPos) { // the exact code takes over at the first position that is not certified
                 exactAt = pz;
-                ms.certEnd = 0;
+                if (second)
+                    ms.certEnd1 = 0;
+                else
+                    ms.certEnd = 0;
             }
         }
     }

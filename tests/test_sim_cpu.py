@@ -79,7 +79,7 @@ def test_sim_persistent_wave_table_generations(sim, oracle):
     sim.sim_persistent_reset()
 
 
-PLANTED = [(v, s, n) for v in range(8) for s, n in ((1, 262144), (2, 200000), (3, 50000))]
+PLANTED = [(v, s, n) for v in range(10) for s, n in ((1, 262144), (2, 200000), (3, 50000))]
 
 
 @pytest.mark.parametrize("variant,seed,n", PLANTED)

@@ -227,6 +227,19 @@ def planted(seed: int, nbytes: int, variant: int = 0) -> bytes:
         a, c, d = sched[len(sched) // 5], sched[len(sched) // 2], sched[len(sched) - 3]
         copy(c, a, 4)
         copy(d, a, 9)
+    elif variant in (8, 9):  # a match in block 0 only: block 1 keeps its own certificate, but starts with
+        first = [x for x in sched if x < (128 << 10)]   # the repcode offset that block 0 left behind
+        t0 = first[3 * len(first) // 4]
+        # 8: too short a match to pay for a compressed block -> block 0 is emitted raw and its repcodes
+        # are dropped; 9: long enough -> block 0 is compressed and block 1 inherits its repcode offset
+        ln = 50 if variant == 8 else 6000
+        src = pick(2, 0, max(65, t0 - ln - 64) - 64)
+        copy(t0, src, ln)
+        if variant == 9 and nbytes > (128 << 10) + 4096:  # ... which then fires at a searched position of block 1
+            second = [x for x in sched if x >= (128 << 10)]
+            t1 = second[len(second) // 2]
+            off = t0 - src
+            b[t1 + 1:t1 + 9] = b[t1 + 1 - off:t1 + 9 - off]
     elif variant == 7:    # plant in the last block only, source in the first block
         last_start = ((nbytes - 1) // (128 << 10)) * (128 << 10)
         tail = [x for x in sched if x >= last_start]
