@@ -31,7 +31,7 @@ class SqConfig(ctypes.Structure):
 
 class SqTimings(ctypes.Structure):
     _fields_ = [("hash_ms", ctypes.c_float), ("dedup_ms", ctypes.c_float),
-                ("compress_ms", ctypes.c_float), ("compact_ms", ctypes.c_float)]
+                ("compress_ms", ctypes.c_float), ("compact_ms", ctypes.c_float), ("fast_ms", ctypes.c_float)]
 
 
 class SquishError(RuntimeError):

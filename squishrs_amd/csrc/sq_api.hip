@@ -67,7 +67,7 @@ struct sq_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     bool own_stream = false;
-    hipEvent_t ev[8];
+    hipEvent_t ev[10];
     int num_cu = 256;
 
     // dedup state (persistent)
@@ -80,11 +80,11 @@ struct sq_ctx {
 
     // per-batch scratch
     DevBuf b_off, b_len, b_slot_off, b_frame_len, b_out_off, b_isnew, b_hashes, b_stage_in,
-        b_stage_out, b_slots, b_ws, b_misc;
+        b_stage_out, b_slots, b_ws, b_misc, b_cert;
     void* h_pinned = nullptr; // small pinned host mirror (total sizes etc.)
     u32* d_sched_tab = nullptr; // constant no-match schedule tables of the compressor (sched_tab_fill)
 
-    sq_timings last = {0, 0, 0, 0};
+    sq_timings last = {0, 0, 0, 0, 0};
 };
 
 static bool is_device_ptr(const void* p) {
@@ -195,7 +195,7 @@ void sq_ctx_destroy(sq_ctx* c) {
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     for (DevBuf* b : {&c->b_off, &c->b_len, &c->b_slot_off, &c->b_frame_len, &c->b_out_off, &c->b_isnew,
-                      &c->b_hashes, &c->b_stage_in, &c->b_stage_out, &c->b_slots, &c->b_ws, &c->b_misc})
+                      &c->b_hashes, &c->b_stage_in, &c->b_stage_out, &c->b_slots, &c->b_ws, &c->b_misc, &c->b_cert})
         b->release();
     if (c->d_table) (void)hipFree(c->d_table);
     if (c->d_keys) (void)hipFree(c->d_keys);
@@ -380,7 +380,22 @@ static int compress_async(sq_ctx* c, const u8* d_data, const u64* h_off, const u
     const size_t ws_each = sqz::workspace_bytes(max_len);
     // keep the workspace pool within ~96 GiB
     while (waves > 64 && (u64)waves * ws_each > (96ull << 30)) waves /= 2;
-    if ((r = c->b_ws.ensure((size_t)waves * ws_each + 256))) return r;
+    // Stage 1, the incompressible-chunk kernel (sq_zstd_fast.h): twice the waves, one certificate
+    // table each (8 bytes x 2^(chainLog-1) of the largest btlazy2 chunk), carved from the same pool.
+    // It only applies to chunks of 16 KiB < len <= 256 KiB.
+    const bool fast = max_len > (16u << 10) && !getenv("SQ_NO_FASTPATH");
+    u32 fwaves = 0;
+    size_t etab_bytes = 0;
+    if (fast) {
+        u32 w = 15;
+        const u32 ml = std::min(max_len, 256u << 10);
+        while ((1u << w) < ml) w++;
+        etab_bytes = (size_t)8 << w; // chainLog - 1 == windowLog
+        fwaves = c->cfg.compress_waves ? c->cfg.compress_waves * 2 : (u32)c->num_cu * 16;
+        fwaves = std::min(fwaves, n);
+        if ((r = c->b_cert.ensure((size_t)n * 8))) return r;
+    }
+    if ((r = c->b_ws.ensure(std::max((size_t)waves * ws_each, (size_t)fwaves * etab_bytes) + 256))) return r;
     if ((r = c->b_misc.ensure(256))) return r;
     HIPCHK(hipMemsetAsync(c->b_misc.p, 0, 256, c->stream));
 
@@ -391,7 +406,23 @@ static int compress_async(sq_ctx* c, const u8* d_data, const u64* h_off, const u
         (void)hipFuncGetAttributes(&fa, (const void*)sqz::k_compress_batch);
         fprintf(stderr, "[squish_gpu] compress kernel: occupancy %d blocks/CU, regs %d, lds %zu, scratch %zu; waves %u, ws_each %zu\n",
                 nb, fa.numRegs, fa.sharedSizeBytes, fa.localSizeBytes, waves, ws_each);
+        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, sqz::k_incompressible_batch, 64, 0);
+        (void)hipFuncGetAttributes(&fa, (const void*)sqz::k_incompressible_batch);
+        fprintf(stderr, "[squish_gpu] incompressible-chunk kernel: occupancy %d blocks/CU, regs %d, lds %zu, scratch %zu; waves %u, table %zu\n",
+                nb, fa.numRegs, fa.sharedSizeBytes, fa.localSizeBytes, fwaves, etab_bytes);
     }
+    c->last.fast_ms = 0;
+    if (fast) {
+        HIPCHK(hipEventRecord(c->ev[8], c->stream));
+        hipLaunchKernelGGL(sqz::k_incompressible_batch, dim3(fwaves), dim3(64), 0, c->stream, d_data,
+                           (const u64*)c->b_off.p, (const u32*)c->b_len.p, d_select, n, d_slots,
+                           (const u64*)c->b_slot_off.p, (u32*)c->b_frame_len.p, (u32*)c->b_cert.p, (u8*)c->b_ws.p,
+                           (u64)etab_bytes, (u32*)c->b_misc.p + 32 /*queue*/, (const u32*)c->d_sched_tab,
+                           (u32)(getenv("SQ_FAST_DBG") ? atoi(getenv("SQ_FAST_DBG")) : 0));
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipEventRecord(c->ev[9], c->stream));
+    }
+    // Stage 2, the compressor proper, for everything stage 1 left undecided
     HIPCHK(hipEventRecord(c->ev[4], c->stream));
     {
         dim3 block(64), grid(waves);
@@ -399,7 +430,7 @@ static int compress_async(sq_ctx* c, const u8* d_data, const u64* h_off, const u
                            (const u32*)c->b_len.p, d_select, n, d_slots,
                            (const u64*)c->b_slot_off.p, (u32*)c->b_frame_len.p, (u8*)c->b_ws.p,
                            (u64)ws_each, (u32*)c->b_misc.p /*queue*/, (u32*)c->b_misc.p + 16 /*err*/,
-                           (const u32*)c->d_sched_tab);
+                           (const u32*)c->d_sched_tab, fast ? (const u32*)c->b_cert.p : (const u32*)nullptr);
         HIPCHK(hipGetLastError());
     }
     HIPCHK(hipEventRecord(c->ev[5], c->stream));
@@ -445,6 +476,7 @@ static int compress_async(sq_ctx* c, const u8* d_data, const u64* h_off, const u
     HIPCHK(hipMemcpyAsync(h_err, (u32*)c->b_misc.p + 16, 4, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
     HIPCHK(hipEventElapsedTime(&c->last.compress_ms, c->ev[4], c->ev[5]));
+    if (fast) HIPCHK(hipEventElapsedTime(&c->last.fast_ms, c->ev[8], c->ev[9]));
 #ifdef SQ_PROF
     {   // profiling build: sum the per-wave phase timers (100 MHz ticks) and print them
         std::vector<unsigned long long> tot(33, 0), one(33);

@@ -12,6 +12,7 @@
 // written straight into per-chunk output slots.
 #pragma once
 #include "sq_zstd_opt.h"
+#include "sq_zstd_fast.h"
 
 namespace sqz {
 
@@ -328,8 +329,10 @@ struct TableGen {
 };
 
 // Returns the frame length, 0 on error.
+// certHint: two words left by k_incompressible_batch for this chunk (certificate ends, see
+// fastpath_frame_wave) or nullptr.
 SQ_DEVFN u32 compress_frame_wave(const u8* src, u32 n, u8* dst, u32 cap, u8* ws, const WsLayout& L, TableGen& tg,
-                                 const u32* schedTab) {
+                                 const u32* schedTab, const u32* certHint) {
     MatchState ms;
     SeqStore ss;
     BlockState bs;
@@ -455,7 +458,11 @@ SQ_DEVFN u32 compress_frame_wave(const u8* src, u32 n, u8* dst, u32 cap, u8* ws,
         u32 const cnt1 = (len1 < 9) ? 0u : (len1 == SQZ_BLOCKSIZE_MAX) ? full1 : sched_count(schedTab + 2 + SQZ_SCHEDTAB_N, full1, len1 - 8);
         ms.nCert = ms.certCnt0 + cnt1;
         PROF_ADD(24, t_pr);
-        if (ms.nCert > 0) {
+        u32 const hint1 = certHint ? gld32(certHint + 1) : 0u;
+        if (hint1 & SQZ_CERT_HINT_VALID) { // already computed by the incompressible-chunk kernel
+            ms.certEnd = gld32(certHint);
+            ms.certEnd1 = hint1 & ~SQZ_CERT_HINT_VALID;
+        } else if (ms.nCert > 0) {
             cert_compute(ms);
         }
         wv_zero_lds(g_lds.u.bloom, SQZ_BLOOM_WORDS);
@@ -536,11 +543,12 @@ SQ_DEVFN u32 compress_frame_wave(const u8* src, u32 n, u8* dst, u32 cap, u8* ws,
 #if SQ_ON_DEVICE
 // One chunk -> one frame in its output slot (kept out of line: keeps the queue loop simple).
 __device__ __noinline__ void compress_one(const u8* data, const u64* off, const u32* len, u32 idx, u8* slots,
-                                          const u64* slot_off, u32* frame_len, u8* ws, u32* err, TableGen& tg, const u32* schedTab) {
+                                          const u64* slot_off, u32* frame_len, u8* ws, u32* err, TableGen& tg, const u32* schedTab,
+                                          const u32* certHint) {
     u32 const L = len[idx];
     WsLayout const lay = ws_layout(L); // offsets for this length are <= the pool's
     u32 const cap = (u32)(slot_off[idx + 1] - slot_off[idx]);
-    u32 const r = compress_frame_wave(data + off[idx], L, slots + slot_off[idx], cap, ws, lay, tg, schedTab);
+    u32 const r = compress_frame_wave(data + off[idx], L, slots + slot_off[idx], cap, ws, lay, tg, schedTab, certHint ? certHint + 2 * (size_t)idx : nullptr);
     if (wv_lane() == 0) {
         frame_len[idx] = r;
         if (r == 0) atomicOr(err, 1u);
@@ -552,7 +560,7 @@ __device__ __noinline__ void compress_one(const u8* data, const u64* off, const 
 __global__ void __launch_bounds__(64, 2) // 2 waves per SIMD: <= 256 registers, 8 waves per CU (LDS: 8 x 19 KiB)
 k_compress_batch(const u8* data, const u64* off, const u32* len, const u8* select, u32 n, u8* slots,
                  const u64* slot_off, u32* frame_len, u8* ws_pool, u64 ws_each, u32* queue, u32* err,
-                 const u32* schedTab) {
+                 const u32* schedTab, const u32* certHint) {
     u8* const ws = ws_pool + (u64)blockIdx.x * ws_each;
     u32* const dbg = (u32*)(ws + ws_each - 256) + 8; // wave-level progress words for the watchdog
     u32 iter = 0;
@@ -572,9 +580,10 @@ k_compress_batch(const u8* data, const u64* off, const u32* len, const u8* selec
         }
         iter++;
         if (idx >= n) break;
-        bool const take = (select == nullptr) || (select[idx] != 0);
+        // certHint != nullptr: k_incompressible_batch ran first; a non-zero frame length is its frame
+        bool const take = ((select == nullptr) || (select[idx] != 0)) && !(certHint && frame_len[idx] != 0);
         PROF_T0(t_all);
-        if (take) compress_one(data, off, len, idx, slots, slot_off, frame_len, ws, err, tg, schedTab);
+        if (take) compress_one(data, off, len, idx, slots, slot_off, frame_len, ws, err, tg, schedTab, certHint);
         PROF_ADD(0, t_all);
     }
     if (wv_lane() == 0) dbg[11] = 777;

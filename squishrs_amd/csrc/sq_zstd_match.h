@@ -131,8 +131,10 @@ struct MatchState {
 #endif
 #define SQZ_DUBT_SEARCHED 0xFFFFFFFFu // sort mark of a deferred (not yet replayed) search node
 
-SQ_DEV u32 ht_dec(const MatchState& ms, u32 w) { return ((w & SQZ_HT_TAG) == ms.genBits) ? (w & ~SQZ_HT_TAG) : 0u; }
-SQ_DEV u32 ht_enc(const MatchState& ms, u32 w) { return w | ms.genBits; }
+SQ_DEV u32 ht_dec_g(u32 genBits, u32 w) { return ((w & SQZ_HT_TAG) == genBits) ? (w & ~SQZ_HT_TAG) : 0u; }
+SQ_DEV u32 ht_enc_g(u32 genBits, u32 w) { return w | genBits; }
+SQ_DEV u32 ht_dec(const MatchState& ms, u32 w) { return ht_dec_g(ms.genBits, w); }
+SQ_DEV u32 ht_enc(const MatchState& ms, u32 w) { return ht_enc_g(ms.genBits, w); }
 
 SQ_DEV u32 hash4(u32 v, u32 hBits) { return (v * 2654435761U) >> (32 - hBits); }
 SQ_DEV u32 hash5(u64 v, u32 hBits) { return (u32)(((v << 24) * 889523592379ULL) >> (64 - hBits)); }
@@ -482,11 +484,12 @@ SQ_DEVFN u32 sched_count(const u32* const entries, u32 const nEntries, u32 const
 }
 // position (index) of the i-th scheduled search of the chunk, i < ms.nCert (a chunk of this
 // strategy has at most two blocks)
-SQ_DEV u32 cert_pos(const MatchState& ms, u32 i) { // one load, no branch
-    bool const first = i < ms.certCnt0;
-    u32 const slot = first ? i : SQZ_SCHEDTAB_N + (i - ms.certCnt0);
-    return sq_gld32(ms.schedTab + 2 + slot) + (first ? SQZ_WINDOW_START : SQZ_WINDOW_START + SQZ_BLOCKSIZE_MAX);
+SQ_DEV u32 cert_pos_t(const u32* schedTab, u32 certCnt0, u32 i) { // one load, no branch
+    bool const first = i < certCnt0;
+    u32 const slot = first ? i : SQZ_SCHEDTAB_N + (i - certCnt0);
+    return sq_gld32(schedTab + 2 + slot) + (first ? SQZ_WINDOW_START : SQZ_WINDOW_START + SQZ_BLOCKSIZE_MAX);
 }
+SQ_DEV u32 cert_pos(const MatchState& ms, u32 i) { return cert_pos_t(ms.schedTab, ms.certCnt0, i); }
 
 // Searches skipped under the no-match certificate were never executed, so the buckets they would
 // have re-sorted hold them (after a replay) as plain unsorted nodes.  Give them the mark of a
@@ -712,36 +715,54 @@ SQ_DEVFN void filter_repair(MatchState& ms, u32 pos, u32 anc, bool first) {
 // Bloom filter of the certificate scan: keyed by the 4 BYTES themselves (probe 1 from the low
 // half, probe 2 from the high half), so a scanned position costs no multiplication; only the few
 // positives are hashed.
-SQ_DEV void vbloom_add(u32 v) {
+SQ_DEV void vbloom_add(SQ_L u32* const B, u32 v) {
     u32 const w1 = (v & 0xFFFFu) >> 5, m1 = 1u << (v & 31), w2 = v >> 21, m2 = 1u << ((v >> 16) & 31);
 #if SQ_ON_DEVICE
-    SQ_L u32* const B = (SQ_L u32*)g_lds.u.bloom;
     __hip_atomic_fetch_or(&B[w1], m1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     __hip_atomic_fetch_or(&B[w2], m2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 #else
-    g_lds.u.bloom[w1] |= m1;
-    g_lds.u.bloom[w2] |= m2;
+    B[w1] |= m1;
+    B[w2] |= m2;
 #endif
 }
+
+// Everything cert_compute_core needs; free of the compressor's MatchState / LDS image so that the
+// incompressible-chunk kernel (sq_zstd_fast.h) can run it at a higher occupancy.
+struct CertCtx {
+    const u8* base;      // base + index; the chunk's first byte has index SQZ_WINDOW_START
+    u32* E;              // certificate table: 2^eLog entries of 8 bytes (global memory)
+    u32 eLog;
+    u32 genBits;         // generation tag of this chunk's entries, in place (bits 19..29)
+    const u32* schedTab; // constant no-match schedules
+    u32 certCnt0, nCert; // scheduled searches in block 0 / in the chunk
+    u32 chunkEndPos;
+    SQ_L u32* bloom;     // SQZ_BLOOM_WORDS words  (LDS)
+    SQ_L u32* cand;      // 256 words              (LDS)
+    SQ_L u32* ovf;       // 2 * SQZ_CERT_OVF_CAP   (LDS)
+    u32 certEnd, certEnd1, nOvf; // results
+    u32 dbg;             // timing experiments (SQ_FAST_DBG): 1 = no build, 2 = no scan, 8 = build without the exchange
+};
+
 #define SQZ_CERT_DUP SQZ_HT_PEND // table-word flag: another scheduled position shares this bucket
 #define SQZ_CERT_OVF_CAP 64u
 
-SQ_DEVFN void cert_compute(MatchState& ms) {
+SQ_DEVFN void cert_compute_core(CertCtx& cx) {
     // certificate table: 2^eLog entries of (position | generation tag [| DUP], the 4 bytes there),
     // 8 bytes each, in the chain-table area (which the finder only reads through valid heads)
-    u32* const E = ms.chainTable;
-    u32 const eLog = ms.cp.chainLog - 1;
-    const u8* const base = ms.base;
-    u32 const nCert = ms.nCert;
+    u32* const E = cx.E;
+    u32 const eLog = cx.eLog;
+    const u8* const base = cx.base;
+    u32 const nCert = cx.nCert;
     // one certificate per block: a match in block 0 changes that block's schedule, not block 1's
-    u32 const blk1 = (nCert > ms.certCnt0) ? SQZ_WINDOW_START + SQZ_BLOCKSIZE_MAX : 0xFFFFFFFFu;
-    u32 certEnd = ms.chunkEndPos, certEnd1 = ms.chunkEndPos;
+    u32 const blk1 = (nCert > cx.certCnt0) ? SQZ_WINDOW_START + SQZ_BLOCKSIZE_MAX : 0xFFFFFFFFu;
+    u32 certEnd = cx.chunkEndPos, certEnd1 = cx.chunkEndPos;
     u32 nOvf = 0;
-    wv_zero_lds(g_lds.u.bloom, SQZ_BLOOM_WORDS);
 #if SQ_ON_DEVICE
     u32 const lane = wv_lane();
+    for (u32 i = lane; i < SQZ_BLOOM_WORDS; i += 64) cx.bloom[i] = 0;
+    wv_fence();
     u64 const below = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
-    SQ_L u32* const ovf = (SQ_L u32*)&g_lds.ent[ms.nxEnt & 1];
+    SQ_L u32* const ovf = cx.ovf;
     u32 vmin = 0xFFFFFFFFu, vmin1 = 0xFFFFFFFFu; // lane-local minima of the violating scheduled positions
     auto note = [&](u32 sviol, u32& v0, u32& v1) { // a search at sviol may succeed
         if (sviol < blk1)
@@ -749,17 +770,21 @@ SQ_DEVFN void cert_compute(MatchState& ms) {
         else
             v1 = sviol < v1 ? sviol : v1;
     };
-    PROF_T0(t_bld);
-    // ---- build, pass A: every s claims its entry (one of several claimants wins), repcode test.
+    // ---- build, one pass over S: every s swaps its entry (position | tag, bytes) into the table with
+    // one 8-byte atomic exchange; what comes back is either stale (another generation: the slot was
+    // free) or the entry of another s of this chunk that it just displaced.  A displaced entry goes
+    // to the overflow list (its slot now carries the DUP flag); if it holds the same 4 bytes, the
+    // later of the two searches can succeed.  The repcode test (offset 1) rides along.
     // 512 scheduled positions per step, all loads unconditional (indices clamped) so that the
-    // dependent loads (schedule table -> bytes) of the eight groups overlap; only the effects are masked.
+    // dependent accesses (schedule table -> bytes -> exchange) of the eight groups overlap.
     u32 const iLast = nCert - 1;
-    for (u32 i0 = 0; i0 < nCert; i0 += 512) {
+    for (u32 i0 = 0; i0 < ((cx.dbg & 1) ? 0u : nCert); i0 += 512) {
         u32 sp[8], v[8], v1[8];
+        u64 old[8];
 #pragma unroll
         for (u32 g = 0; g < 8; g++) {
             u32 const i = i0 + 64 * g + lane;
-            sp[g] = cert_pos(ms, i < nCert ? i : iLast);
+            sp[g] = cert_pos_t(cx.schedTab, cx.certCnt0, i < nCert ? i : iLast);
         }
 #pragma unroll
         for (u32 g = 0; g < 8; g++) {
@@ -768,41 +793,35 @@ SQ_DEVFN void cert_compute(MatchState& ms) {
         }
 #pragma unroll
         for (u32 g = 0; g < 8; g++) {
+            old[g] = 0;
             if (i0 + 64 * g + lane < nCert) {
-                sq_gst64v(E + 2 * hash4(v[g], eLog), ht_enc(ms, sp[g]), v[g]);
-                vbloom_add(v[g]);
+                u64 const mine = ((u64)v[g] << 32) | ht_enc_g(cx.genBits, sp[g]);
+                if (!(cx.dbg & 8))
+                    old[g] = __hip_atomic_exchange((SQ_G u64*)(E + 2 * hash4(v[g], eLog)), mine, __ATOMIC_RELAXED,
+                                                   __HIP_MEMORY_SCOPE_AGENT);
+                vbloom_add(cx.bloom, v[g]);
                 if (v1[g] == v[g]) note(sp[g], vmin, vmin1); // offset_1 == 1 repcode at s+1
             }
         }
-    }
-    wv_mem_sync();
-    // ---- build, pass B: those that did not win their entry go to the overflow list
-    for (u32 i0 = 0; i0 < nCert; i0 += 512) {
-        u32 sp[8], v[8], t[8];
 #pragma unroll
         for (u32 g = 0; g < 8; g++) {
-            u32 const i = i0 + 64 * g + lane;
-            sp[g] = cert_pos(ms, i < nCert ? i : iLast);
-        }
-#pragma unroll
-        for (u32 g = 0; g < 8; g++) v[g] = sq_grd32(base + sp[g]);
-#pragma unroll
-        for (u32 g = 0; g < 8; g++) t[g] = sq_tld32(E + 2 * hash4(v[g], eLog));
-#pragma unroll
-        for (u32 g = 0; g < 8; g++) {
-            bool const valid = i0 + 64 * g + lane < nCert;
-            u32 const td = ht_dec(ms, t[g]);
-            bool const loser = valid && (td & SQZ_HT_IDX) != sp[g];
-            if (loser) sq_gst32(E + 2 * hash4(v[g], eLog), ht_enc(ms, td | SQZ_CERT_DUP));
-            u64 const m = wv_ballot(loser);
+            u32 const od = ht_dec_g(cx.genBits, (u32)old[g]); // 0 unless an entry of this chunk
+            bool const displaced = od != 0;
+            u32 const opos = od & SQZ_HT_IDX, oval = (u32)(old[g] >> 32);
+            if (displaced) {
+                __hip_atomic_fetch_or((SQ_G u32*)(E + 2 * hash4(v[g], eLog)), SQZ_CERT_DUP, __ATOMIC_RELAXED,
+                                      __HIP_MEMORY_SCOPE_AGENT);
+                if (oval == v[g]) note(opos > sp[g] ? opos : sp[g], vmin, vmin1);
+            }
+            u64 const m = wv_ballot(displaced);
             if (m) {
-                if (loser) {
+                if (displaced) {
                     u32 const slot = nOvf + (u32)__popcll(m & below);
                     if (slot < SQZ_CERT_OVF_CAP) {
-                        ovf[2 * slot] = sp[g];
-                        ovf[2 * slot + 1] = v[g];
+                        ovf[2 * slot] = opos;
+                        ovf[2 * slot + 1] = oval;
                     } else
-                        note(sp[g], vmin, vmin1); // no room to remember it: the certificate ends there
+                        note(opos, vmin, vmin1); // no room to remember it: the certificate ends there
                 }
                 nOvf += (u32)__popcll(m);
             }
@@ -825,7 +844,6 @@ SQ_DEVFN void cert_compute(MatchState& ms) {
         }
     };
     settle(vmin, vmin1);
-    PROF_ADD(25, t_bld);
     // ---- scan: positions [2, min(certEnd, last position with 4 readable bytes]), as one software
     // pipeline over rounds of 1024 bytes.  The kernel is latency-bound (2 waves per SIMD) and a
     // wave's loads complete in order, so every load of the scan is issued >= 4 rounds (about one
@@ -838,15 +856,15 @@ SQ_DEVFN void cert_compute(MatchState& ms) {
     //   round k+5 : that slot is judged, then refilled
     // The first 4 KiB of a block, where the schedule itself is dense (every position, every 2nd, ...),
     // are done by a simple round that judges each lane's positives in place.
-    u32 const pEnd = ms.chunkEndPos - 3; // one past the last p with p + 4 <= chunkEnd
-    SQ_L u32* const cand = (SQ_L u32*)g_lds.grp; // 128 x (position, bytes)
-    const SQ_L u32* const B = (const SQ_L u32*)g_lds.u.bloom;
+    u32 const pEnd = cx.chunkEndPos - 3; // one past the last p with p + 4 <= chunkEnd
+    SQ_L u32* const cand = cx.cand; // 128 x (position, bytes)
+    const SQ_L u32* const B = cx.bloom;
     // the stream starts at the 16-byte boundary at or below the first source byte (same page, so
     // readable) and never reads beyond the 16-byte block that holds the chunk's last byte
     const u8* const src0 = base + SQZ_WINDOW_START;
     const u8* const a0 = src0 - ((size_t)src0 & 15);
     s32 const p0 = (s32)SQZ_WINDOW_START - (s32)(src0 - a0); // position of a0 (may be negative)
-    const u8* const lastByte = base + ms.chunkEndPos - 1;
+    const u8* const lastByte = base + cx.chunkEndPos - 1;
     const u8* const aLast = lastByte - ((size_t)lastByte & 15);
     s32 pos = p0; // position of the current round's first byte
 
@@ -856,7 +874,7 @@ SQ_DEVFN void cert_compute(MatchState& ms) {
         u32 n;
     };
     auto judge = [&](u32 p, u32 vp, sq_v2u e, bool valid, u32& v0, u32& v1) {
-        u32 const t = ht_dec(ms, e.x);
+        u32 const t = ht_dec_g(cx.genBits, e.x);
         if (valid && t) {
             u32 const sw = t & SQZ_HT_IDX;
             if (p < sw && vp == e.y) note(sw, v0, v1);
@@ -937,7 +955,6 @@ SQ_DEVFN void cert_compute(MatchState& ms) {
     };
     // a round of the pipelined part; returns false when the pipelined segment is over
     auto round = [&](sq_v4u w, sq_v4u wn, Slot& sl) -> bool {
-        PROF_T0(t_s1);
         u32 d4;
         u32 cm = testRound(w, wn, pos, d4);
         s32 const lo = pos + (s32)(16 * lane);
@@ -957,8 +974,6 @@ SQ_DEVFN void cert_compute(MatchState& ms) {
             cnt += (u32)__popcll(m);
         }
         wv_fence();
-        PROF_ADD(26, t_s1);
-        PROF_T0(t_s2);
         judgeSlot(sl); // filled 5 rounds ago
         if (cnt > 128) { // cannot happen outside the dense zones with a working filter: stay conservative
             u32 const cut = (u32)(pos < (s32)SQZ_WINDOW_START ? (s32)SQZ_WINDOW_START : pos) + 1;
@@ -974,7 +989,6 @@ SQ_DEVFN void cert_compute(MatchState& ms) {
             sl.v[g] = cand[2 * j + 1];
             sl.e[g] = loadEntry(sl.v[g]);
         }
-        PROF_ADD(27, t_s2);
         pos += 1024;
         return pos < (s32)scanStop() && !isDense(pos);
     };
@@ -1008,7 +1022,7 @@ SQ_DEVFN void cert_compute(MatchState& ms) {
     cand[0] = SQZ_WINDOW_START; // entry 0 is what idle lanes re-read
     cand[1] = 0;
     wv_fence();
-    while (pos < (s32)scanStop()) {
+    while (pos < (s32)scanStop() && !(cx.dbg & 2)) {
         if (isDense(pos)) {
             roundSimple();
             continue;
@@ -1039,6 +1053,7 @@ SQ_DEVFN void cert_compute(MatchState& ms) {
     wv_fence();
 #else
     // scalar twin: same table, same rule
+    for (u32 i = 0; i < SQZ_BLOOM_WORDS; i++) cx.bloom[i] = 0;
     u32 ovfS[SQZ_CERT_OVF_CAP], ovfV[SQZ_CERT_OVF_CAP];
     auto note = [&](u32 sviol) { // a search at sviol may succeed
         if (sviol < blk1)
@@ -1047,35 +1062,32 @@ SQ_DEVFN void cert_compute(MatchState& ms) {
             certEnd1 = sviol < certEnd1 ? sviol : certEnd1;
     };
     for (u32 i = 0; i < nCert; i++) {
-        u32 const sp = cert_pos(ms, i);
+        u32 const sp = cert_pos_t(cx.schedTab, cx.certCnt0, i);
         u32 const v = sq_rd32(base + sp);
         u32 const h = hash4(v, eLog);
-        E[2 * h] = ht_enc(ms, sp); // the last claimant wins
+        u32 const od = ht_dec_g(cx.genBits, E[2 * h]);
+        u32 const oval = E[2 * h + 1];
+        E[2 * h] = ht_enc_g(cx.genBits, sp) | (od ? SQZ_CERT_DUP : 0u); // exchange (+ DUP if it displaced one)
         E[2 * h + 1] = v;
-        vbloom_add(v);
+        vbloom_add(cx.bloom, v);
         if (sq_rd32(base + sp + 1) == v) note(sp);
-    }
-    for (u32 i = 0; i < nCert; i++) {
-        u32 const sp = cert_pos(ms, i);
-        u32 const v = sq_rd32(base + sp);
-        u32 const h = hash4(v, eLog);
-        u32 const t = ht_dec(ms, E[2 * h]);
-        if ((t & SQZ_HT_IDX) != sp) {
-            E[2 * h] = ht_enc(ms, t | SQZ_CERT_DUP);
+        if (od) {
+            u32 const opos = od & SQZ_HT_IDX;
+            if (oval == v) note(opos > sp ? opos : sp);
             if (nOvf < SQZ_CERT_OVF_CAP) {
-                ovfS[nOvf] = sp;
-                ovfV[nOvf] = v;
+                ovfS[nOvf] = opos;
+                ovfV[nOvf] = oval;
                 nOvf++;
             } else
-                note(sp);
+                note(opos);
         }
     }
-    u32 const pEnd = ms.chunkEndPos - 3;
+    u32 const pEnd = cx.chunkEndPos - 3;
     for (u32 p = SQZ_WINDOW_START; p < ((blk1 != 0xFFFFFFFFu) ? certEnd1 : certEnd) && p < pEnd; p++) {
         u32 const vp = sq_rd32(base + p);
-        if (!((g_lds.u.bloom[(vp & 0xFFFFu) >> 5] >> (vp & 31)) & (g_lds.u.bloom[vp >> 21] >> ((vp >> 16) & 31)) & 1u)) continue;
+        if (!((cx.bloom[(vp & 0xFFFFu) >> 5] >> (vp & 31)) & (cx.bloom[vp >> 21] >> ((vp >> 16) & 31)) & 1u)) continue;
         u32 const h = hash4(vp, eLog);
-        u32 const t = ht_dec(ms, E[2 * h]);
+        u32 const t = ht_dec_g(cx.genBits, E[2 * h]);
         if (!t) continue;
         u32 const sw = t & SQZ_HT_IDX;
         if (p < sw && vp == E[2 * h + 1]) note(sw);
@@ -1084,12 +1096,34 @@ SQ_DEVFN void cert_compute(MatchState& ms) {
                 if (vp == ovfV[k] && p < ovfS[k]) note(ovfS[k]);
     }
 #endif
-    ms.certEnd = certEnd;
-    ms.certEnd1 = (blk1 != 0xFFFFFFFFu) ? certEnd1 : 0u;
-    SQ_TRACE(40, certEnd);
-    SQ_TRACE(41, nOvf);
-    SQ_TRACE(42, ms.certEnd1);
+    cx.certEnd = certEnd;
+    cx.certEnd1 = (blk1 != 0xFFFFFFFFu) ? certEnd1 : 0u;
+    cx.nOvf = nOvf;
 }
+
+// the compressor's own use: table in the chain-table area, LDS pieces of the match-finding phase
+SQ_DEVFN void cert_compute(MatchState& ms) {
+    CertCtx cx;
+    cx.base = ms.base;
+    cx.E = ms.chainTable;
+    cx.eLog = ms.cp.chainLog - 1;
+    cx.genBits = ms.genBits;
+    cx.schedTab = ms.schedTab;
+    cx.certCnt0 = ms.certCnt0;
+    cx.nCert = ms.nCert;
+    cx.chunkEndPos = ms.chunkEndPos;
+    cx.bloom = (SQ_L u32*)g_lds.u.bloom;
+    cx.cand = (SQ_L u32*)g_lds.grp;
+    cx.ovf = (SQ_L u32*)&g_lds.ent[ms.nxEnt & 1];
+    cx.dbg = 0;
+    cert_compute_core(cx);
+    ms.certEnd = cx.certEnd;
+    ms.certEnd1 = cx.certEnd1;
+    SQ_TRACE(40, cx.certEnd);
+    SQ_TRACE(41, cx.nOvf);
+    SQ_TRACE(42, cx.certEnd1);
+}
+
 
 // Block 1 was certified under the assumption that it starts with repcode offset 1.  When block 0
 // ended with another offset (it had a match), redo the repcode test of block 1's scheduled

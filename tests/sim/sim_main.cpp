@@ -25,7 +25,7 @@ extern "C" size_t sim_compress_chunk(const uint8_t* src, size_t n, uint8_t* dst,
     memset(&sqz::g_lds, poison ? 0x5A : 0, sizeof(sqz::g_lds));
     u8* wsa = (u8*)(((uintptr_t)ws + 255) & ~(uintptr_t)255);
     sqz::TableGen tg = {0, 0};
-    u32 r = sqz::compress_frame_wave(src, (u32)n, dst, (u32)cap, wsa, L, tg, sched_tab());
+    u32 r = sqz::compress_frame_wave(src, (u32)n, dst, (u32)cap, wsa, L, tg, sched_tab(), nullptr);
     if (getenv("SQ_SIM_STATS")) {
         const u32* t = (const u32*)(wsa + L.dummy) + 8;
         fprintf(stderr, "[sim] n=%zu eager=%u repairs=%u live=%u skips=%u epochs=%u specfail=%u replays=%u certified=%u lastblock_skipped_live=%u\n", n, t[30],
@@ -52,7 +52,38 @@ extern "C" size_t sim_compress_persistent(const uint8_t* src, size_t n, uint8_t*
     }
     u8* wsa = (u8*)(((uintptr_t)g_ws + 255) & ~(uintptr_t)255);
     sqz::WsLayout L = sqz::ws_layout((u32)n); // per-chunk layout inside the pool slot, as compress_one does
-    return sqz::compress_frame_wave(src, (u32)n, dst, (u32)cap, wsa, L, g_tg, sched_tab());
+    return sqz::compress_frame_wave(src, (u32)n, dst, (u32)cap, wsa, L, g_tg, sched_tab(), nullptr);
 }
+// The incompressible-chunk path (sq_zstd_fast.h) followed, when it leaves the chunk undecided, by the
+// compressor with the certificate ends it computed -- the two-kernel sequence of sq_compress_batch.
+// *decided = 1 when the fast path produced the frame.
+extern "C" size_t sim_compress_two_stage(const uint8_t* src, size_t n, uint8_t* dst, size_t cap, int* decided) {
+    static sqz::FastLds lds;
+    static u32* etab = nullptr;
+    static u32 gen = 0;
+    if (!etab) {
+        etab = (u32*)malloc(2u << 20);
+        memset(etab, 0, 2u << 20);
+    }
+    if (++gen >= SQZ_HT_GEN_MAX) {
+        memset(etab, 0, 2u << 20);
+        gen = 1;
+    }
+    memset(&lds, 0x77, sizeof(lds));
+    u32 hint[2] = {0x55555555u, 0x55555555u};
+    u32 r = sqz::fastpath_frame_wave(src, (u32)n, dst, (u32)cap, etab, gen << SQZ_HT_GEN_SHIFT, sched_tab(), &lds, hint);
+    *decided = r != 0;
+    if (r) return r;
+    sqz::WsLayout L = sqz::ws_layout((u32)n);
+    u8* ws = (u8*)malloc(L.total + 256 + 1024);
+    memset(ws, 0xA5, L.total + 256 + 1024);
+    memset(&sqz::g_lds, 0x5A, sizeof(sqz::g_lds));
+    u8* wsa = (u8*)(((uintptr_t)ws + 255) & ~(uintptr_t)255);
+    sqz::TableGen tg = {0, 0};
+    r = sqz::compress_frame_wave(src, (u32)n, dst, (u32)cap, wsa, L, tg, sched_tab(), hint);
+    free(ws);
+    return r;
+}
+extern "C" size_t sim_fast_lds_bytes(void) { return sizeof(sqz::FastLds); }
 extern "C" size_t sim_workspace_bytes(size_t n) { return sqz::workspace_bytes((u32)n); }
 extern "C" size_t sim_lds_bytes(void) { return sizeof(sqz::LdsState); }

@@ -51,6 +51,21 @@ class OracleStages:
         off[len(lens)] = pos
         return off
 
+    def compress_device_slots(self, data, offs, lens, select, comp):
+        """slots layout (sq_compress_batch_slots): frame i stays at its slot offset"""
+        d = data.numpy()
+        off = np.zeros(len(lens), dtype=np.uint64)
+        ln = np.zeros(len(lens), dtype=np.uint32)
+        pos = 0
+        for i, (o_, l_) in enumerate(zip(offs, lens)):
+            off[i] = pos
+            if select[i]:
+                f = self.o.compress_chunk(d[int(o_):int(o_) + int(l_)].tobytes())
+                comp[pos:pos + len(f)] = torch.frombuffer(bytearray(f), dtype=torch.uint8)
+                ln[i] = len(f)
+            pos += (int(l_) + (int(l_) >> 8) + 64 + 32 + 15) // 16 * 16
+        return off, ln
+
 
 def _make_chunks():
     sys.path.insert(0, os.path.join(ROOT, "tools"))
@@ -76,10 +91,17 @@ def _worker(rank, world, port, q):
     data = torch.frombuffer(bytearray(b"".join(mine)), dtype=torch.uint8)
     hashes = torch.zeros(n * 16, dtype=torch.uint8)
     is_new = torch.zeros(n, dtype=torch.uint8)
-    comp = torch.zeros(int(lens.sum()) + 4096, dtype=torch.uint8)
+    comp = torch.zeros(int(lens.sum()) + 4096 + 128 * n, dtype=torch.uint8)
     st = OracleStages()
     p = ShardedPacker(st)
     coff = p.pack(data, offs, lens, hashes, is_new, comp)
+    # the same batch again through the slots layout (bench.py's default) on a fresh dedup set
+    st2 = OracleStages()
+    is_new2 = torch.zeros(n, dtype=torch.uint8)
+    soff, slen = ShardedPacker(st2).pack(data, offs, lens, hashes, is_new2, comp, layout="slots")
+    assert is_new2.tolist() == is_new.tolist()
+    assert [int(x) for x in slen] == [int(coff[j + 1] - coff[j]) for j in range(n)]
+    assert all(int(soff[j + 1]) >= int(soff[j]) + int(slen[j]) for j in range(n - 1))
     q.put((rank, first, is_new.tolist(), len(st.seen), [int(x) for x in coff]))
     dist.barrier()
     dist.destroy_process_group()

@@ -89,3 +89,34 @@ def test_sim_no_match_certificate_handover(sim, oracle, variant, seed, n):
     with the tree state libzstd would have (deferred searches replayed)."""
     d = corpus.planted(seed, n, variant)
     assert _sim_compress(sim, d) == oracle.compress_chunk(d)
+
+
+TWO_STAGE = ([("random", s, n) for s, n in ((0, 262144), (1, 200000), (2, 131072), (3, 70000), (4, 40960), (5, 40959),
+                                            (6, 131072 + 40960), (7, 131072 + 40959), (8, 16385), (9, 300000))]
+             + [("planted%d" % v, 1, 262144) for v in range(10)]
+             + [(k, 2, n) for k in ("text", "mixed", "skewed", "zeros", "runs", "records") for n in (50000, 262144)])
+
+
+@pytest.mark.parametrize("kind,seed,n", TWO_STAGE)
+def test_sim_incompressible_kernel_then_compressor(sim, oracle, kind, seed, n):
+    """The two-kernel sequence of sq_compress_batch: the incompressible-chunk path either produces
+    the whole frame (then it must be the oracle's) or hands its certificate ends to the compressor."""
+    sim.sim_compress_two_stage.restype = ctypes.c_size_t
+    sim.sim_compress_two_stage.argtypes = [ctypes.c_char_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_size_t,
+                                           ctypes.POINTER(ctypes.c_int)]
+    d = corpus.make(kind, seed, n)
+    cap = n + (n >> 8) + 1024
+    dst = ctypes.create_string_buffer(cap)
+    decided = ctypes.c_int(0)
+    r = sim.sim_compress_two_stage(d, n, dst, cap, ctypes.byref(decided))
+    assert dst.raw[:r] == oracle.compress_chunk(d)
+    if kind == "random" and n >= 40960 and (n <= 131072 or n - 131072 >= 40960) and n <= 262144:
+        # no planted repeat: decided here unless a 4-byte coincidence hit a searched position
+        assert decided.value in (0, 1)
+    if kind in ("text", "zeros", "runs", "records") or n > 262144 or n < 40960:
+        assert decided.value == 0
+
+
+def test_fast_kernel_lds_allows_16_waves_per_cu(sim):
+    sim.sim_fast_lds_bytes.restype = ctypes.c_size_t
+    assert sim.sim_fast_lds_bytes() * 14 <= 160 * 1024
