@@ -24,6 +24,7 @@ struct FastLds {
     u32 bloom[SQZ_BLOOM_WORDS]; // certificate Bloom filter; afterwards the 256-bin sample histograms
     u32 cand[256];
     u32 ovf[2 * SQZ_CERT_OVF_CAP];
+    u32 lvl[2 * SQZ_SCHEDLVL_N]; // level words of the two schedules (copied once per wave)
 };
 
 #define SQZ_FAST_MIN_BLOCK (4096u * 10u) // HUF's sampled pre-check needs srcSize >= 10 samples
@@ -91,6 +92,7 @@ SQ_DEVFN u32 fastpath_frame_wave(const u8* src, u32 n, u8* dst, u32 cap, u32* E,
         cx.bloom = (SQ_L u32*)L->bloom;
         cx.cand = (SQ_L u32*)L->cand;
         cx.ovf = (SQ_L u32*)L->ovf;
+        cx.lvl = (SQ_L u32*)L->lvl;
         cx.certEnd = cx.certEnd1 = 0;
         if (cx.nCert > 0) {
             cx.dbg = dbg;
@@ -142,6 +144,8 @@ k_incompressible_batch(const u8* data, const u64* off, const u32* len, const u8*
                        u32* queue, const u32* schedTab, u32 dbg) {
     __shared__ FastLds lds;
     u32* const E = (u32*)(etab_pool + (u64)blockIdx.x * etab_bytes);
+    for (u32 i = wv_lane(); i < 2 * SQZ_SCHEDLVL_N; i += 64) lds.lvl[i] = schedTab[SQZ_SCHEDLVL_OFF + i];
+    __builtin_amdgcn_s_waitcnt(0);
     u32 gen = 0; // 0: the table holds unknown words
     for (;;) {
         u32 idx = 0;

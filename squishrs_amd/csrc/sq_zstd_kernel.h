@@ -118,6 +118,15 @@ SQ_HD void sched_tab_fill(u32* tab) {
             p += (p >> 8) + 1;
         }
         tab[variant] = n;
+        // level words: smallest scheduled position >= 256 k | ceil(65536 / (k + 1)) << 17
+        u32* const lv = tab + SQZ_SCHEDLVL_OFF + variant * SQZ_SCHEDLVL_N;
+        u32 j = 0;
+        for (u32 k = 0; k < SQZ_SCHEDLVL_N; k++) {
+            while (j < n && e[j] < (k << 8)) j++;
+            u32 const first = (j < n) ? e[j] : 0x1FFFFu;
+            u32 const R = (65536u + k) / (k + 1);
+            lv[k] = first | ((R > 0x7FFFu ? 0x7FFFu : R) << 17);
+        }
     }
 }
 

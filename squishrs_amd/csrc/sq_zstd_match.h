@@ -467,7 +467,12 @@ SQ_DEVFN void dubt_replay(MatchState& ms, u32 to) {
 // byte into the frame's first block) and "later"; a shorter block uses a prefix.  Layout (u32):
 // [0] entries of "first", [1] entries of "later", then the two tables, SQZ_SCHEDTAB_N slots each.
 #define SQZ_SCHEDTAB_N 2048u
-#define SQZ_SCHEDTAB_WORDS (2u + 2u * SQZ_SCHEDTAB_N)
+// ... followed by one word per 256-byte level k (512 levels) of each table: the smallest scheduled
+// relative position >= 256 k (17 bits, 0x1FFFF = none) | ceil(65536 / (k + 1)) << 17, which lets a
+// lane decide with two multiplications whether one of its 16 positions is a scheduled one.
+#define SQZ_SCHEDLVL_N 512u
+#define SQZ_SCHEDLVL_OFF (2u + 2u * SQZ_SCHEDTAB_N)
+#define SQZ_SCHEDTAB_WORDS (SQZ_SCHEDLVL_OFF + 2u * SQZ_SCHEDLVL_N)
 
 // number of table entries < limit (entries ascending); whole wave, ~28 coalesced loads per lane
 SQ_DEVFN u32 sched_count(const u32* const entries, u32 const nEntries, u32 const limit) {
@@ -740,6 +745,9 @@ struct CertCtx {
     SQ_L u32* cand;      // 256 words              (LDS)
     SQ_L u32* ovf;       // 2 * SQZ_CERT_OVF_CAP   (LDS)
     u32 certEnd, certEnd1, nOvf; // results
+    SQ_L u32* lvl;       // 2 * SQZ_SCHEDLVL_N level words in LDS, or nullptr: when given, the scan leaves
+                         // the scheduled positions themselves out (their mutual repeats are found
+                         // while the table is built)
     u32 dbg;             // timing experiments (SQ_FAST_DBG): 1 = no build, 2 = no scan, 8 = build without the exchange
 };
 
@@ -829,6 +837,23 @@ SQ_DEVFN void cert_compute_core(CertCtx& cx) {
     }
     if (nOvf > SQZ_CERT_OVF_CAP) nOvf = SQZ_CERT_OVF_CAP;
     wv_mem_sync();
+    // scheduled positions with equal bytes that were not neighbours in a displacement chain: every
+    // displaced entry against the entry that now sits in its slot and against the other displaced ones
+    if (nOvf) {
+        for (u32 k0 = 0; k0 < nOvf; k0 += 64) {
+            u32 const k = k0 + lane;
+            if (k < nOvf) {
+                u32 const so = ovf[2 * k], vo = ovf[2 * k + 1];
+                u64 const raw = __hip_atomic_load((const SQ_G u64*)(E + 2 * hash4(vo, eLog)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                u32 const t = ht_dec_g(cx.genBits, (u32)raw);
+                if (t && (u32)(raw >> 32) == vo) note((t & SQZ_HT_IDX) > so ? (t & SQZ_HT_IDX) : so, vmin, vmin1);
+                for (u32 j = 0; j < nOvf; j++) {
+                    u32 const sj = ovf[2 * j], vj = ovf[2 * j + 1];
+                    if (j != k && vj == vo) note(sj > so ? sj : so, vmin, vmin1);
+                }
+            }
+        }
+    }
     auto settle = [&](u32 v0, u32 v1) { // wave minima of the violations -> certEnd / certEnd1
         if (wv_ballot((v0 & v1) != 0xFFFFFFFFu)) {
             u32 x = v0, z = v1;
@@ -953,11 +978,28 @@ SQ_DEVFN void cert_compute_core(CertCtx& cx) {
         settle(v0, v1);
         sl.n = 0;
     };
+    // The (at most one, outside the dense zones) scheduled position among a lane's 16, as a bit mask.
+    auto schedMask = [&](s32 lo) -> u32 {
+        bool const second = (blk1 != 0xFFFFFFFFu) && lo >= (s32)blk1;
+        u32 const r = (u32)(lo - (s32)(second ? blk1 : SQZ_WINDOW_START)); // relative to the block start
+        u32 const k = r >> 8;
+        u32 const wd = cx.lvl[(second ? SQZ_SCHEDLVL_N : 0u) + (k < SQZ_SCHEDLVL_N ? k : SQZ_SCHEDLVL_N - 1)];
+        u32 const first = wd & 0x1FFFFu, R = wd >> 17, step = k + 1;
+        // first scheduled position >= r: first + ceil((r - first) / step) * step
+        u32 const x = r > first ? r - first : 0u;
+        u32 const q = (x * R) >> 16; // floor(x / step), exact for x < 256 and step >= 17
+        u32 const m = x - q * step;
+        u32 const nxt = (r > first ? r : first) + (m ? step - m : 0u);
+        bool const ok = lo >= (s32)SQZ_WINDOW_START && k >= 16 && (r & 255) <= 240 && nxt < r + 16 && nxt < ((k + 1) << 8) &&
+                        first != 0x1FFFFu;
+        return ok ? 1u << (nxt - r) : 0u;
+    };
     // a round of the pipelined part; returns false when the pipelined segment is over
     auto round = [&](sq_v4u w, sq_v4u wn, Slot& sl) -> bool {
         u32 d4;
         u32 cm = testRound(w, wn, pos, d4);
         s32 const lo = pos + (s32)(16 * lane);
+        if (cx.lvl) cm &= ~schedMask(lo);
         u32 cnt = 0;
         for (;;) { // compaction: one candidate per lane and turn
             u64 const m = wv_ballot(cm != 0);
@@ -1082,8 +1124,24 @@ SQ_DEVFN void cert_compute_core(CertCtx& cx) {
                 note(opos);
         }
     }
+    // (closure over the displaced entries, as on the device)
+    for (u32 k = 0; k < nOvf; k++) {
+        u32 const h = hash4(ovfV[k], eLog);
+        u32 const t = ht_dec_g(cx.genBits, E[2 * h]);
+        if (t && E[2 * h + 1] == ovfV[k]) note((t & SQZ_HT_IDX) > ovfS[k] ? (t & SQZ_HT_IDX) : ovfS[k]);
+        for (u32 j = 0; j < nOvf; j++)
+            if (j != k && ovfV[j] == ovfV[k]) note(ovfS[j] > ovfS[k] ? ovfS[j] : ovfS[k]);
+    }
     u32 const pEnd = cx.chunkEndPos - 3;
     for (u32 p = SQZ_WINDOW_START; p < ((blk1 != 0xFFFFFFFFu) ? certEnd1 : certEnd) && p < pEnd; p++) {
+        if (cx.lvl) { // leave the scheduled positions themselves out (outside the dense block starts)
+            bool const second = (blk1 != 0xFFFFFFFFu) && p >= blk1;
+            u32 const r = p - (second ? blk1 : SQZ_WINDOW_START), k = r >> 8;
+            if (k >= 16 && k < SQZ_SCHEDLVL_N) {
+                u32 const first = cx.lvl[(second ? SQZ_SCHEDLVL_N : 0u) + k] & 0x1FFFFu;
+                if (first != 0x1FFFFu && r >= first && (r - first) % (k + 1) == 0) continue;
+            }
+        }
         u32 const vp = sq_rd32(base + p);
         if (!((cx.bloom[(vp & 0xFFFFu) >> 5] >> (vp & 31)) & (cx.bloom[vp >> 21] >> ((vp >> 16) & 31)) & 1u)) continue;
         u32 const h = hash4(vp, eLog);
@@ -1115,6 +1173,7 @@ SQ_DEVFN void cert_compute(MatchState& ms) {
     cx.bloom = (SQ_L u32*)g_lds.u.bloom;
     cx.cand = (SQ_L u32*)g_lds.grp;
     cx.ovf = (SQ_L u32*)&g_lds.ent[ms.nxEnt & 1];
+    cx.lvl = nullptr; // no LDS to spare here
     cx.dbg = 0;
     cert_compute_core(cx);
     ms.certEnd = cx.certEnd;

@@ -70,6 +70,7 @@ extern "C" size_t sim_compress_two_stage(const uint8_t* src, size_t n, uint8_t* 
         gen = 1;
     }
     memset(&lds, 0x77, sizeof(lds));
+    memcpy(lds.lvl, sched_tab() + SQZ_SCHEDLVL_OFF, sizeof(lds.lvl));
     u32 hint[2] = {0x55555555u, 0x55555555u};
     u32 r = sqz::fastpath_frame_wave(src, (u32)n, dst, (u32)cap, etab, gen << SQZ_HT_GEN_SHIFT, sched_tab(), &lds, hint);
     *decided = r != 0;

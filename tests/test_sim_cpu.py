@@ -117,6 +117,6 @@ def test_sim_incompressible_kernel_then_compressor(sim, oracle, kind, seed, n):
         assert decided.value == 0
 
 
-def test_fast_kernel_lds_allows_16_waves_per_cu(sim):
+def test_fast_kernel_lds_allows_11_waves_per_cu(sim):
     sim.sim_fast_lds_bytes.restype = ctypes.c_size_t
-    assert sim.sim_fast_lds_bytes() * 14 <= 160 * 1024
+    assert sim.sim_fast_lds_bytes() * 11 <= 160 * 1024
