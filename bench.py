@@ -25,16 +25,17 @@ sys.path.insert(0, os.path.join(ROOT, "tools"))
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 
-def _pmc_traffic(n, L):
-    """HBM traffic of one k_compress_batch launch (bytes), from the committed rocprofv3 PMC passes
-    (FETCH_SIZE and WRITE_SIZE collected in separate runs of this same script, see
-    tools/profile_r1.sh and profiles/): counters cannot be read from inside the process.  None when
-    no committed measurement matches this workload."""
+def _pmc_traffic(kernel, n, L):
+    """HBM traffic of one launch of `kernel` (bytes), from the committed rocprofv3 PMC passes
+    (FETCH_SIZE and WRITE_SIZE collected in separate runs of this same script on fewer chunks of the
+    same workload, see tools/profile_r1.sh, tools/pmc_summary.py and profiles/), scaled linearly to n
+    chunks: counters cannot be read from inside the process.  None when no committed measurement
+    matches this kernel and chunk size."""
     try:
         with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
             t = json.load(f)
-        e = t.get(f"{n}x{L}")
-        return None if e is None else float(e["fetch_bytes"] + e["write_bytes"])
+        e = t.get(f"{kernel}@{L}")
+        return None if e is None else float(e["fetch_bytes_per_chunk"] + e["write_bytes_per_chunk"]) * n
     except (OSError, ValueError, KeyError):
         return None
 
@@ -145,15 +146,27 @@ def main():
         value = world * n * L / 2**20 / (ms_per_step / 1e3)
         cms = float(np.mean(kern["compress"]))
         hms = float(np.mean(kern["hash"]))
-        # algorithmic bytes of the dominant kernel (compress stage): unique input read once +
-        # frames written once (SURVEY.md 8d "compress-only")
-        comp_bytes = n * L + clen_total
+        # The compress stage is two kernels: stage 1 (k_incompressible_batch) looks at every new
+        # chunk once and writes the frames it can decide; stage 2 (k_compress_batch) does the rest.
+        # Algorithmic bytes (SURVEY.md 8d "compress-only"): every unique input byte read once +
+        # every frame byte written once, attributed to the kernel that produced the frame.
+        fms = float(np.mean(kern["fast"]))
+        decided = int(store.timings().fast_decided)
+        frame_avg = clen_total / max(1, int(unique if world == 1 else n))
+        fast_bytes = n * L + decided * frame_avg
+        slow_bytes = (n - decided) * (L + frame_avg)
         hash_bytes = n * L + 16 * n
         bw_probe_ms = min(store.read_bw_ms(data) for _ in range(3))
-        roof = {"bound": "hbm", "kernel": "sqz::k_compress_batch",
-                "achieved": comp_bytes / (cms / 1e3) / 1e9, "peak": 8000.0, "unit": "GB/s",
-                "frac": comp_bytes / (cms / 1e3) / 1e9 / 8000.0, "traffic": _pmc_traffic(n, L),
-                "kernel_ms": cms, "fast_kernel_ms": float(np.mean(kern["fast"])),
+        stages = {"sqz::k_incompressible_batch": (fms, fast_bytes), "sqz::k_compress_batch": (cms, slow_bytes)}
+        dom = max(stages, key=lambda k: stages[k][0])
+        dms, dbytes = stages[dom]
+        roof = {"bound": "hbm", "kernel": dom,
+                "achieved": dbytes / (dms / 1e3) / 1e9, "peak": 8000.0, "unit": "GB/s",
+                "frac": dbytes / (dms / 1e3) / 1e9 / 8000.0, "traffic": _pmc_traffic(dom, n, L),
+                "kernel_ms": dms,
+                "compress_stage": {"k_incompressible_batch_ms": fms, "k_compress_batch_ms": cms,
+                                   "chunks_decided_by_stage1": decided,
+                                   "stage_GBps": (n * L + clen_total) / ((fms + cms) / 1e3) / 1e9},
                 "hash_kernel": {"kernel": "sqx::k_xxh3_128_batch", "ms": hms,
                                 "achieved": hash_bytes / (hms / 1e3) / 1e9,
                                 "frac": hash_bytes / (hms / 1e3) / 1e9 / 8000.0},

@@ -134,6 +134,7 @@ int sq_calibrate_read_bw(sq_ctx* ctx, const uint8_t* d_buf, uint64_t nbytes, flo
 typedef struct sq_timings {
     float hash_ms, dedup_ms, compress_ms, compact_ms;
     float fast_ms; /* incompressible-chunk kernel (stage 1 of the compress stage); compress_ms = stage 2 */
+    uint32_t fast_decided; /* chunks whose frame stage 1 produced in the most recent compress stage */
 } sq_timings;
 int sq_last_timings(sq_ctx* ctx, sq_timings* out);
 

@@ -84,7 +84,7 @@ struct sq_ctx {
     void* h_pinned = nullptr; // small pinned host mirror (total sizes etc.)
     u32* d_sched_tab = nullptr; // constant no-match schedule tables of the compressor (sched_tab_fill)
 
-    sq_timings last = {0, 0, 0, 0, 0};
+    sq_timings last = {0, 0, 0, 0, 0, 0};
 };
 
 static bool is_device_ptr(const void* p) {
@@ -474,9 +474,11 @@ static int compress_async(sq_ctx* c, const u8* d_data, const u64* h_off, const u
     }
     u32* h_err = (u32*)c->h_pinned;
     HIPCHK(hipMemcpyAsync(h_err, (u32*)c->b_misc.p + 16, 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipMemcpyAsync(h_err + 1, (u32*)c->b_misc.p + 33, 4, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
     HIPCHK(hipEventElapsedTime(&c->last.compress_ms, c->ev[4], c->ev[5]));
     if (fast) HIPCHK(hipEventElapsedTime(&c->last.fast_ms, c->ev[8], c->ev[9]));
+    c->last.fast_decided = fast ? h_err[1] : 0;
 #ifdef SQ_PROF
     {   // profiling build: sum the per-wave phase timers (100 MHz ticks) and print them
         std::vector<unsigned long long> tot(33, 0), one(33);

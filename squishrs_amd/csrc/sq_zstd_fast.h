@@ -141,7 +141,7 @@ SQ_DEVFN u32 fastpath_frame_wave(const u8* src, u32 n, u8* dst, u32 cap, u32* E,
 __global__ void __launch_bounds__(64, 4)
 k_incompressible_batch(const u8* data, const u64* off, const u32* len, const u8* select, u32 n, u8* slots,
                        const u64* slot_off, u32* frame_len, u32* cert_out, u8* etab_pool, u64 etab_bytes,
-                       u32* queue, const u32* schedTab, u32 dbg) {
+                       u32* queue, const u32* schedTab, u32 dbg) { // queue[1]: number of chunks decided here
     __shared__ FastLds lds;
     u32* const E = (u32*)(etab_pool + (u64)blockIdx.x * etab_bytes);
     for (u32 i = wv_lane(); i < 2 * SQZ_SCHEDLVL_N; i += 64) lds.lvl[i] = schedTab[SQZ_SCHEDLVL_OFF + i];
@@ -167,7 +167,10 @@ k_incompressible_batch(const u8* data, const u64* off, const u32* len, const u8*
             cert_out[2 * (size_t)idx] = 0;
             cert_out[2 * (size_t)idx + 1] = 0;
         }
-        if (wv_lane() == 0) frame_len[idx] = r;
+        if (wv_lane() == 0) {
+            frame_len[idx] = r;
+            if (r) atomicAdd(queue + 1, 1u);
+        }
     }
 }
 #endif

@@ -548,8 +548,47 @@ SQ_DEV void filter_add_skip(MatchState& ms, u32 from, u32 to) {
     ms.nSkip++;
 }
 
+// filter_predict through the tables, for the two states the parser is in when a prediction is
+// needed after a hand-over or a match: `pos` is a scheduled position of its block's own table
+// (anchor = chunk start) or of the "later" table laid at the anchor (after a sequence ip == anchor).
+// Returns the number of predicted positions, or 0xFFFFFFFF when (pos, anc) is not on such a lattice.
+SQ_DEVFN u32 filter_predict_tab(MatchState& ms, u32 pos, u32 anc, u32* const sched) {
+    bool const firstVar = anc == SQZ_WINDOW_START;
+    const u32* const ent = ms.schedTab + 2 + (firstVar ? 0u : SQZ_SCHEDTAB_N);
+    u32 const nEnt = gld32(ms.schedTab + (firstVar ? 0 : 1));
+    u32 const rel = pos - anc;
+    u32 const j0 = sched_count(ent, nEnt, rel);
+    if (j0 >= nEnt || gld32(ent + j0) != rel) return 0xFFFFFFFFu;
+    u32 const lim0 = ms.blockEndPos - 8 - anc; // scheduled while anc + rel < blockEnd - 8
+    u32 const j1 = sched_count(ent, nEnt, lim0);
+    u32 const cnt0 = j1 > j0 ? j1 - j0 : 0u;
+    // at most one more block in a chunk of this strategy
+    u32 cnt1 = 0;
+    u32 const b1 = ms.blockEndPos;
+    const u32* const later = ms.schedTab + 2 + SQZ_SCHEDTAB_N;
+    if (b1 < ms.chunkEndPos) {
+        u32 const len1 = (ms.chunkEndPos - b1 < SQZ_BLOCKSIZE_MAX) ? ms.chunkEndPos - b1 : SQZ_BLOCKSIZE_MAX;
+        if (b1 + len1 < ms.chunkEndPos) return 0xFFFFFFFFu; // a third block: let the serial loop do it
+        if (len1 >= 9) cnt1 = sched_count(later, gld32(ms.schedTab + 1), len1 - 8);
+    }
+    if (cnt0 + cnt1 >= SQZ_SCHED_CAP) return 0xFFFFFFFFu;
+#if SQ_ON_DEVICE
+    for (u32 i = wv_lane(); i < cnt0; i += 64) sq_gst32(sched + i, anc + sq_gld32(ent + j0 + i));
+    for (u32 i = wv_lane(); i < cnt1; i += 64) sq_gst32(sched + cnt0 + i, b1 + sq_gld32(later + i));
+    wv_mem_sync();
+#else
+    for (u32 i = 0; i < cnt0; i++) sched[i] = anc + ent[j0 + i];
+    for (u32 i = 0; i < cnt1; i++) sched[cnt0 + i] = b1 + later[i];
+#endif
+    return cnt0 + cnt1;
+}
+
 // The lazy parser's no-match search schedule from (pos, anchor) to the end of the chunk.
 SQ_DEVFN u32 filter_predict(MatchState& ms, u32 pos, u32 anc, u32* const sched) {
+    {
+        u32 const nt = filter_predict_tab(ms, pos, anc, sched);
+        if (nt != 0xFFFFFFFFu) return nt;
+    }
     WV_SERIAL {
         u32 n = 0, p = pos, a = anc, bEnd = ms.blockEndPos;
         for (;;) {
@@ -613,31 +652,39 @@ SQ_DEVFN void filter_mark(MatchState& ms, u32 n, bool first) {
         wv_mem_sync();
         return;
     }
-    for (u32 i0 = 0; i0 < total; i0 += 64) {
-        u32 const i = i0 + lane;
-        bool fresh = false;
-        u32 h = 0;
-        if (i < total) {
-            u32 const p = sq_gld32(ms.sched + i / 3) + (i % 3);
-            if (p + 8 <= ms.chunkEndPos) {
-                h = hash4(sq_grd32(ms.base + p), hashLog);
-                u32 const v = ht_dec(ms, sq_tld32(ms.hashTable + h));
-                if (!(v & (SQZ_HT_LIVE | SQZ_HT_PEND))) {
-                    sq_gst32(ms.hashTable + h, ht_enc(ms, v | SQZ_HT_PEND));
-                    fresh = true;
-                }
-            }
+    // 256 per step, every load unconditional (clamped index) so that the dependent loads (schedule ->
+    // bytes -> table word) of the four groups overlap.  A bucket met twice before its PENDING store
+    // has landed is simply listed twice (the list only feeds idempotent passes).
+    u64 const belowm = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+    u32 const iLast = total ? total - 1 : 0u;
+    for (u32 i0 = 0; i0 < total; i0 += 256) {
+        u32 pp[4], hh[4], vv[4];
+#pragma unroll
+        for (u32 g = 0; g < 4; g++) {
+            u32 const i = i0 + 64 * g + lane;
+            u32 const ic = i < total ? i : iLast;
+            pp[g] = sq_gld32(ms.sched + ic / 3) + (ic % 3);
         }
-        u64 const m = wv_ballot(fresh);
-        if (m) {
+#pragma unroll
+        for (u32 g = 0; g < 4; g++) {
+            u32 const pc = pp[g] + 8 <= ms.chunkEndPos ? pp[g] : ms.chunkEndPos - 8;
+            hh[g] = hash4(sq_grd32(ms.base + pc), hashLog);
+        }
+#pragma unroll
+        for (u32 g = 0; g < 4; g++) vv[g] = ht_dec(ms, sq_tld32(ms.hashTable + hh[g]));
+#pragma unroll
+        for (u32 g = 0; g < 4; g++) {
+            bool const fresh = (i0 + 64 * g + lane < total) && (pp[g] + 8 <= ms.chunkEndPos) &&
+                               !(vv[g] & (SQZ_HT_LIVE | SQZ_HT_PEND));
+            u64 const m = wv_ballot(fresh);
             if (fresh) {
-                u32 const r = (u32)__popcll(m & ((lane == 0) ? 0ull : (~0ull >> (64 - lane))));
-                sq_gst32(ms.liveList + ms.nLive + r, h);
-                bloom_add(h);
+                sq_gst32(ms.hashTable + hh[g], ht_enc(ms, vv[g] | SQZ_HT_PEND));
+                sq_gst32(ms.liveList + ms.nLive + (u32)__popcll(m & belowm), hh[g]);
+                bloom_add(hh[g]);
             }
             ms.nLive += (u32)__popcll(m);
-            wv_mem_sync();
         }
+        wv_mem_sync();
     }
 #else
     for (u32 i = 0; i < total; i++) {

@@ -26,13 +26,14 @@ for kind, cname in (("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE")):
             if k.startswith("sq") and r["Counter_Name"] == cname:
                 out["kernels"][k][cname] = out["kernels"][k].get(cname, 0.0) + float(r["Counter_Value"])
 json.dump(out, open(os.path.join(ROOT, "profiles", f"{tag}_pmc.json"), "w"), indent=1)
-ck = out["kernels"].get("sqz::k_compress_batch")
-if ck and "FETCH_SIZE" in ck and "WRITE_SIZE" in ck:
-    p = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-    t = json.load(open(p)) if os.path.exists(p) else {}
-    t[f"{n}x{L}"] = {"fetch_bytes": ck["FETCH_SIZE"] * 1024 / launches, "write_bytes": ck["WRITE_SIZE"] * 1024 / launches,
-                     "source": f"profiles/{tag}_pmc.json", "launches": launches,
-                     "note": "per k_compress_batch launch; FETCH_SIZE uncorrected (the kernel mixes streaming reads, "
-                             "counted at half, with 4-8 byte gathers)"}
-    json.dump(t, open(p, "w"), indent=1)
-    print(json.dumps(t[f"{n}x{L}"]))
+p = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+t = {}
+for k, ck in out["kernels"].items():
+    if "FETCH_SIZE" in ck and "WRITE_SIZE" in ck and k.startswith("sqz::"):
+        t[f"{k}@{L}"] = {"fetch_bytes_per_chunk": ck["FETCH_SIZE"] * 1024 / launches / n,
+                         "write_bytes_per_chunk": ck["WRITE_SIZE"] * 1024 / launches / n,
+                         "measured_on_chunks": n, "source": f"profiles/{tag}_pmc.json",
+                         "note": "FETCH_SIZE uncorrected (streaming reads are counted at half on gfx950; these "
+                                 "kernels mix them with 4-8 byte gathers and 8-byte atomics)"}
+        print(k, json.dumps(t[f"{k}@{L}"]))
+json.dump(t, open(p, "w"), indent=1)
