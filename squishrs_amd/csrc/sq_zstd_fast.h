@@ -88,6 +88,9 @@ SQ_DEVFN u32 fastpath_frame_wave(const u8* src, u32 n, u8* dst, u32 cap, u32* E,
         cx.certCnt0 = (len0 == SQZ_BLOCKSIZE_MAX) ? full0 : sched_count(schedTab + 2, full0, len0 - 8);
         u32 const cnt1 = (len1 < 9) ? 0u : (len1 == SQZ_BLOCKSIZE_MAX) ? full1 : sched_count(schedTab + 2 + SQZ_SCHEDTAB_N, full1, len1 - 8);
         cx.nCert = cx.certCnt0 + cnt1;
+        cx.base1Pos = SQZ_WINDOW_START + SQZ_BLOCKSIZE_MAX;
+        cx.tabOff1 = 0;
+        cx.repOff = 1;
         cx.chunkEndPos = n + SQZ_WINDOW_START;
         cx.bloom = (SQ_L u32*)L->bloom;
         cx.cand = (SQ_L u32*)L->cand;

@@ -26,7 +26,7 @@ struct Fingerprint {
 
 struct WsLayout {
     size_t hashTable, table2, hashTable3, seqs, lits, llCode, ofCode, mlCode, optState, fp, sched, liveList,
-        skipList, blockTab, dummy, total;
+        skipList, blockTab, certTab, dummy, total;
 };
 
 #if SQ_ON_DEVICE
@@ -39,7 +39,7 @@ SQ_HD size_t ws_align(size_t x) { return (x + 255) & ~(size_t)255; }
 
 SQ_HD WsLayout ws_layout(u32 max_len) {
     // table areas sized for the largest parameters of any chunk length <= max_len
-    size_t hashBytes = 0, t2Bytes = 0;
+    size_t hashBytes = 0, t2Bytes = 0, certBytes = 0;
     const u32 bps[9] = {16u << 10, 32u << 10, 64u << 10, 128u << 10, 256u << 10, 512u << 10, 1u << 20, 2u << 20, max_len};
     for (int i = 0; i < 9; i++) {
         u32 n = bps[i] < max_len ? bps[i] : max_len;
@@ -69,6 +69,8 @@ SQ_HD WsLayout ws_layout(u32 max_len) {
         size_t tb = (strategy == 5) ? ((size_t)1 << hashLog) : (((size_t)4) << chainLog);
         if (hb > hashBytes) hashBytes = hb;
         if (tb > t2Bytes) t2Bytes = tb;
+        // table of a tail certificate (tail_certify): 8 bytes x 2^(chainLog-1), btlazy2 only
+        if (strategy == 6 && ((size_t)8 << (chainLog - 1)) > certBytes) certBytes = (size_t)8 << (chainLog - 1);
     }
     WsLayout L;
     size_t o = 0;
@@ -100,6 +102,8 @@ SQ_HD WsLayout ws_layout(u32 max_len) {
     o += ws_align((size_t)SQZ_SKIP_CAP * 8);
     L.blockTab = o;
     o += ws_align((size_t)SQZ_BLOCKTAB_CAP * 8);
+    L.certTab = o;
+    o += ws_align(certBytes);
     L.dummy = o;
     o += 256;
     L.total = o;
@@ -335,6 +339,7 @@ SQ_DEVFN u32 compressBlock_internal(MatchState& ms, SeqStore& ss, BlockState& bs
 struct TableGen {
     u32 gen;
     u32 windowLog; // size class of the chunk that last cleared / tagged the table
+    u32 tailTabClean; // 1 once the tail-certificate table of this size class has been cleared in this launch
 };
 
 // Returns the frame length, 0 on error.
@@ -401,6 +406,9 @@ SQ_DEVFN u32 compress_frame_wave(const u8* src, u32 n, u8* dst, u32 cap, u8* ws,
     ms.blockTab = (u32*)(ws + L.blockTab);
     ms.schedTab = schedTab;
     ms.certCnt0 = 0;
+    ms.tailTab = (u32*)(ws + L.certTab);
+    ms.tailTabClean = &tg.tailTabClean;
+    ms.tailTried = 0;
     ms.nCert = ms.nCertDone = ms.certEnd = ms.certEnd1 = 0;
     ms.nLive = ms.nSkip = ms.nBlocks = 0;
     ms.specOff = 0;
@@ -409,6 +417,7 @@ SQ_DEVFN u32 compress_frame_wave(const u8* src, u32 n, u8* dst, u32 cap, u8* ws,
     ms.nEpoch = ms.nSpecFail = ms.nReplay = 0;
     SQ_TRACE(0, 2);
     SQ_TRACE(38, 0);
+    SQ_TRACE(39, 0);
     PROF_T0(t_clr);
     ms.genBits = 0;
     if (cp.strategy == STRAT_BTLAZY2) {
@@ -418,6 +427,7 @@ SQ_DEVFN u32 compress_frame_wave(const u8* src, u32 n, u8* dst, u32 cap, u8* ws,
             wv_fill32(ms.chainTable, 0, (size_t)1 << cp.chainLog);
             tg.gen = 0;
             tg.windowLog = cp.windowLog;
+            tg.tailTabClean = 0;
         }
         tg.gen++;
         ms.genBits = tg.gen << SQZ_HT_GEN_SHIFT;
@@ -573,7 +583,7 @@ k_compress_batch(const u8* data, const u64* off, const u32* len, const u8* selec
     u8* const ws = ws_pool + (u64)blockIdx.x * ws_each;
     u32* const dbg = (u32*)(ws + ws_each - 256) + 8; // wave-level progress words for the watchdog
     u32 iter = 0;
-    TableGen tg = {0, 0}; // this wave's hash-table area holds unknown words
+    TableGen tg = {0, 0, 0}; // this wave's hash-table area holds unknown words
 #ifdef SQ_PROF
     if (wv_lane() == 0)
         for (int k = 0; k < 32; k++) g_lds.prof[k] = 0;

@@ -102,6 +102,9 @@ struct MatchState {
     u32 nCertDone;   // leading ones that were skipped as certainly failing
     u32 certEnd;     // every scheduled search of block 0 at a position < certEnd certainly fails; 0 = none
     u32 certEnd1;    // the same for block 1 (given that block 1 starts with repcode offset 1)
+    u32* tailTab;        // table of the tail certificate (workspace; see tail_certify)
+    u32* tailTabClean;   // -> the wave's flag: that table has been cleared in this launch
+    u32 tailTried;       // a tail certificate has been attempted in this chunk
     u32 sbMax;       // current super-batch length of the filtered insertion stream (256..2048)
     u32 genBits;     // btlazy2 hash-table generation tag of this chunk, in place (bits 19..29)
     CParams cp;
@@ -787,6 +790,9 @@ struct CertCtx {
     u32 genBits;         // generation tag of this chunk's entries, in place (bits 19..29)
     const u32* schedTab; // constant no-match schedules
     u32 certCnt0, nCert; // scheduled searches in block 0 / in the chunk
+    u32 base1Pos;        // position the "later" table is laid at (block 1's start; an anchor for a tail certificate)
+    u32 tabOff1;         // first entry of the "later" table that is used
+    u32 repOff;          // repcode offset of the searches' repcode test (1 at the start of a frame)
     u32 chunkEndPos;
     SQ_L u32* bloom;     // SQZ_BLOOM_WORDS words  (LDS)
     SQ_L u32* cand;      // 256 words              (LDS)
@@ -801,6 +807,12 @@ struct CertCtx {
 #define SQZ_CERT_DUP SQZ_HT_PEND // table-word flag: another scheduled position shares this bucket
 #define SQZ_CERT_OVF_CAP 64u
 
+SQ_DEV u32 cert_pos_c(const CertCtx& cx, u32 i) { // position of the i-th scheduled search; one load, no branch
+    bool const first = i < cx.certCnt0;
+    u32 const slot = first ? i : SQZ_SCHEDTAB_N + cx.tabOff1 + (i - cx.certCnt0);
+    return sq_gld32(cx.schedTab + 2 + slot) + (first ? SQZ_WINDOW_START : cx.base1Pos);
+}
+
 SQ_DEVFN void cert_compute_core(CertCtx& cx) {
     // certificate table: 2^eLog entries of (position | generation tag [| DUP], the 4 bytes there),
     // 8 bytes each, in the chain-table area (which the finder only reads through valid heads)
@@ -809,7 +821,7 @@ SQ_DEVFN void cert_compute_core(CertCtx& cx) {
     const u8* const base = cx.base;
     u32 const nCert = cx.nCert;
     // one certificate per block: a match in block 0 changes that block's schedule, not block 1's
-    u32 const blk1 = (nCert > cx.certCnt0) ? SQZ_WINDOW_START + SQZ_BLOCKSIZE_MAX : 0xFFFFFFFFu;
+    u32 const blk1 = (nCert > cx.certCnt0) ? cx.base1Pos : 0xFFFFFFFFu;
     u32 certEnd = cx.chunkEndPos, certEnd1 = cx.chunkEndPos;
     u32 nOvf = 0;
 #if SQ_ON_DEVICE
@@ -839,12 +851,16 @@ SQ_DEVFN void cert_compute_core(CertCtx& cx) {
 #pragma unroll
         for (u32 g = 0; g < 8; g++) {
             u32 const i = i0 + 64 * g + lane;
-            sp[g] = cert_pos_t(cx.schedTab, cx.certCnt0, i < nCert ? i : iLast);
+            sp[g] = cert_pos_c(cx, i < nCert ? i : iLast);
         }
+        // repcode test of the search at s: read32(s + 1 - repOff) == read32(s + 1); for repOff == 1
+        // the left side is the 4 bytes at s themselves
+        u32 vr[8];
 #pragma unroll
         for (u32 g = 0; g < 8; g++) {
             v[g] = sq_grd32(base + sp[g]);
             v1[g] = sq_grd32(base + sp[g] + 1);
+            vr[g] = (cx.repOff > 1) ? sq_grd32(base + sp[g] + 1 - cx.repOff) : v[g];
         }
 #pragma unroll
         for (u32 g = 0; g < 8; g++) {
@@ -855,7 +871,7 @@ SQ_DEVFN void cert_compute_core(CertCtx& cx) {
                     old[g] = __hip_atomic_exchange((SQ_G u64*)(E + 2 * hash4(v[g], eLog)), mine, __ATOMIC_RELAXED,
                                                    __HIP_MEMORY_SCOPE_AGENT);
                 vbloom_add(cx.bloom, v[g]);
-                if (v1[g] == v[g]) note(sp[g], vmin, vmin1); // offset_1 == 1 repcode at s+1
+                if (cx.repOff && v1[g] == vr[g]) note(sp[g], vmin, vmin1); // repcode at s+1
             }
         }
 #pragma unroll
@@ -1151,7 +1167,7 @@ SQ_DEVFN void cert_compute_core(CertCtx& cx) {
             certEnd1 = sviol < certEnd1 ? sviol : certEnd1;
     };
     for (u32 i = 0; i < nCert; i++) {
-        u32 const sp = cert_pos_t(cx.schedTab, cx.certCnt0, i);
+        u32 const sp = cert_pos_c(cx, i);
         u32 const v = sq_rd32(base + sp);
         u32 const h = hash4(v, eLog);
         u32 const od = ht_dec_g(cx.genBits, E[2 * h]);
@@ -1159,7 +1175,7 @@ SQ_DEVFN void cert_compute_core(CertCtx& cx) {
         E[2 * h] = ht_enc_g(cx.genBits, sp) | (od ? SQZ_CERT_DUP : 0u); // exchange (+ DUP if it displaced one)
         E[2 * h + 1] = v;
         vbloom_add(cx.bloom, v);
-        if (sq_rd32(base + sp + 1) == v) note(sp);
+        if (cx.repOff && sq_rd32(base + sp + 1) == sq_rd32(base + sp + 1 - cx.repOff)) note(sp);
         if (od) {
             u32 const opos = od & SQZ_HT_IDX;
             if (oval == v) note(opos > sp ? opos : sp);
@@ -1216,6 +1232,9 @@ SQ_DEVFN void cert_compute(MatchState& ms) {
     cx.schedTab = ms.schedTab;
     cx.certCnt0 = ms.certCnt0;
     cx.nCert = ms.nCert;
+    cx.base1Pos = SQZ_WINDOW_START + SQZ_BLOCKSIZE_MAX;
+    cx.tabOff1 = 0;
+    cx.repOff = 1;
     cx.chunkEndPos = ms.chunkEndPos;
     cx.bloom = (SQ_L u32*)g_lds.u.bloom;
     cx.cand = (SQ_L u32*)g_lds.grp;
@@ -1230,6 +1249,47 @@ SQ_DEVFN void cert_compute(MatchState& ms) {
     SQ_TRACE(42, cx.certEnd1);
 }
 
+
+// Tail certificate.  After a hand-over (a 4-byte coincidence at a searched position, a real match,
+// ...) the exact code has dealt with the match and the parser is back to finding nothing, at `ipPos`,
+// with anchor `anc` and repcode offset `off1`.  Its remaining searches of this block are the "later"
+// schedule laid at the anchor, from the entry that equals ipPos - anc on.  The same certificate
+// (table in the workspace's tail-certificate area, Bloom filter in LDS) decides whether all of them
+// certainly fail.  The caller uses a positive answer only where nothing later can observe the finder's
+// tables, because skipping those searches leaves the tables behind.  The live-bucket Bloom filter
+// shares its LDS with the certificate's: the caller rebuilds it after a negative answer.
+SQ_DEVFN bool tail_certify(MatchState& ms, u32 ipPos, u32 anc, u32 off1, u32 ilimPos) {
+    const u32* const later = ms.schedTab + 2 + SQZ_SCHEDTAB_N;
+    u32 const nLater = gld32(ms.schedTab + 1);
+    u32 const rel = ipPos - anc;
+    u32 const j0 = sched_count(later, nLater, rel);
+    if (j0 >= nLater || gld32(later + j0) != rel) return false; // not on the anchor's lattice
+    u32 const j1 = sched_count(later, nLater, ilimPos - anc);
+    if (j1 <= j0) return true; // no search left in this block
+    CertCtx cx;
+    cx.base = ms.base;
+    cx.E = ms.tailTab;
+    cx.eLog = ms.cp.chainLog - 1;
+    cx.genBits = ms.genBits;
+    cx.schedTab = ms.schedTab;
+    cx.certCnt0 = 0;
+    cx.nCert = j1 - j0;
+    cx.base1Pos = anc;
+    cx.tabOff1 = j0;
+    cx.repOff = off1;
+    cx.chunkEndPos = ms.chunkEndPos;
+    cx.bloom = (SQ_L u32*)g_lds.u.bloom;
+    cx.cand = (SQ_L u32*)g_lds.grp;
+    cx.ovf = (SQ_L u32*)&g_lds.ent[ms.nxEnt & 1];
+    cx.lvl = nullptr;
+    cx.dbg = 0;
+    if (!*ms.tailTabClean) { // first use in this launch (or after a change of size class)
+        wv_fill32(cx.E, 0, (size_t)2 << cx.eLog);
+        *ms.tailTabClean = 1;
+    }
+    cert_compute_core(cx);
+    return cx.certEnd1 >= ilimPos;
+}
 
 // Block 1 was certified under the assumption that it starts with repcode offset 1.  When block 0
 // ended with another offset (it had a match), redo the repcode test of block 1's scheduled
@@ -1961,6 +2021,30 @@ SQ_DEVFN u32 compressBlock_lazy(MatchState& ms, SeqStore& ss, u32* rep, const u8
         u32 offBase = 1; // REPCODE1_TO_OFFBASE
         const u8* start = ip + 1;
         ms.anchorPos = (u32)(anchor - base);
+        if (!ROW && !ms.tailTried && (failStreak >= SQZ_EPOCH_AFTER_FAILS || ss.nseq > 0) && (ms.eager || ms.nLive)) {
+            // The finder was woken by a hand-over and the exact code has dealt with what stopped the
+            // certificate (a sequence has been stored, or the search found nothing after all): before
+            // the next search (and the schedule repair it would trigger), ask the tail certificate whether the rest of this block can
+            // find anything at all.  Only where no later code can observe the tables we would leave
+            // behind: in the last block, or when the next (last) block is certified whatever repcode
+            // offset this block passes on (offset 1 if it ends raw, offset_1 if it is compressed).
+            u32 const blkEnd = (u32)(iend - base);
+            bool lastOrCovered = blkEnd >= ms.chunkEndPos;
+            if (!lastOrCovered && blkEnd == SQZ_WINDOW_START + SQZ_BLOCKSIZE_MAX && ms.certEnd1 &&
+                ms.chunkEndPos - blkEnd <= SQZ_BLOCKSIZE_MAX) {
+                u32 const lim1 = ms.chunkEndPos - 8;
+                lastOrCovered = ms.certEnd1 >= lim1 && (offset_1 <= 1 || cert_rep_recheck(ms, offset_1, lim1) >= lim1);
+            }
+            ms.tailTried = 1;
+            if (lastOrCovered) {
+                if (tail_certify(ms, (u32)(ip - base), (u32)(anchor - base), offset_1, (u32)(ilimit - base))) {
+                    SQ_TRACE(39, 1);
+                    ip = ilimit; // every remaining search of the block fails; nothing observes the tables any more
+                    break;
+                }
+                if (!ms.eager) bloom_rebuild(ms);
+            }
+        }
         if (!ROW && !ms.specOff && failStreak >= SQZ_EPOCH_AFTER_FAILS && (u32)(ip - base) != exactAt) {
             u32 nextPos = 0, stopped = 1;
             u32 const f = spec_epoch(ms, (u32)(ip - base), ms.anchorPos, offset_1, (u32)(ilimit - base), &nextPos, &stopped);

@@ -24,12 +24,12 @@ extern "C" size_t sim_compress_chunk(const uint8_t* src, size_t n, uint8_t* dst,
     memset(ws, poison ? 0xA5 : 0, L.total + 256 + 1024);
     memset(&sqz::g_lds, poison ? 0x5A : 0, sizeof(sqz::g_lds));
     u8* wsa = (u8*)(((uintptr_t)ws + 255) & ~(uintptr_t)255);
-    sqz::TableGen tg = {0, 0};
+    sqz::TableGen tg = {0, 0, 0};
     u32 r = sqz::compress_frame_wave(src, (u32)n, dst, (u32)cap, wsa, L, tg, sched_tab(), nullptr);
     if (getenv("SQ_SIM_STATS")) {
         const u32* t = (const u32*)(wsa + L.dummy) + 8;
-        fprintf(stderr, "[sim] n=%zu eager=%u repairs=%u live=%u skips=%u epochs=%u specfail=%u replays=%u certified=%u lastblock_skipped_live=%u\n", n, t[30],
-                t[31], t[32], t[33], t[34], t[35], t[36], t[37], t[38]);
+        fprintf(stderr, "[sim] n=%zu eager=%u repairs=%u live=%u skips=%u epochs=%u specfail=%u replays=%u certified=%u lastblock_skipped_live=%u tail_certified=%u\n", n, t[30],
+                t[31], t[32], t[33], t[34], t[35], t[36], t[37], t[38], t[39]);
     }
     free(ws);
     return r;
@@ -37,11 +37,11 @@ extern "C" size_t sim_compress_chunk(const uint8_t* src, size_t n, uint8_t* dst,
 // Same, but with ONE workspace and ONE table-generation state kept across calls, as a persistent
 // wave of k_compress_batch keeps them across the chunks it pulls from the queue.
 static u8* g_ws = nullptr;
-static sqz::TableGen g_tg = {0, 0};
+static sqz::TableGen g_tg = {0, 0, 0};
 extern "C" void sim_persistent_reset(void) {
     free(g_ws);
     g_ws = nullptr;
-    g_tg.gen = g_tg.windowLog = 0;
+    g_tg.gen = g_tg.windowLog = g_tg.tailTabClean = 0;
 }
 extern "C" unsigned sim_persistent_gen(void) { return g_tg.gen; }
 extern "C" size_t sim_compress_persistent(const uint8_t* src, size_t n, uint8_t* dst, size_t cap) {
@@ -80,7 +80,7 @@ extern "C" size_t sim_compress_two_stage(const uint8_t* src, size_t n, uint8_t* 
     memset(ws, 0xA5, L.total + 256 + 1024);
     memset(&sqz::g_lds, 0x5A, sizeof(sqz::g_lds));
     u8* wsa = (u8*)(((uintptr_t)ws + 255) & ~(uintptr_t)255);
-    sqz::TableGen tg = {0, 0};
+    sqz::TableGen tg = {0, 0, 0};
     r = sqz::compress_frame_wave(src, (u32)n, dst, (u32)cap, wsa, L, tg, sched_tab(), hint);
     free(ws);
     return r;
