@@ -80,7 +80,14 @@ struct sq_ctx {
 
     // per-batch scratch
     DevBuf b_off, b_len, b_slot_off, b_frame_len, b_out_off, b_isnew, b_hashes, b_stage_in,
-        b_stage_out, b_slots, b_ws, b_misc, b_cert;
+        b_stage_out, b_slots, b_ws, b_misc, b_cert, b_etab;
+    // shapes of the two table pools at the last launch that completed (persistent generation tags)
+    void* ws_ptr_last = nullptr;
+    size_t ws_each_last = 0;
+    u32 ws_waves_last = 0;
+    void* etab_ptr_last = nullptr;
+    size_t etab_bytes_last = 0;
+    u32 etab_waves_last = 0;
     void* h_pinned = nullptr; // small pinned host mirror (total sizes etc.)
     u32* d_sched_tab = nullptr; // constant no-match schedule tables of the compressor (sched_tab_fill)
 
@@ -195,7 +202,7 @@ void sq_ctx_destroy(sq_ctx* c) {
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     for (DevBuf* b : {&c->b_off, &c->b_len, &c->b_slot_off, &c->b_frame_len, &c->b_out_off, &c->b_isnew,
-                      &c->b_hashes, &c->b_stage_in, &c->b_stage_out, &c->b_slots, &c->b_ws, &c->b_misc, &c->b_cert})
+                      &c->b_hashes, &c->b_stage_in, &c->b_stage_out, &c->b_slots, &c->b_ws, &c->b_misc, &c->b_cert, &c->b_etab})
         b->release();
     if (c->d_table) (void)hipFree(c->d_table);
     if (c->d_keys) (void)hipFree(c->d_keys);
@@ -395,7 +402,13 @@ static int compress_async(sq_ctx* c, const u8* d_data, const u64* h_off, const u
         fwaves = std::min(fwaves, n);
         if ((r = c->b_cert.ensure((size_t)n * 8))) return r;
     }
-    if ((r = c->b_ws.ensure(std::max((size_t)waves * ws_each, (size_t)fwaves * etab_bytes) + 256))) return r;
+    if ((r = c->b_ws.ensure((size_t)waves * ws_each + 256))) return r;
+    if (fast && (r = c->b_etab.ensure((size_t)fwaves * (etab_bytes + 256)))) return r;
+    // the pools keep their generation tags from launch to launch as long as nothing about them changes
+    const u32 ws_persist = (c->b_ws.p == c->ws_ptr_last && ws_each == c->ws_each_last && waves == c->ws_waves_last && fast) ? 1u : 0u;
+    const u32 etab_persist = (fast && c->b_etab.p == c->etab_ptr_last && etab_bytes == c->etab_bytes_last && fwaves == c->etab_waves_last) ? 1u : 0u;
+    c->ws_ptr_last = nullptr; // becomes valid again when this launch has completed
+    c->etab_ptr_last = nullptr;
     if ((r = c->b_misc.ensure(256))) return r;
     HIPCHK(hipMemsetAsync(c->b_misc.p, 0, 256, c->stream));
 
@@ -416,9 +429,9 @@ static int compress_async(sq_ctx* c, const u8* d_data, const u64* h_off, const u
         HIPCHK(hipEventRecord(c->ev[8], c->stream));
         hipLaunchKernelGGL(sqz::k_incompressible_batch, dim3(fwaves), dim3(64), 0, c->stream, d_data,
                            (const u64*)c->b_off.p, (const u32*)c->b_len.p, d_select, n, d_slots,
-                           (const u64*)c->b_slot_off.p, (u32*)c->b_frame_len.p, (u32*)c->b_cert.p, (u8*)c->b_ws.p,
+                           (const u64*)c->b_slot_off.p, (u32*)c->b_frame_len.p, (u32*)c->b_cert.p, (u8*)c->b_etab.p,
                            (u64)etab_bytes, (u32*)c->b_misc.p + 32 /*queue*/, (const u32*)c->d_sched_tab,
-                           (u32)(getenv("SQ_FAST_DBG") ? atoi(getenv("SQ_FAST_DBG")) : 0));
+                           (u32)(getenv("SQ_FAST_DBG") ? atoi(getenv("SQ_FAST_DBG")) : 0), etab_persist);
         HIPCHK(hipGetLastError());
         HIPCHK(hipEventRecord(c->ev[9], c->stream));
     }
@@ -430,7 +443,7 @@ static int compress_async(sq_ctx* c, const u8* d_data, const u64* h_off, const u
                            (const u32*)c->b_len.p, d_select, n, d_slots,
                            (const u64*)c->b_slot_off.p, (u32*)c->b_frame_len.p, (u8*)c->b_ws.p,
                            (u64)ws_each, (u32*)c->b_misc.p /*queue*/, (u32*)c->b_misc.p + 16 /*err*/,
-                           (const u32*)c->d_sched_tab, fast ? (const u32*)c->b_cert.p : (const u32*)nullptr);
+                           (const u32*)c->d_sched_tab, fast ? (const u32*)c->b_cert.p : (const u32*)nullptr, ws_persist);
         HIPCHK(hipGetLastError());
     }
     HIPCHK(hipEventRecord(c->ev[5], c->stream));
@@ -479,6 +492,16 @@ static int compress_async(sq_ctx* c, const u8* d_data, const u64* h_off, const u
     HIPCHK(hipEventElapsedTime(&c->last.compress_ms, c->ev[4], c->ev[5]));
     if (fast) HIPCHK(hipEventElapsedTime(&c->last.fast_ms, c->ev[8], c->ev[9]));
     c->last.fast_decided = fast ? h_err[1] : 0;
+    if (!*h_err) { // both kernels ran to completion: their saved table states are good for the next launch
+        c->ws_ptr_last = c->b_ws.p;
+        c->ws_each_last = ws_each;
+        c->ws_waves_last = waves;
+        if (fast) {
+            c->etab_ptr_last = c->b_etab.p;
+            c->etab_bytes_last = etab_bytes;
+            c->etab_waves_last = fwaves;
+        }
+    }
 #ifdef SQ_PROF
     {   // profiling build: sum the per-wave phase timers (100 MHz ticks) and print them
         std::vector<unsigned long long> tot(33, 0), one(33);

@@ -144,12 +144,16 @@ SQ_DEVFN u32 fastpath_frame_wave(const u8* src, u32 n, u8* dst, u32 cap, u32* E,
 __global__ void __launch_bounds__(64, 4)
 k_incompressible_batch(const u8* data, const u64* off, const u32* len, const u8* select, u32 n, u8* slots,
                        const u64* slot_off, u32* frame_len, u32* cert_out, u8* etab_pool, u64 etab_bytes,
-                       u32* queue, const u32* schedTab, u32 dbg) { // queue[1]: number of chunks decided here
+                       u32* queue, const u32* schedTab, u32 dbg, u32 persist) { // queue[1]: number of chunks decided here
     __shared__ FastLds lds;
-    u32* const E = (u32*)(etab_pool + (u64)blockIdx.x * etab_bytes);
+    // a wave's slice: its table, then 256 bytes that keep its generation counter between launches
+    u32* const E = (u32*)(etab_pool + (u64)blockIdx.x * (etab_bytes + 256));
+    u32* const saved = (u32*)((u8*)E + etab_bytes);
     for (u32 i = wv_lane(); i < 2 * SQZ_SCHEDLVL_N; i += 64) lds.lvl[i] = schedTab[SQZ_SCHEDLVL_OFF + i];
     __builtin_amdgcn_s_waitcnt(0);
-    u32 gen = 0; // 0: the table holds unknown words
+    // 0: the table holds unknown words; `persist`: the host vouches that the pool is as the previous
+    // launch left it, so the saved counter is still true and the tags go on counting
+    u32 gen = persist ? gld32(saved) : 0u;
     for (;;) {
         u32 idx = 0;
         if (wv_lane() == 0) idx = atomicAdd(queue, 1u);
@@ -175,6 +179,7 @@ k_incompressible_batch(const u8* data, const u64* off, const u32* len, const u8*
             if (r) atomicAdd(queue + 1, 1u);
         }
     }
+    if (wv_lane() == 0) saved[0] = gen;
 }
 #endif
 

@@ -423,8 +423,9 @@ SQ_DEVFN u32 compress_frame_wave(const u8* src, u32 n, u8* dst, u32 cap, u8* ws,
     if (cp.strategy == STRAT_BTLAZY2) {
         if (tg.gen == 0 || tg.gen >= SQZ_HT_GEN_MAX || tg.windowLog != cp.windowLog) {
             wv_fill32(ms.hashTable, 0, (size_t)1 << cp.hashLog);
-            // the chain-table area hosts the no-match certificate's tagged entries (cert_compute)
-            wv_fill32(ms.chainTable, 0, (size_t)1 << cp.chainLog);
+            // the chain-table area hosts the no-match certificate's tagged entries (cert_compute),
+            // unless stage 1 computes the certificates
+            if (!certHint) wv_fill32(ms.chainTable, 0, (size_t)1 << cp.chainLog);
             tg.gen = 0;
             tg.windowLog = cp.windowLog;
             tg.tailTabClean = 0;
@@ -481,7 +482,7 @@ SQ_DEVFN u32 compress_frame_wave(const u8* src, u32 n, u8* dst, u32 cap, u8* ws,
         if (hint1 & SQZ_CERT_HINT_VALID) { // already computed by the incompressible-chunk kernel
             ms.certEnd = gld32(certHint);
             ms.certEnd1 = hint1 & ~SQZ_CERT_HINT_VALID;
-        } else if (ms.nCert > 0) {
+        } else if (ms.nCert > 0 && !certHint) {
             cert_compute(ms);
         }
         wv_zero_lds(g_lds.u.bloom, SQZ_BLOOM_WORDS);
@@ -579,11 +580,20 @@ __device__ __noinline__ void compress_one(const u8* data, const u64* off, const 
 __global__ void __launch_bounds__(64, 2) // 2 waves per SIMD: <= 256 registers, 8 waves per CU (LDS: 8 x 19 KiB)
 k_compress_batch(const u8* data, const u64* off, const u32* len, const u8* select, u32 n, u8* slots,
                  const u64* slot_off, u32* frame_len, u8* ws_pool, u64 ws_each, u32* queue, u32* err,
-                 const u32* schedTab, const u32* certHint) {
+                 const u32* schedTab, const u32* certHint, u32 persist) {
     u8* const ws = ws_pool + (u64)blockIdx.x * ws_each;
     u32* const dbg = (u32*)(ws + ws_each - 256) + 8; // wave-level progress words for the watchdog
     u32 iter = 0;
-    TableGen tg = {0, 0, 0}; // this wave's hash-table area holds unknown words
+    // State of this wave's table areas.  `persist`: the host vouches that this workspace is exactly as
+    // the previous launch of this kernel left it, so the state saved at its end is still true and the
+    // tables need no clearing (generation tags go on counting); otherwise they hold unknown words.
+    u32* const saved = (u32*)(ws + ws_each - 704);
+    TableGen tg = {0, 0, 0};
+    if (persist) {
+        tg.gen = gld32(saved);
+        tg.windowLog = gld32(saved + 1);
+        tg.tailTabClean = gld32(saved + 2);
+    }
 #ifdef SQ_PROF
     if (wv_lane() == 0)
         for (int k = 0; k < 32; k++) g_lds.prof[k] = 0;
@@ -605,7 +615,12 @@ k_compress_batch(const u8* data, const u64* off, const u32* len, const u8* selec
         if (take) compress_one(data, off, len, idx, slots, slot_off, frame_len, ws, err, tg, schedTab, certHint);
         PROF_ADD(0, t_all);
     }
-    if (wv_lane() == 0) dbg[11] = 777;
+    if (wv_lane() == 0) {
+        dbg[11] = 777;
+        saved[0] = tg.gen;
+        saved[1] = tg.windowLog;
+        saved[2] = tg.tailTabClean;
+    }
 #ifdef SQ_PROF
     wv_fence();
     if (wv_lane() == 0) {

@@ -252,3 +252,23 @@ def test_slots_layout_equals_packed(gpu_store, oracle):
     # too small an output buffer is refused, not overrun
     with pytest.raises(squishrs_amd.SquishError):
         gpu_store.compress_device_slots(d, offs, lens, select, comp[:1000])
+
+
+def test_table_generations_persist_across_launches(oracle):
+    """The two table pools keep their generation tags from launch to launch while their shapes do not
+    change (no clearing), and start over when they do: several launches on one ctx, alternating
+    between batches of the same and of different size classes / wave counts; every frame every time
+    must equal the oracle's."""
+    import squishrs_amd
+    st = squishrs_amd.ChunkStore(device=0, dedup_capacity=1 << 12, compress_waves=3)
+    a = [corpus.make(k, 300 + i, 262144) for i, k in enumerate(["random", "planted0", "random", "planted4", "text",
+                                                               "random", "planted9", "random", "planted8", "random",
+                                                               "planted1", "random"])]
+    b = [corpus.make(k, 400 + i, 70000) for i, k in enumerate(["random", "text", "planted3", "random", "mixed"])]
+    c = [corpus.make("random", 500 + i, 262144) for i in range(2)]      # fewer chunks than waves: other wave count
+    ref = {id(x): [oracle.compress_chunk(ch) for ch in x] for x in (a, b, c)}
+    try:
+        for batch in (a, a, b, a, c, a, a, b, b):
+            assert _batch_compress(st, batch) == ref[id(batch)]
+    finally:
+        st.close()
