@@ -398,7 +398,10 @@ static int compress_async(sq_ctx* c, const u8* d_data, const u64* h_off, const u
         const u32 ml = std::min(max_len, 256u << 10);
         while ((1u << w) < ml) w++;
         etab_bytes = (size_t)8 << w; // chainLog - 1 == windowLog
-        fwaves = c->cfg.compress_waves ? c->cfg.compress_waves * 2 : (u32)c->num_cu * 16;
+        int occ = 0; // resident waves per CU (LDS-bound)
+        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, sqz::k_incompressible_batch, 64, 0);
+        if (occ < 1) occ = 4;
+        fwaves = c->cfg.compress_waves ? c->cfg.compress_waves * 2 : (u32)c->num_cu * (u32)occ;
         fwaves = std::min(fwaves, n);
         if ((r = c->b_cert.ensure((size_t)n * 8))) return r;
     }

@@ -12,19 +12,32 @@
 // so the frame is header + raw blocks.  Everything else is left to k_compress_batch (frame length 0),
 // together with the certificate ends already computed here.
 //
-// Why a separate kernel: k_compress_batch needs 248 VGPRs and 20 KB of LDS per wave (8 waves/CU)
-// and is latency-bound at that occupancy; this path needs ~11 KB of LDS and half the registers, so
-// twice as many waves hide the same memory latency.
+// Why a separate kernel: this path is a few streaming passes with all of its state in LDS (the
+// certificate's set S, 25 KB per wave: 6 waves per CU); k_compress_batch carries the whole zstd state
+// machine (248 VGPRs, 20 KB of LDS of entropy tables) and keeps the certificate's table in HBM.
 #pragma once
 #include "sq_zstd_match.h"
+#if !SQ_ON_DEVICE
+#include <algorithm>
+#include <utility>
+#include <vector>
+#endif
 
 namespace sqz {
 
+#define SQZ_FAST_VALS 3584u  // >= scheduled searches of a chunk of this strategy (2 x 1748)
+#define SQZ_FAST_KEYS 1024u  // value buckets: top 10 bits
+#define SQZ_FAST_HITS 32u
+#define SQZ_FAST_BUCKET_MAX 24u // a bucket holds 3.4 values on average; beyond this the data is not random
+
+// LDS of one wave of k_incompressible_batch (25.6 KB: 6 waves per CU)
 struct FastLds {
-    u32 bloom[SQZ_BLOOM_WORDS]; // certificate Bloom filter; afterwards the 256-bin sample histograms
-    u32 cand[256];
-    u32 ovf[2 * SQZ_CERT_OVF_CAP];
-    u32 lvl[2 * SQZ_SCHEDLVL_N]; // level words of the two schedules (copied once per wave)
+    u32 bloom[SQZ_BLOOM_WORDS];      // certificate Bloom filter; afterwards the 256-bin sample histograms
+    u32 vals[SQZ_FAST_VALS];         // the 4-byte values at the scheduled positions, grouped by their top 10 bits
+    u32 ends[SQZ_FAST_KEYS / 2 + 2]; // per bucket, packed 2 x u16: first counts, then starts, finally END offsets
+    u32 cand[256];                   // a round's Bloom positives: 128 x (position, bytes)
+    u32 hits[2 * SQZ_FAST_HITS];     // (position, bytes) of scanned positions whose bytes equal a scheduled position's;
+                                     // position 0 = two scheduled positions with equal bytes
 };
 
 #define SQZ_FAST_MIN_BLOCK (4096u * 10u) // HUF's sampled pre-check needs srcSize >= 10 samples
@@ -67,6 +80,501 @@ SQ_DEVFN u32 fast_literals_uncompressible(const u8* blk, u32 size, u32* count /*
     return l1 + l2 <= ((2 * 4096) >> 7) + 4;
 }
 
+// ---------------------------------------------------------------- the certificate, LDS edition
+// Same statement as cert_compute_core (sq_zstd_match.h) -- for each block, the first scheduled
+// search position s for which an earlier position holds the same 4 bytes, or whose repcode test
+// fires -- but the set S lives in LDS instead of a 2 MiB table in HBM (whose 3,500 random 8-byte
+// writes and ~6,000 random reads per chunk were 60 % of this kernel's time):
+//   build : the values at the scheduled positions are bucketed by their top 10 bits with a counting
+//           sort in LDS (count, prefix sum, scatter: the bucket "end" array doubles as the cursor);
+//           two scheduled positions with equal values show up as equal neighbours in a bucket;
+//   scan  : as before (aligned 16-byte stream loads, value-keyed Bloom filter, scheduled positions
+//           left out -- here in EVERY round, so that a Bloom positive that is found in its bucket is
+//           a genuine repeat); positives are looked up in their bucket (~3.4 values);
+//   hits  : the rare genuine repeats (0.1 per random chunk) are resolved at the end by walking S.
+
+// scheduled positions among [rlo, rhi) of level k (rlo, rhi relative to the block start, inside
+// level k), as bits relative to r; wd = the level word of k
+SQ_DEV u32 fast_sched_bits(u32 wd, u32 k, u32 rlo, u32 rhi, u32 r) {
+    u32 const first = wd & 0x1FFFFu, step = k + 1;
+    if (first == 0x1FFFFu || rlo >= rhi) return 0;
+    u32 nxt = first;
+    if (rlo > first) {
+        u32 const x = rlo - first;
+        u32 const m = (step >= 17) ? x - ((x * (wd >> 17)) >> 16) * step : x % step;
+        nxt = rlo + (m ? step - m : 0u);
+    }
+    u32 bits = 0;
+    for (; nxt < rhi; nxt += step) bits |= 1u << (nxt - r);
+    return bits;
+}
+// scheduled positions of ONE block (start bs, end blkEnd, level words lv) among the 16 positions that
+// start at lo, as bits relative to lo
+SQ_DEV u32 fast_sched_mask_blk(const u32* lv, s32 lo, u32 bs, u32 blkEnd, u32 wdA, u32 wdB, bool haveWords) {
+    if (blkEnd - bs < 9) return 0; // too small a block to be searched at all
+    s32 const limPos = (s32)(blkEnd - 8); // a block's searches stop 8 bytes before its end
+    s32 const a = lo < (s32)bs ? (s32)bs : lo, e = (lo + 16 < limPos) ? lo + 16 : limPos;
+    if (a >= e) return 0;
+    u32 const rlo = (u32)(a - (s32)bs), rhi = (u32)(e - (s32)bs);
+    u32 const r = (u32)(lo - (s32)bs); // may wrap when lo < bs: bits are taken relative to it modulo 2^32
+    u32 const kA = rlo >> 8, kB = (rhi - 1) >> 8;
+    u32 const wa = haveWords ? wdA : sq_gld32(lv + (kA < SQZ_SCHEDLVL_N ? kA : SQZ_SCHEDLVL_N - 1));
+    u32 const wb = haveWords ? wdB : sq_gld32(lv + (kB < SQZ_SCHEDLVL_N ? kB : SQZ_SCHEDLVL_N - 1));
+    u32 const split = (kA + 1) << 8;
+    u32 bits = fast_sched_bits(wa, kA, rlo, rhi < split ? rhi : split, r);
+    if (kB != kA) bits |= fast_sched_bits(wb, kB, split, rhi, r);
+    return bits;
+}
+// all scheduled positions among the 16 that start at position lo (blocks start at SQZ_WINDOW_START and
+// blk1); wdA / wdB: the level words loadLevels() fetched for this window, valid unless it straddles blk1
+SQ_DEV u32 fast_sched_mask(const u32* lvlWords /*global*/, s32 lo, u32 blk1, u32 chunkEndPos, u32 wdA, u32 wdB,
+                           bool haveWords) {
+    bool const two = blk1 != 0xFFFFFFFFu;
+    u32 const end0 = two ? blk1 : chunkEndPos;
+    if (two && lo < (s32)blk1 && lo + 16 > (s32)blk1) // straddles the block boundary (one lane of one round)
+        return fast_sched_mask_blk(lvlWords, lo, SQZ_WINDOW_START, end0, 0, 0, false) |
+               fast_sched_mask_blk(lvlWords + SQZ_SCHEDLVL_N, lo, blk1, chunkEndPos, 0, 0, false);
+    if (two && lo >= (s32)blk1) return fast_sched_mask_blk(lvlWords + SQZ_SCHEDLVL_N, lo, blk1, chunkEndPos, wdA, wdB, haveWords);
+    return fast_sched_mask_blk(lvlWords, lo, SQZ_WINDOW_START, end0, wdA, wdB, haveWords);
+}
+
+// The same for a window [ur, ur + 16) (relative to its block's start) that lies in levels >= 16, inside
+// the block's searched range and inside one block: at most one scheduled position per level part, no
+// loop, no division.  wa / wb: level words of the levels of ur and ur + 15.
+SQ_DEV u32 fast_sched_mask_plain(u32 ur, u32 wa, u32 wb) {
+    u32 const kA = ur >> 8, kB = (ur + 15) >> 8, split = (kA + 1) << 8;
+    u32 bits = 0;
+    { // part in level kA: [ur, min(ur + 16, split))
+        u32 const first = wa & 0x1FFFFu, step = kA + 1, hi = ur + 16 < split ? ur + 16 : split;
+        u32 const x = ur > first ? ur - first : 0u;
+        u32 const m = x - ((x * (wa >> 17)) >> 16) * step;
+        u32 const nxt = (ur > first ? ur : first) + (m ? step - m : 0u);
+        if (first != 0x1FFFFu && nxt < hi) bits |= 1u << (nxt - ur);
+    }
+    if (kB != kA) { // part in level kB: [split, ur + 16); that level's first scheduled position is >= split
+        u32 const first = wb & 0x1FFFFu;
+        if (first != 0x1FFFFu && first < ur + 16) bits |= 1u << (first - ur);
+    }
+    return bits;
+}
+
+SQ_DEV u32 fast_cnt16_add(SQ_L u32* arr, u32 key) { // packed 16-bit counters; returns the old count
+#if SQ_ON_DEVICE
+    u32 const old = __hip_atomic_fetch_add(&arr[key >> 1], 1u << (16 * (key & 1)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#else
+    u32 const old = arr[key >> 1];
+    arr[key >> 1] = old + (1u << (16 * (key & 1)));
+#endif
+    return (old >> (16 * (key & 1))) & 0xFFFFu;
+}
+SQ_DEV u32 fast_get16(const SQ_L u32* arr, u32 key) { return (arr[key >> 1] >> (16 * (key & 1))) & 0xFFFFu; }
+
+// cx: base, schedTab, certCnt0, nCert, base1Pos, tabOff1 (0), repOff, chunkEndPos are inputs;
+// certEnd / certEnd1 the results.
+SQ_DEVFN void cert_lds_core(CertCtx& cx, FastLds* L) {
+    const u8* const base = cx.base;
+    u32 const nCert = cx.nCert;
+    u32 const blk1 = (nCert > cx.certCnt0) ? cx.base1Pos : 0xFFFFFFFFu;
+    u32 certEnd = cx.chunkEndPos, certEnd1 = cx.chunkEndPos;
+    u32 const pEnd = cx.chunkEndPos - 3; // one past the last p with p + 4 <= chunkEnd
+    const u32* const lvlWords = cx.schedTab + SQZ_SCHEDLVL_OFF;
+    SQ_L u32* const bloom = (SQ_L u32*)L->bloom;
+    SQ_L u32* const vals = (SQ_L u32*)L->vals;
+    SQ_L u32* const ends = (SQ_L u32*)L->ends;
+    SQ_L u32* const hits = (SQ_L u32*)L->hits;
+    u32 nHits = 0;
+#if SQ_ON_DEVICE
+    u32 const lane = wv_lane();
+    u64 const below = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+    SQ_L u32* const cand = (SQ_L u32*)L->cand;
+    for (u32 i = lane; i < SQZ_BLOOM_WORDS; i += 64) bloom[i] = 0;
+    for (u32 i = lane; i < SQZ_FAST_KEYS / 2 + 2; i += 64) ends[i] = 0;
+    wv_fence();
+    u32 vmin = 0xFFFFFFFFu, vmin1 = 0xFFFFFFFFu; // lane-local minima of the violating scheduled positions
+    auto note = [&](u32 sviol, u32& v0, u32& v1) {
+        if (sviol < blk1)
+            v0 = sviol < v0 ? sviol : v0;
+        else
+            v1 = sviol < v1 ? sviol : v1;
+    };
+    auto settle = [&](u32 v0, u32 v1) { // wave minima of the violations -> certEnd / certEnd1
+        if (wv_ballot((v0 & v1) != 0xFFFFFFFFu)) {
+            u32 x = v0, z = v1;
+            for (int sft = 32; sft >= 1; sft >>= 1) {
+                u32 const y = (u32)__shfl_xor((int)x, sft, 64), w = (u32)__shfl_xor((int)z, sft, 64);
+                x = y < x ? y : x;
+                z = w < z ? w : z;
+            }
+            x = wv_uni(x);
+            z = wv_uni(z);
+            if (x < certEnd) certEnd = x;
+            if (z < certEnd1) certEnd1 = z;
+        }
+    };
+    auto pushHit = [&](bool have, u32 p, u32 vp) -> bool { // false: the list is full
+        u64 const m = wv_ballot(have);
+        if (!m) return true;
+        u32 const slot = nHits + (u32)__popcll(m & below);
+        if (have && slot < SQZ_FAST_HITS) {
+            hits[2 * slot] = p;
+            hits[2 * slot + 1] = vp;
+        }
+        nHits += (u32)__popcll(m);
+        if (nHits > SQZ_FAST_HITS) {
+            nHits = SQZ_FAST_HITS;
+            return false;
+        }
+        return true;
+    };
+    // ---- build pass 1: Bloom filter, bucket counts, repcode test
+    u32 const iLast = nCert - 1;
+    u32 const nBuild = (cx.dbg & 1) ? 0u : nCert; // SQ_FAST_DBG timing experiments: 1 = no build, 2 = no scan
+    for (u32 i0 = 0; i0 < nBuild; i0 += 512) {
+        u32 sp[8], v[8], v1[8], vr[8];
+#pragma unroll
+        for (u32 g = 0; g < 8; g++) {
+            u32 const i = i0 + 64 * g + lane;
+            sp[g] = cert_pos_c(cx, i < nCert ? i : iLast);
+        }
+#pragma unroll
+        for (u32 g = 0; g < 8; g++) {
+            v[g] = sq_grd32(base + sp[g]);
+            v1[g] = sq_grd32(base + sp[g] + 1);
+            vr[g] = (cx.repOff > 1) ? sq_grd32(base + sp[g] + 1 - cx.repOff) : v[g];
+        }
+#pragma unroll
+        for (u32 g = 0; g < 8; g++) {
+            if (i0 + 64 * g + lane < nCert) {
+                vbloom_add(bloom, v[g]);
+                (void)fast_cnt16_add(ends, v[g] >> 22);
+                if (cx.repOff && v1[g] == vr[g]) note(sp[g], vmin, vmin1); // repcode at s+1
+            }
+        }
+    }
+    wv_fence();
+    // ---- prefix sum: counts -> bucket starts (16 buckets = 8 words per lane)
+    bool bigBucket = false;
+    {
+        u32 w[8], c[16], tot = 0;
+#pragma unroll
+        for (u32 k = 0; k < 8; k++) w[k] = ends[8 * lane + k];
+#pragma unroll
+        for (u32 k = 0; k < 16; k++) {
+            c[k] = (w[k >> 1] >> (16 * (k & 1))) & 0xFFFFu;
+            tot += c[k];
+        }
+        // structured data piles its values into a few buckets: that is not what this path is for
+        u32 mx = 0;
+#pragma unroll
+        for (u32 k = 0; k < 16; k++) mx = c[k] > mx ? c[k] : mx;
+        bigBucket = wv_ballot(mx > SQZ_FAST_BUCKET_MAX) != 0;
+        u32 all = 0;
+        u32 run = wv_excl_scan(tot, &all);
+#pragma unroll
+        for (u32 k = 0; k < 8; k++) {
+            u32 const s0 = run;
+            run += c[2 * k];
+            u32 const s1 = run;
+            run += c[2 * k + 1];
+            ends[8 * lane + k] = s0 | (s1 << 16);
+        }
+        wv_fence();
+    }
+    if (bigBucket) { // no certificate
+        cx.certEnd = SQZ_WINDOW_START;
+        cx.certEnd1 = (blk1 != 0xFFFFFFFFu) ? SQZ_WINDOW_START : 0u;
+        return;
+    }
+    // ---- build pass 2: scatter the values; a bucket's start counts up to its end
+    for (u32 i0 = 0; i0 < nBuild; i0 += 512) {
+        u32 sp[8], v[8];
+#pragma unroll
+        for (u32 g = 0; g < 8; g++) {
+            u32 const i = i0 + 64 * g + lane;
+            sp[g] = cert_pos_c(cx, i < nCert ? i : iLast);
+        }
+#pragma unroll
+        for (u32 g = 0; g < 8; g++) v[g] = sq_grd32(base + sp[g]);
+#pragma unroll
+        for (u32 g = 0; g < 8; g++)
+            if (i0 + 64 * g + lane < nCert) {
+                u32 const slot = fast_cnt16_add(ends, v[g] >> 22);
+                if (slot < SQZ_FAST_VALS) vals[slot] = v[g];
+            }
+    }
+    wv_fence();
+    // ---- scheduled positions with equal values: equal neighbours inside a bucket
+    bool hitsFull = false;
+    for (u32 k0 = 0; k0 < SQZ_FAST_KEYS; k0 += 64) {
+        u32 const k = k0 + lane;
+        u32 const lo = k ? fast_get16(ends, k - 1) : 0u, hi = fast_get16(ends, k);
+        // every value that occurs twice in the bucket is reported once (at its second occurrence)
+        u32 b = lo + 1;
+        for (;;) {
+            bool dup = false;
+            u32 dupv = 0;
+            for (; b < hi && !dup; b++) {
+                u32 const vb = vals[b];
+                u32 seen = 0;
+                for (u32 a = lo; a < b; a++) seen += (vals[a] == vb) ? 1u : 0u;
+                if (seen == 1) { // exactly one earlier copy: first time this value repeats
+                    dup = true;
+                    dupv = vb;
+                }
+            }
+            if (!wv_ballot(dup)) break;
+            if (!pushHit(dup, 0u, dupv)) hitsFull = true;
+        }
+    }
+    settle(vmin, vmin1);
+    if (hitsFull) { // cannot even list the repeats inside the schedule: no certificate
+        certEnd = certEnd1 = SQZ_WINDOW_START;
+    }
+    // ---- scan
+    const SQ_L u32* const B = bloom;
+    const u8* const src0 = base + SQZ_WINDOW_START;
+    const u8* const a0 = src0 - ((size_t)src0 & 15);
+    s32 const p0 = (s32)SQZ_WINDOW_START - (s32)(src0 - a0); // position of a0 (may be negative)
+    const u8* const lastByte = base + cx.chunkEndPos - 1;
+    const u8* const aLast = lastByte - ((size_t)lastByte & 15);
+    s32 pos = p0;
+    auto scanStop = [&]() -> u32 {
+        u32 const ce = (blk1 != 0xFFFFFFFFu) ? certEnd1 : certEnd;
+        return ce < pEnd ? ce : pEnd;
+    };
+    auto loadRound = [&](s32 rp) -> sq_v4u {
+        const u8* ad = a0 + (size_t)(u32)(rp - p0) + 16 * lane;
+        return sq_grd128(ad < aLast ? ad : aLast);
+    };
+    // level words of the lane's 16 positions in the round at rp (two, for a window across two levels)
+    // Level words for the round at rp.  A round spans 1024 bytes = at most 5 levels of one block (rounds
+    // that touch the block boundary or the dense start take the general routine, which loads its own):
+    // lane l loads word (k0 + (l & 7)), k0 = level of the round's first byte; pickLevels() hands every
+    // lane the two words of its own 16 positions.
+    auto loadLevels = [&](s32 rp, u32& wl) {
+        bool const second = (blk1 != 0xFFFFFFFFu) && rp >= (s32)blk1;
+        u32 const bs = second ? blk1 : SQZ_WINDOW_START;
+        s32 const r0 = rp - (s32)bs;
+        u32 const k0 = r0 > 0 ? (u32)r0 >> 8 : 0u;
+        u32 const k = k0 + (lane & 7);
+        wl = sq_gld32(lvlWords + (second ? SQZ_SCHEDLVL_N : 0u) + (k < SQZ_SCHEDLVL_N ? k : SQZ_SCHEDLVL_N - 1));
+    };
+    auto pickLevels = [&](s32 rp, u32 wl, u32& wa, u32& wb) {
+        bool const second = (blk1 != 0xFFFFFFFFu) && rp >= (s32)blk1;
+        u32 const bs = second ? blk1 : SQZ_WINDOW_START;
+        s32 const r0 = rp - (s32)bs;
+        u32 const k0 = r0 > 0 ? (u32)r0 >> 8 : 0u;
+        s32 const r = r0 + (s32)(16 * lane);
+        u32 const kA = r > 0 ? (u32)r >> 8 : 0u, kB = r + 15 > 0 ? (u32)(r + 15) >> 8 : 0u;
+        wa = (u32)__shfl((int)wl, (int)((kA - k0) & 7), 64);
+        wb = (u32)__shfl((int)wl, (int)((kB - k0) & 7), 64);
+    };
+    auto valAt = [&](sq_v4u w, u32 d4, u32 j) -> u32 {
+        u32 const a = j >> 2;
+        u32 const lo = a == 0 ? w.x : a == 1 ? w.y : a == 2 ? w.z : w.w;
+        u32 const hi = a == 0 ? w.y : a == 1 ? w.z : a == 2 ? w.w : d4;
+        return __builtin_amdgcn_alignbyte(hi, lo, j & 3);
+    };
+    // is vp among the scheduled values?  (its bucket: ~3.4 values)
+    auto inSet = [&](u32 vp) -> bool {
+        u32 const k = vp >> 22;
+        u32 const lo = k ? fast_get16(ends, k - 1) : 0u, hi = fast_get16(ends, k);
+        // the first 8 values of the bucket with independent reads (one LDS latency), the rest in a loop
+        u32 b[8];
+#pragma unroll
+        for (u32 a = 0; a < 8; a++) b[a] = vals[(lo + a < SQZ_FAST_VALS) ? lo + a : SQZ_FAST_VALS - 1];
+        bool f = false;
+#pragma unroll
+        for (u32 a = 0; a < 8; a++) f = f || (lo + a < hi && b[a] == vp);
+        for (u32 a = lo + 8; a < hi; a++) f = f || (vals[a] == vp);
+        return f;
+    };
+    // Scheduled positions among a lane's 16, for windows whose levels are all >= 16 (one candidate per
+    // level part, no loop, no division); anything else (first 4 KiB of a block, the window across the
+    // block boundary, the last windows of a block) takes the general routine.
+    auto schedMaskFast = [&](s32 lo, u32 wa, u32 wb) -> u32 {
+        bool const second = (blk1 != 0xFFFFFFFFu) && lo >= (s32)blk1;
+        u32 const bs = second ? blk1 : SQZ_WINDOW_START;
+        u32 const blkEnd = (!second && blk1 != 0xFFFFFFFFu) ? blk1 : cx.chunkEndPos;
+        s32 const r = lo - (s32)bs;
+        bool const plain = r >= 4096 && (u32)(lo + 16) <= blkEnd - 8 && !((blk1 != 0xFFFFFFFFu) && lo < (s32)blk1 && lo + 16 > (s32)blk1);
+        if (wv_ballot(!plain)) return fast_sched_mask(lvlWords, lo, blk1, cx.chunkEndPos, wa, wb, plain);
+        return fast_sched_mask_plain((u32)r, wa, wb);
+    };
+    // one round: Bloom tests, scheduled positions removed, positives looked up; false = list of hits full
+    auto round = [&](sq_v4u w, sq_v4u wn, u32 wl) -> bool {
+        u32 wa, wb;
+        pickLevels(pos, wl, wa, wb);
+        u32 d4;
+        {
+            u32 const nx = (u32)__builtin_amdgcn_update_dpp(0, (int)w.x, 0x130 /* wave_shl:1 */, 0xF, 0xF, false);
+            u32 const n63 = wv_uni(wn.x);
+            d4 = (lane == 63) ? n63 : nx;
+        }
+        u32 const d[5] = {w.x, w.y, w.z, w.w, d4};
+        u32 const stop = scanStop();
+        s32 const lo = pos + (s32)(16 * lane);
+        s32 f = (s32)SQZ_WINDOW_START - lo, l = (s32)stop - lo;
+        f = f < 0 ? 0 : (f > 16 ? 16 : f);
+        l = l < 0 ? 0 : (l > 16 ? 16 : l);
+        u32 const okMask = ((1u << l) - 1u) & ~((1u << f) - 1u);
+        u32 cm = 0;
+#pragma unroll
+        for (u32 q = 0; q < 4; q++) {
+            u32 v[4], p1[4], p2[4];
+            v[0] = d[q];
+            v[1] = __builtin_amdgcn_alignbyte(d[q + 1], d[q], 1);
+            v[2] = __builtin_amdgcn_alignbyte(d[q + 1], d[q], 2);
+            v[3] = __builtin_amdgcn_alignbyte(d[q + 1], d[q], 3);
+#pragma unroll
+            for (u32 k = 0; k < 4; k++) {
+                p1[k] = B[(v[k] & 0xFFFFu) >> 5];
+                p2[k] = B[v[k] >> 21];
+            }
+#pragma unroll
+            for (u32 k = 0; k < 4; k++) {
+                u32 const c = (p1[k] >> (v[k] & 31)) & (p2[k] >> ((v[k] >> 16) & 31)) & 1u;
+                cm |= c << (4 * q + k);
+            }
+        }
+        cm &= okMask;
+        cm &= ~schedMaskFast(lo, wa, wb);
+        bool ok = true;
+        // compaction (one positive per lane and turn), then the positives are looked up 64 at a time
+        u32 cnt = 0;
+        for (;;) {
+            u64 const m = wv_ballot(cm != 0);
+            if (!m) break;
+            if (cm) {
+                u32 const j = (u32)__builtin_ctz(cm);
+                cm &= cm - 1;
+                u32 const slot = cnt + (u32)__popcll(m & below);
+                if (slot < 128) {
+                    cand[2 * slot] = (u32)(lo + (s32)j);
+                    cand[2 * slot + 1] = valAt(w, d4, j);
+                }
+            }
+            cnt += (u32)__popcll(m);
+        }
+        wv_fence();
+        if (cnt > 128) { // not with a working filter on random data: treat like a full list
+            ok = false;
+            cnt = 128;
+        }
+        for (u32 j0 = 0; j0 < cnt; j0 += 64) {
+            bool const have = j0 + lane < cnt;
+            u32 const hp = have ? cand[2 * (j0 + lane)] : 0u, hv = have ? cand[2 * (j0 + lane) + 1] : 0u;
+            bool const hit = have && inSet(hv);
+            if (!pushHit(hit, hp, hv)) ok = false;
+        }
+        pos += 1024;
+        return ok;
+    };
+    if (pos < (s32)scanStop() && !(cx.dbg & 2)) {
+        sq_v4u wA = loadRound(pos), wB = loadRound(pos + 1024), wC = loadRound(pos + 2048), wD = loadRound(pos + 3072), wE;
+        u32 lA, lB, lC, lD, lE;
+        loadLevels(pos, lA);
+        loadLevels(pos + 1024, lB);
+        loadLevels(pos + 2048, lC);
+        loadLevels(pos + 3072, lD);
+        bool full = false;
+        for (;;) {
+            wE = loadRound(pos + 4096);
+            loadLevels(pos + 4096, lE);
+            if (!round(wA, wB, lA)) { full = true; break; }
+            if (pos >= (s32)scanStop()) break;
+            wA = loadRound(pos + 4096);
+            loadLevels(pos + 4096, lA);
+            if (!round(wB, wC, lB)) { full = true; break; }
+            if (pos >= (s32)scanStop()) break;
+            wB = loadRound(pos + 4096);
+            loadLevels(pos + 4096, lB);
+            if (!round(wC, wD, lC)) { full = true; break; }
+            if (pos >= (s32)scanStop()) break;
+            wC = loadRound(pos + 4096);
+            loadLevels(pos + 4096, lC);
+            if (!round(wD, wE, lD)) { full = true; break; }
+            if (pos >= (s32)scanStop()) break;
+            wD = loadRound(pos + 4096);
+            loadLevels(pos + 4096, lD);
+            if (!round(wE, wA, lE)) { full = true; break; }
+            if (pos >= (s32)scanStop()) break;
+        }
+        if (full) { // more genuine repeats than the list holds (compressible data): positions >= pos - 1024
+            // stay unverified, which only matters to searches beyond them
+            u32 const cut = (u32)((pos - 1024) < (s32)SQZ_WINDOW_START ? (s32)SQZ_WINDOW_START : (pos - 1024)) + 1;
+            if (cut < certEnd) certEnd = cut;
+            if (cut < certEnd1) certEnd1 = cut;
+        }
+    }
+    // ---- resolve the hits by walking S: a scheduled s fails to be certified when an equal value sits at
+    // an earlier position (a scanned position p, or for a pair inside the schedule the earliest member)
+    for (u32 hIdx = 0; hIdx < nHits; hIdx++) {
+        u32 const hp = hits[2 * hIdx], hv = hits[2 * hIdx + 1];
+        u32 thr = hp;
+        if (hp == 0) { // pair inside the schedule: everything after its earliest member
+            u32 mn = 0xFFFFFFFFu;
+            for (u32 i0 = 0; i0 < nCert; i0 += 64) {
+                u32 const i = i0 + lane;
+                u32 const sp = cert_pos_c(cx, i < nCert ? i : iLast);
+                if (i < nCert && sq_grd32(base + sp) == hv && sp < mn) mn = sp;
+            }
+            for (int sft = 32; sft >= 1; sft >>= 1) {
+                u32 const y = (u32)__shfl_xor((int)mn, sft, 64);
+                mn = y < mn ? y : mn;
+            }
+            thr = wv_uni(mn);
+        }
+        u32 v0 = 0xFFFFFFFFu, v1 = 0xFFFFFFFFu;
+        for (u32 i0 = 0; i0 < nCert; i0 += 64) {
+            u32 const i = i0 + lane;
+            u32 const sp = cert_pos_c(cx, i < nCert ? i : iLast);
+            if (i < nCert && sq_grd32(base + sp) == hv && sp > thr) note(sp, v0, v1);
+        }
+        settle(v0, v1);
+    }
+    wv_fence();
+#else
+    // scalar twin: the same statement, computed plainly
+    (void)bloom; (void)vals; (void)ends; (void)hits; (void)nHits; (void)lvlWords;
+    auto note = [&](u32 sviol) {
+        if (sviol < blk1)
+            certEnd = sviol < certEnd ? sviol : certEnd;
+        else
+            certEnd1 = sviol < certEnd1 ? sviol : certEnd1;
+    };
+    // scheduled positions as a bitmap, through the same arithmetic the device uses
+    static thread_local u8 isSched[(256u << 10) + 64];
+    memset(isSched, 0, sizeof(isSched));
+    for (s32 lo = 0; lo < (s32)cx.chunkEndPos; lo += 16) {
+        u32 const m = fast_sched_mask(lvlWords, lo, blk1, cx.chunkEndPos, 0, 0, false);
+        for (u32 j = 0; j < 16; j++)
+            if ((m >> j) & 1) isSched[lo + j] = 1;
+    }
+    // (value, position) of every scheduled search, sorted by value then position
+    std::vector<std::pair<u32, u32>> sv(nCert);
+    for (u32 i = 0; i < nCert; i++) {
+        u32 const sp = cert_pos_c(cx, i);
+        sv[i] = std::make_pair(sq_rd32(base + sp), sp);
+        if (cx.repOff && sq_rd32(base + sp + 1) == sq_rd32(base + sp + 1 - cx.repOff)) note(sp);
+    }
+    std::sort(sv.begin(), sv.end());
+    for (u32 i = 1; i < nCert; i++) // an earlier scheduled position with the same bytes
+        if (sv[i].first == sv[i - 1].first) note(sv[i].second);
+    // every scheduled position must be one the arithmetic knows (else the scan would skip a wrong set)
+    for (u32 i = 0; i < nCert; i++)
+        if (!isSched[sv[i].second]) certEnd = certEnd1 = SQZ_WINDOW_START;
+    for (u32 p = SQZ_WINDOW_START; p < ((blk1 != 0xFFFFFFFFu) ? certEnd1 : certEnd) && p < pEnd; p++) {
+        if (isSched[p]) continue;
+        u32 const vp = sq_rd32(base + p);
+        auto it = std::lower_bound(sv.begin(), sv.end(), std::make_pair(vp, p + 1));
+        for (; it != sv.end() && it->first == vp; ++it) note(it->second); // scheduled positions beyond p with these bytes
+    }
+#endif
+    cx.certEnd = certEnd;
+    cx.certEnd1 = (blk1 != 0xFFFFFFFFu) ? certEnd1 : 0u;
+}
+
 // Returns the frame length when the chunk is decided here, 0 when it is left to k_compress_batch.
 // certOut[0..1]: the certificate ends for k_compress_batch (certOut[1] carries SQZ_CERT_HINT_VALID),
 // or 0, 0 when no certificate was computed.
@@ -92,14 +600,14 @@ SQ_DEVFN u32 fastpath_frame_wave(const u8* src, u32 n, u8* dst, u32 cap, u32* E,
         cx.tabOff1 = 0;
         cx.repOff = 1;
         cx.chunkEndPos = n + SQZ_WINDOW_START;
-        cx.bloom = (SQ_L u32*)L->bloom;
-        cx.cand = (SQ_L u32*)L->cand;
-        cx.ovf = (SQ_L u32*)L->ovf;
-        cx.lvl = (SQ_L u32*)L->lvl;
+        cx.bloom = nullptr;
+        cx.cand = nullptr;
+        cx.ovf = nullptr;
+        cx.lvl = nullptr;
         cx.certEnd = cx.certEnd1 = 0;
-        if (cx.nCert > 0) {
+        if (cx.nCert > 0 && cx.nCert <= SQZ_FAST_VALS) {
             cx.dbg = dbg;
-            cert_compute_core(cx);
+            cert_lds_core(cx, L);
             c0 = cx.certEnd;
             c1 = cx.certEnd1 | SQZ_CERT_HINT_VALID;
             // every search of every block certainly fails?
@@ -141,7 +649,7 @@ SQ_DEVFN u32 fastpath_frame_wave(const u8* src, u32 n, u8* dst, u32 cap, u32* E,
 #if SQ_ON_DEVICE
 // Persistent waves, one certificate table each; every wave pulls chunk indices from *queue until
 // exhausted (every wave reaches idx >= n).  frame_len[idx] = frame size, or 0 = not decided here.
-__global__ void __launch_bounds__(64, 4)
+__global__ void __launch_bounds__(64, 2)
 k_incompressible_batch(const u8* data, const u64* off, const u32* len, const u8* select, u32 n, u8* slots,
                        const u64* slot_off, u32* frame_len, u32* cert_out, u8* etab_pool, u64 etab_bytes,
                        u32* queue, const u32* schedTab, u32 dbg, u32 persist) { // queue[1]: number of chunks decided here
@@ -149,8 +657,6 @@ k_incompressible_batch(const u8* data, const u64* off, const u32* len, const u8*
     // a wave's slice: its table, then 256 bytes that keep its generation counter between launches
     u32* const E = (u32*)(etab_pool + (u64)blockIdx.x * (etab_bytes + 256));
     u32* const saved = (u32*)((u8*)E + etab_bytes);
-    for (u32 i = wv_lane(); i < 2 * SQZ_SCHEDLVL_N; i += 64) lds.lvl[i] = schedTab[SQZ_SCHEDLVL_OFF + i];
-    __builtin_amdgcn_s_waitcnt(0);
     // 0: the table holds unknown words; `persist`: the host vouches that the pool is as the previous
     // launch left it, so the saved counter is still true and the tags go on counting
     u32 gen = persist ? gld32(saved) : 0u;

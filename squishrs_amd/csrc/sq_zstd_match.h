@@ -867,7 +867,9 @@ SQ_DEVFN void cert_compute_core(CertCtx& cx) {
             old[g] = 0;
             if (i0 + 64 * g + lane < nCert) {
                 u64 const mine = ((u64)v[g] << 32) | ht_enc_g(cx.genBits, sp[g]);
-                if (!(cx.dbg & 8))
+                if (cx.dbg & 16) // timing experiment: plain store instead of the exchange
+                    sq_gst64v(E + 2 * hash4(v[g], eLog), (u32)mine, (u32)(mine >> 32));
+                else if (!(cx.dbg & 8))
                     old[g] = __hip_atomic_exchange((SQ_G u64*)(E + 2 * hash4(v[g], eLog)), mine, __ATOMIC_RELAXED,
                                                    __HIP_MEMORY_SCOPE_AGENT);
                 vbloom_add(cx.bloom, v[g]);

@@ -6,6 +6,7 @@
 #include "../../squishrs_amd/csrc/sq_zstd_kernel.h"
 #include <stdio.h>
 #include <stdlib.h>
+#include <vector>
 
 static const u32* sched_tab() {
     static u32 tab[SQZ_SCHEDTAB_WORDS];
@@ -70,7 +71,6 @@ extern "C" size_t sim_compress_two_stage(const uint8_t* src, size_t n, uint8_t* 
         gen = 1;
     }
     memset(&lds, 0x77, sizeof(lds));
-    memcpy(lds.lvl, sched_tab() + SQZ_SCHEDLVL_OFF, sizeof(lds.lvl));
     u32 hint[2] = {0x55555555u, 0x55555555u};
     u32 r = sqz::fastpath_frame_wave(src, (u32)n, dst, (u32)cap, etab, gen << SQZ_HT_GEN_SHIFT, sched_tab(), &lds, hint);
     *decided = r != 0;
@@ -84,6 +84,49 @@ extern "C" size_t sim_compress_two_stage(const uint8_t* src, size_t n, uint8_t* 
     r = sqz::compress_frame_wave(src, (u32)n, dst, (u32)cap, wsa, L, tg, sched_tab(), hint);
     free(ws);
     return r;
+}
+// The arithmetic that tells the scan which positions are scheduled ones (fast_sched_mask) against the
+// schedule tables, for a chunk of n bytes: returns the number of positions where they disagree and
+// the first such position through *firstBad.
+extern "C" unsigned sim_sched_mask_check(size_t n, unsigned* firstBad) {
+    const u32* tab = sched_tab();
+    u32 const blk1 = (n > SQZ_BLOCKSIZE_MAX) ? SQZ_WINDOW_START + SQZ_BLOCKSIZE_MAX : 0xFFFFFFFFu;
+    std::vector<u8> want(n + 64, 0), got(n + 64, 0);
+    u32 const len0 = n < SQZ_BLOCKSIZE_MAX ? (u32)n : SQZ_BLOCKSIZE_MAX, len1 = (u32)n - len0;
+    for (u32 i = 0; i < tab[0]; i++)
+        if (tab[2 + i] < len0 - 8) want[SQZ_WINDOW_START + tab[2 + i]] = 1;
+    if (len1 >= 9)
+        for (u32 i = 0; i < tab[1]; i++)
+            if (tab[2 + SQZ_SCHEDTAB_N + i] < len1 - 8) want[SQZ_WINDOW_START + SQZ_BLOCKSIZE_MAX + tab[2 + SQZ_SCHEDTAB_N + i]] = 1;
+    unsigned bad = 0;
+    for (s32 align = 0; align < 16; align++) { // the scan's 16-byte windows sit at any alignment
+        std::fill(got.begin(), got.end(), 0);
+        for (s32 lo = align - 16; lo < (s32)(n + SQZ_WINDOW_START); lo += 16) {
+            u32 const m = sqz::fast_sched_mask(tab + SQZ_SCHEDLVL_OFF, lo, blk1, (u32)n + SQZ_WINDOW_START, 0, 0, false);
+            for (u32 j = 0; j < 16; j++)
+                if (((m >> j) & 1) && lo + (s32)j >= 0) got[lo + j] = 1;
+            // the loop-free variant the kernel uses for "plain" windows must agree with the general one
+            bool const second = blk1 != 0xFFFFFFFFu && lo >= (s32)blk1;
+            u32 const bs = second ? blk1 : SQZ_WINDOW_START;
+            u32 const blkEnd = (!second && blk1 != 0xFFFFFFFFu) ? blk1 : (u32)n + SQZ_WINDOW_START;
+            s32 const r = lo - (s32)bs;
+            bool const plain = r >= 4096 && (u32)(lo + 16) <= blkEnd - 8 && !(blk1 != 0xFFFFFFFFu && lo < (s32)blk1 && lo + 16 > (s32)blk1);
+            if (plain) {
+                const u32* lv = tab + SQZ_SCHEDLVL_OFF + (second ? SQZ_SCHEDLVL_N : 0u);
+                u32 const mp = sqz::fast_sched_mask_plain((u32)r, lv[(u32)r >> 8], lv[((u32)r + 15) >> 8]);
+                if (mp != m) {
+                    if (!bad) *firstBad = (unsigned)lo;
+                    bad++;
+                }
+            }
+        }
+        for (u32 p = 0; p < n + SQZ_WINDOW_START; p++)
+            if (want[p] != got[p]) {
+                if (!bad) *firstBad = p;
+                bad++;
+            }
+    }
+    return bad;
 }
 extern "C" size_t sim_fast_lds_bytes(void) { return sizeof(sqz::FastLds); }
 extern "C" size_t sim_workspace_bytes(size_t n) { return sqz::workspace_bytes((u32)n); }

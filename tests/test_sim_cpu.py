@@ -117,6 +117,19 @@ def test_sim_incompressible_kernel_then_compressor(sim, oracle, kind, seed, n):
         assert decided.value == 0
 
 
-def test_fast_kernel_lds_allows_11_waves_per_cu(sim):
+def test_fast_kernel_lds_allows_6_waves_per_cu(sim):
     sim.sim_fast_lds_bytes.restype = ctypes.c_size_t
-    assert sim.sim_fast_lds_bytes() * 11 <= 160 * 1024
+    assert sim.sim_fast_lds_bytes() * 6 <= 160 * 1024
+
+
+@pytest.mark.parametrize("n", [16385, 16392, 16400, 40960, 70000, 131072, 131073, 131080, 131081, 131090, 200000,
+                               262137, 262143, 262144])
+def test_scheduled_position_arithmetic_matches_the_tables(sim, n):
+    """The incompressible-chunk kernel leaves the scheduled search positions out of its scan; it
+    recognises them arithmetically (level words + one multiplication).  For every position of a chunk
+    of n bytes and every alignment of the 16-byte windows that arithmetic must name exactly the
+    positions of the schedule tables -- a wrongly skipped position could hide a repeat."""
+    sim.sim_sched_mask_check.argtypes = [ctypes.c_size_t, ctypes.POINTER(ctypes.c_uint)]
+    sim.sim_sched_mask_check.restype = ctypes.c_uint
+    first = ctypes.c_uint(0)
+    assert sim.sim_sched_mask_check(n, ctypes.byref(first)) == 0, first.value
