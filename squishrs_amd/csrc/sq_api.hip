@@ -523,6 +523,13 @@ static int compress_async(sq_ctx* c, const u8* d_data, const u64* h_off, const u
         fprintf(stderr, "\n");
     }
 #endif
+    if (getenv("SQ_DEBUG_STATS") && fast) { // certificate ends of the first chunks, as stage 1 left them
+        std::vector<u32> ce(2 * (size_t)std::min(n, 24u));
+        (void)hipMemcpy(ce.data(), c->b_cert.p, ce.size() * 4, hipMemcpyDeviceToHost);
+        fprintf(stderr, "[squish_gpu stats] cert ends:");
+        for (size_t i = 0; i < ce.size(); i += 2) fprintf(stderr, " %u/%u", ce[i], ce[i + 1] & 0x7FFFFFFFu);
+        fprintf(stderr, "\n");
+    }
     if (getenv("SQ_DEBUG_STATS")) { // per-wave statistics words of the last chunk each wave compressed
         const sqz::WsLayout L = sqz::ws_layout(max_len);
         for (u32 w = 0; w < waves && w < 6; w++) {

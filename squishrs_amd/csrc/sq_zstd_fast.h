@@ -28,6 +28,9 @@ namespace sqz {
 #define SQZ_FAST_VALS 3584u  // >= scheduled searches of a chunk of this strategy (2 x 1748)
 #define SQZ_FAST_KEYS 1024u  // value buckets: top 10 bits
 #define SQZ_FAST_HITS 32u
+#ifndef SQZ_FAST_LOOKUP_BATCH
+#define SQZ_FAST_LOOKUP_BATCH 64u // Bloom positives collected before their buckets are looked up
+#endif
 #define SQZ_FAST_BUCKET_MAX 24u // a bucket holds 3.4 values on average; beyond this the data is not random
 
 // LDS of one wave of k_incompressible_batch (25.6 KB: 6 waves per CU)
@@ -401,7 +404,22 @@ SQ_DEVFN void cert_lds_core(CertCtx& cx, FastLds* L) {
         if (wv_ballot(!plain)) return fast_sched_mask(lvlWords, lo, blk1, cx.chunkEndPos, wa, wb, plain);
         return fast_sched_mask_plain((u32)r, wa, wb);
     };
-    // one round: Bloom tests, scheduled positions removed, positives looked up; false = list of hits full
+    // look the collected positives up, 64 at a time, while at least `atLeast` are waiting; false = list of hits full
+    u32 nCand = 0;
+    s32 pendFrom = p0; // first position whose positives have not all been looked up yet
+    auto lookUp = [&](u32 atLeast) -> bool {
+        bool ok = true;
+        while (nCand >= atLeast && nCand) {
+            u32 const take = nCand < 64 ? nCand : 64, j0 = nCand - take; // from the end of the list
+            bool const have = lane < take;
+            u32 const hp = have ? cand[2 * (j0 + lane)] : 0u, hv = have ? cand[2 * (j0 + lane) + 1] : 0u;
+            bool const hit = have && inSet(hv);
+            if (!pushHit(hit, hp, hv)) ok = false;
+            nCand = j0;
+        }
+        return ok;
+    };
+    // one round: Bloom tests, scheduled positions removed, positives collected; false = list of hits full
     auto round = [&](sq_v4u w, sq_v4u wn, u32 wl) -> bool {
         u32 wa, wb;
         pickLevels(pos, wl, wa, wb);
@@ -440,32 +458,34 @@ SQ_DEVFN void cert_lds_core(CertCtx& cx, FastLds* L) {
         cm &= okMask;
         cm &= ~schedMaskFast(lo, wa, wb);
         bool ok = true;
-        // compaction (one positive per lane and turn), then the positives are looked up 64 at a time
-        u32 cnt = 0;
+        if (nCand == 0) pendFrom = pos; // nothing older than this round is waiting for its look-up
+        // compaction (one positive per lane and turn) into the list that collects the positives of several
+        // rounds: a look-up is a chain of dependent LDS reads, paid once per 64 positives instead of once
+        // per round
         for (;;) {
             u64 const m = wv_ballot(cm != 0);
             if (!m) break;
+            if (nCand + (u32)__popcll(m) > 128 && !lookUp(1)) ok = false; // make room: look the waiting ones up now
             if (cm) {
                 u32 const j = (u32)__builtin_ctz(cm);
                 cm &= cm - 1;
-                u32 const slot = cnt + (u32)__popcll(m & below);
+                u32 const slot = nCand + (u32)__popcll(m & below);
                 if (slot < 128) {
                     cand[2 * slot] = (u32)(lo + (s32)j);
                     cand[2 * slot + 1] = valAt(w, d4, j);
                 }
             }
-            cnt += (u32)__popcll(m);
+            nCand += (u32)__popcll(m);
         }
         wv_fence();
-        if (cnt > 128) { // not with a working filter on random data: treat like a full list
+        if (nCand > 128) { // not with a working filter on random data: treat like a full list of hits
             ok = false;
-            cnt = 128;
+            cx.nOvf = 1u | (nCand << 8);
+            nCand = 128;
         }
-        for (u32 j0 = 0; j0 < cnt; j0 += 64) {
-            bool const have = j0 + lane < cnt;
-            u32 const hp = have ? cand[2 * (j0 + lane)] : 0u, hv = have ? cand[2 * (j0 + lane) + 1] : 0u;
-            bool const hit = have && inSet(hv);
-            if (!pushHit(hit, hp, hv)) ok = false;
+        if (nCand >= SQZ_FAST_LOOKUP_BATCH && !lookUp(SQZ_FAST_LOOKUP_BATCH)) {
+            ok = false;
+            cx.nOvf = 2u | (nHits << 8);
         }
         pos += 1024;
         return ok;
@@ -500,9 +520,10 @@ SQ_DEVFN void cert_lds_core(CertCtx& cx, FastLds* L) {
             if (!round(wE, wA, lE)) { full = true; break; }
             if (pos >= (s32)scanStop()) break;
         }
-        if (full) { // more genuine repeats than the list holds (compressible data): positions >= pos - 1024
+        if (!full && !lookUp(1)) full = true; // the positives still waiting
+        if (full) { // more genuine repeats than the list holds (compressible data): positions >= pendFrom
             // stay unverified, which only matters to searches beyond them
-            u32 const cut = (u32)((pos - 1024) < (s32)SQZ_WINDOW_START ? (s32)SQZ_WINDOW_START : (pos - 1024)) + 1;
+            u32 const cut = (u32)(pendFrom < (s32)SQZ_WINDOW_START ? (s32)SQZ_WINDOW_START : pendFrom) + 1;
             if (cut < certEnd) certEnd = cut;
             if (cut < certEnd1) certEnd1 = cut;
         }
@@ -605,11 +626,13 @@ SQ_DEVFN u32 fastpath_frame_wave(const u8* src, u32 n, u8* dst, u32 cap, u32* E,
         cx.ovf = nullptr;
         cx.lvl = nullptr;
         cx.certEnd = cx.certEnd1 = 0;
+        cx.nOvf = 0;
         if (cx.nCert > 0 && cx.nCert <= SQZ_FAST_VALS) {
             cx.dbg = dbg;
             cert_lds_core(cx, L);
             c0 = cx.certEnd;
             c1 = cx.certEnd1 | SQZ_CERT_HINT_VALID;
+            if (dbg & 64) c0 = cx.nOvf; // bring-up: why the scan gave up
             // every search of every block certainly fails?
             bool whole = cx.certEnd >= SQZ_WINDOW_START + len0 - 8;
             if (len1) whole = whole && (cx.certEnd1 >= SQZ_WINDOW_START + SQZ_BLOCKSIZE_MAX + len1 - 8);
