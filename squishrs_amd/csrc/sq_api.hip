@@ -387,17 +387,13 @@ static int compress_async(sq_ctx* c, const u8* d_data, const u64* h_off, const u
     const size_t ws_each = sqz::workspace_bytes(max_len);
     // keep the workspace pool within ~96 GiB
     while (waves > 64 && (u64)waves * ws_each > (96ull << 30)) waves /= 2;
-    // Stage 1, the incompressible-chunk kernel (sq_zstd_fast.h): twice the waves, one certificate
-    // table each (8 bytes x 2^(chainLog-1) of the largest btlazy2 chunk), carved from the same pool.
-    // It only applies to chunks of 16 KiB < len <= 256 KiB.
+    // Stage 1, the incompressible-chunk kernel (sq_zstd_fast.h): as many waves as fit (its state is all
+    // in LDS).  It only applies to chunks of 16 KiB < len <= 256 KiB.
     const bool fast = max_len > (16u << 10) && !getenv("SQ_NO_FASTPATH");
     u32 fwaves = 0;
     size_t etab_bytes = 0;
     if (fast) {
-        u32 w = 15;
-        const u32 ml = std::min(max_len, 256u << 10);
-        while ((1u << w) < ml) w++;
-        etab_bytes = (size_t)8 << w; // chainLog - 1 == windowLog
+        etab_bytes = 0; // the certificate's set lives in LDS now; a wave's slice only keeps its 256 bytes of saved state
         int occ = 0; // resident waves per CU (LDS-bound)
         (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, sqz::k_incompressible_batch, 64, 0);
         if (occ < 1) occ = 4;
