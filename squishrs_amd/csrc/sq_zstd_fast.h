@@ -33,10 +33,10 @@ namespace sqz {
 #endif
 #define SQZ_FAST_BUCKET_MAX 24u // a bucket holds 3.4 values on average; beyond this the data is not random
 
-// LDS of one wave of k_incompressible_batch (25.6 KB: 6 waves per CU)
+// LDS of one wave of k_incompressible_batch (18.3 KB: 8 waves per CU)
 struct FastLds {
     u32 bloom[SQZ_BLOOM_WORDS];      // certificate Bloom filter; afterwards the 256-bin sample histograms
-    u32 vals[SQZ_FAST_VALS];         // the 4-byte values at the scheduled positions, grouped by their top 10 bits
+    u16 vals[SQZ_FAST_VALS];         // per scheduled position: bits 6..21 of its 4-byte value, grouped by bits 22..31
     u32 ends[SQZ_FAST_KEYS / 2 + 2]; // per bucket, packed 2 x u16: first counts, then starts, finally END offsets
     u32 cand[256];                   // a round's Bloom positives: 128 x (position, bytes)
     u32 hits[2 * SQZ_FAST_HITS];     // (position, bytes) of scanned positions whose bytes equal a scheduled position's;
@@ -182,7 +182,7 @@ SQ_DEVFN void cert_lds_core(CertCtx& cx, FastLds* L) {
     u32 const pEnd = cx.chunkEndPos - 3; // one past the last p with p + 4 <= chunkEnd
     const u32* const lvlWords = cx.schedTab + SQZ_SCHEDLVL_OFF;
     SQ_L u32* const bloom = (SQ_L u32*)L->bloom;
-    SQ_L u32* const vals = (SQ_L u32*)L->vals;
+    SQ_L u16* const vals = (SQ_L u16*)L->vals; // 16-bit tags: with the bucket's 10 bits, 26 bits of the value
     SQ_L u32* const ends = (SQ_L u32*)L->ends;
     SQ_L u32* const hits = (SQ_L u32*)L->hits;
     u32 nHits = 0;
@@ -302,7 +302,7 @@ SQ_DEVFN void cert_lds_core(CertCtx& cx, FastLds* L) {
         for (u32 g = 0; g < 8; g++)
             if (i0 + 64 * g + lane < nCert) {
                 u32 const slot = fast_cnt16_add(ends, v[g] >> 22);
-                if (slot < SQZ_FAST_VALS) vals[slot] = v[g];
+                if (slot < SQZ_FAST_VALS) vals[slot] = (u16)(v[g] >> 6);
             }
     }
     wv_fence();
@@ -320,9 +320,9 @@ SQ_DEVFN void cert_lds_core(CertCtx& cx, FastLds* L) {
                 u32 const vb = vals[b];
                 u32 seen = 0;
                 for (u32 a = lo; a < b; a++) seen += (vals[a] == vb) ? 1u : 0u;
-                if (seen == 1) { // exactly one earlier copy: first time this value repeats
+                if (seen == 1) { // exactly one earlier copy: first time these 26 bits repeat
                     dup = true;
-                    dupv = vb;
+                    dupv = (k << 22) | (vb << 6); // the bits 6..31 they share; resolved on full values below
                 }
             }
             if (!wv_ballot(dup)) break;
@@ -386,10 +386,11 @@ SQ_DEVFN void cert_lds_core(CertCtx& cx, FastLds* L) {
         u32 b[8];
 #pragma unroll
         for (u32 a = 0; a < 8; a++) b[a] = vals[(lo + a < SQZ_FAST_VALS) ? lo + a : SQZ_FAST_VALS - 1];
+        u32 const tp = (vp >> 6) & 0xFFFFu;
         bool f = false;
 #pragma unroll
-        for (u32 a = 0; a < 8; a++) f = f || (lo + a < hi && b[a] == vp);
-        for (u32 a = lo + 8; a < hi; a++) f = f || (vals[a] == vp);
+        for (u32 a = 0; a < 8; a++) f = f || (lo + a < hi && b[a] == tp);
+        for (u32 a = lo + 8; a < hi; a++) f = f || (vals[a] == tp);
         return f;
     };
     // Scheduled positions among a lane's 16, for windows whose levels are all >= 16 (one candidate per
@@ -532,25 +533,54 @@ SQ_DEVFN void cert_lds_core(CertCtx& cx, FastLds* L) {
     // an earlier position (a scanned position p, or for a pair inside the schedule the earliest member)
     for (u32 hIdx = 0; hIdx < nHits; hIdx++) {
         u32 const hp = hits[2 * hIdx], hv = hits[2 * hIdx + 1];
-        u32 thr = hp;
-        if (hp == 0) { // pair inside the schedule: everything after its earliest member
-            u32 mn = 0xFFFFFFFFu;
-            for (u32 i0 = 0; i0 < nCert; i0 += 64) {
-                u32 const i = i0 + lane;
-                u32 const sp = cert_pos_c(cx, i < nCert ? i : iLast);
-                if (i < nCert && sq_grd32(base + sp) == hv && sp < mn) mn = sp;
-            }
-            for (int sft = 32; sft >= 1; sft >>= 1) {
-                u32 const y = (u32)__shfl_xor((int)mn, sft, 64);
-                mn = y < mn ? y : mn;
-            }
-            thr = wv_uni(mn);
-        }
         u32 v0 = 0xFFFFFFFFu, v1 = 0xFFFFFFFFu;
-        for (u32 i0 = 0; i0 < nCert; i0 += 64) {
-            u32 const i = i0 + lane;
-            u32 const sp = cert_pos_c(cx, i < nCert ? i : iLast);
-            if (i < nCert && sq_grd32(base + sp) == hv && sp > thr) note(sp, v0, v1);
+        if (hp != 0) { // a scanned position p with the bytes hv: every scheduled s > p with those bytes
+            for (u32 i0 = 0; i0 < nCert; i0 += 512) {
+                u32 sp[8], v[8];
+#pragma unroll
+                for (u32 g = 0; g < 8; g++) {
+                    u32 const i = i0 + 64 * g + lane;
+                    sp[g] = cert_pos_c(cx, i < nCert ? i : iLast);
+                }
+#pragma unroll
+                for (u32 g = 0; g < 8; g++) v[g] = sq_grd32(base + sp[g]);
+#pragma unroll
+                for (u32 g = 0; g < 8; g++)
+                    if (i0 + 64 * g + lane < nCert && v[g] == hv && sp[g] > hp) note(sp[g], v0, v1);
+            }
+        } else {
+            // two scheduled positions share bits 6..31 of their values (hv).  Collect the (few) members of
+            // that class; a member whose full value equals an earlier member's is a search that can succeed.
+            SQ_L u32* const mem = (SQ_L u32*)L->cand; // [0] count, then (position, value) pairs
+            if (lane == 0) mem[0] = 0;
+            wv_fence();
+            for (u32 i0 = 0; i0 < nCert; i0 += 512) {
+                u32 sp[8], v[8];
+#pragma unroll
+                for (u32 g = 0; g < 8; g++) {
+                    u32 const i = i0 + 64 * g + lane;
+                    sp[g] = cert_pos_c(cx, i < nCert ? i : iLast);
+                }
+#pragma unroll
+                for (u32 g = 0; g < 8; g++) v[g] = sq_grd32(base + sp[g]);
+#pragma unroll
+                for (u32 g = 0; g < 8; g++)
+                    if (i0 + 64 * g + lane < nCert && (v[g] & 0xFFFFFFC0u) == hv) {
+                        u32 const at = __hip_atomic_fetch_add(&mem[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        if (at < 60) {
+                            mem[2 + 2 * at] = sp[g];
+                            mem[3 + 2 * at] = v[g];
+                        }
+                    }
+            }
+            wv_fence();
+            u32 const nm = mem[0];
+            if (lane < nm && lane < 60) {
+                u32 const ms = mem[2 + 2 * lane], mv = mem[3 + 2 * lane];
+                bool rpt = nm > 60; // more members than we keep: every one counts as a repeat (conservative)
+                for (u32 j = 0; j < nm && j < 60; j++) rpt = rpt || (mem[3 + 2 * j] == mv && mem[2 + 2 * j] < ms);
+                if (rpt) note(ms, v0, v1);
+            }
         }
         settle(v0, v1);
     }
