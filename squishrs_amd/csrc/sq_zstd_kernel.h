@@ -409,6 +409,8 @@ SQ_DEVFN u32 compress_frame_wave(const u8* src, u32 n, u8* dst, u32 cap, u8* ws,
     ms.tailTab = (u32*)(ws + L.certTab);
     ms.tailTabClean = &tg.tailTabClean;
     ms.tailTried = 0;
+    ms.tailAt = 0;
+    ms.tailSeqs = 0;
     ms.nCert = ms.nCertDone = ms.certEnd = ms.certEnd1 = 0;
     ms.nLive = ms.nSkip = ms.nBlocks = 0;
     ms.specOff = 0;

@@ -104,7 +104,9 @@ struct MatchState {
     u32 certEnd1;    // the same for block 1 (given that block 1 starts with repcode offset 1)
     u32* tailTab;        // table of the tail certificate (workspace; see tail_certify)
     u32* tailTabClean;   // -> the wave's flag: that table has been cleared in this launch
-    u32 tailTried;       // a tail certificate has been attempted in this chunk
+    u32 tailTried;       // tail certificates attempted in this chunk (at most SQZ_TAIL_TRIES)
+    u32 tailAt, tailSeqs; // where the last one was attempted, and how many sequences the block had then
+    u32 tailBlkTried;    // one has been attempted in the current block
     u32 sbMax;       // current super-batch length of the filtered insertion stream (256..2048)
     u32 genBits;     // btlazy2 hash-table generation tag of this chunk, in place (bits 19..29)
     CParams cp;
@@ -126,6 +128,7 @@ struct MatchState {
 #define SQZ_SKIP_CAP 256u
 #define SQZ_MAX_REPAIRS 24u
 #define SQZ_BLOCKTAB_CAP 64u
+#define SQZ_TAIL_TRIES 4u // tail certificates per chunk (each later one first clears its 2 MiB table)
 #ifndef SQZ_EPOCH_AFTER_FAILS
 #define SQZ_EPOCH_AFTER_FAILS 16u // plain no-match searches in a row before speculative epochs start
 #endif
@@ -1285,7 +1288,9 @@ SQ_DEVFN bool tail_certify(MatchState& ms, u32 ipPos, u32 anc, u32 off1, u32 ili
     cx.ovf = (SQ_L u32*)&g_lds.ent[ms.nxEnt & 1];
     cx.lvl = nullptr;
     cx.dbg = 0;
-    if (!*ms.tailTabClean) { // first use in this launch (or after a change of size class)
+    // The table must hold no entry with this chunk's tag: first use in this launch (or after a change of
+    // size class), or an earlier tail certificate of this same chunk
+    if (!*ms.tailTabClean || ms.tailTried > 1) {
         wv_fill32(cx.E, 0, (size_t)2 << cx.eLog);
         *ms.tailTabClean = 1;
     }
@@ -1967,6 +1972,8 @@ SQ_DEVFN u32 compressBlock_lazy(MatchState& ms, SeqStore& ss, u32* rep, const u8
         if (offset_1 > maxRep) offsetSaved1 = offset_1, offset_1 = 0;
     }
     ms.lazySkipping = 0;
+    ms.tailSeqs = 0; // sequences are counted per block
+    ms.tailBlkTried = 0;
 
     if (!ROW && (ms.certEnd | ms.certEnd1)) {
         // No-match certificate (cert_compute): the scheduled searches of this block at positions
@@ -2023,7 +2030,8 @@ SQ_DEVFN u32 compressBlock_lazy(MatchState& ms, SeqStore& ss, u32* rep, const u8
         u32 offBase = 1; // REPCODE1_TO_OFFBASE
         const u8* start = ip + 1;
         ms.anchorPos = (u32)(anchor - base);
-        if (!ROW && !ms.tailTried && (failStreak >= SQZ_EPOCH_AFTER_FAILS || ss.nseq > 0) && (ms.eager || ms.nLive)) {
+        if (!ROW && ms.tailTried < SQZ_TAIL_TRIES && ms.tailAt != (u32)(ip - base) &&
+            (ss.nseq > ms.tailSeqs || (!ms.tailBlkTried && failStreak >= SQZ_EPOCH_AFTER_FAILS)) && (ms.eager || ms.nLive)) {
             // The finder was woken by a hand-over and the exact code has dealt with what stopped the
             // certificate (a sequence has been stored, or the search found nothing after all): before
             // the next search (and the schedule repair it would trigger), ask the tail certificate whether the rest of this block can
@@ -2037,7 +2045,11 @@ SQ_DEVFN u32 compressBlock_lazy(MatchState& ms, SeqStore& ss, u32* rep, const u8
                 u32 const lim1 = ms.chunkEndPos - 8;
                 lastOrCovered = ms.certEnd1 >= lim1 && (offset_1 <= 1 || cert_rep_recheck(ms, offset_1, lim1) >= lim1);
             }
-            ms.tailTried = 1;
+            ms.tailTried++;
+            SQ_TRACE(43, ms.tailTried);
+            ms.tailAt = (u32)(ip - base); // not again before the parser has moved on ...
+            ms.tailSeqs = ss.nseq;        // ... and stored another sequence
+            ms.tailBlkTried = 1;
             if (lastOrCovered) {
                 if (tail_certify(ms, (u32)(ip - base), (u32)(anchor - base), offset_1, (u32)(ilimit - base))) {
                     SQ_TRACE(39, 1);

@@ -29,8 +29,8 @@ extern "C" size_t sim_compress_chunk(const uint8_t* src, size_t n, uint8_t* dst,
     u32 r = sqz::compress_frame_wave(src, (u32)n, dst, (u32)cap, wsa, L, tg, sched_tab(), nullptr);
     if (getenv("SQ_SIM_STATS")) {
         const u32* t = (const u32*)(wsa + L.dummy) + 8;
-        fprintf(stderr, "[sim] n=%zu eager=%u repairs=%u live=%u skips=%u epochs=%u specfail=%u replays=%u certified=%u lastblock_skipped_live=%u tail_certified=%u\n", n, t[30],
-                t[31], t[32], t[33], t[34], t[35], t[36], t[37], t[38], t[39]);
+        fprintf(stderr, "[sim] n=%zu eager=%u repairs=%u live=%u skips=%u epochs=%u specfail=%u replays=%u certified=%u lastblock_skipped_live=%u tail_certified=%u tail_tries=%u\n", n, t[30],
+                t[31], t[32], t[33], t[34], t[35], t[36], t[37], t[38], t[39], t[43]);
     }
     free(ws);
     return r;
