@@ -80,7 +80,7 @@ struct sq_ctx {
 
     // per-batch scratch
     DevBuf b_off, b_len, b_slot_off, b_frame_len, b_out_off, b_isnew, b_hashes, b_stage_in,
-        b_stage_out, b_slots, b_ws, b_misc, b_cert, b_etab;
+        b_stage_out, b_slots, b_ws, b_misc, b_cert, b_etab, b_work;
     // shapes of the two table pools at the last launch that completed (persistent generation tags)
     void* ws_ptr_last = nullptr;
     size_t ws_each_last = 0;
@@ -202,7 +202,7 @@ void sq_ctx_destroy(sq_ctx* c) {
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     for (DevBuf* b : {&c->b_off, &c->b_len, &c->b_slot_off, &c->b_frame_len, &c->b_out_off, &c->b_isnew,
-                      &c->b_hashes, &c->b_stage_in, &c->b_stage_out, &c->b_slots, &c->b_ws, &c->b_misc, &c->b_cert, &c->b_etab})
+                      &c->b_hashes, &c->b_stage_in, &c->b_stage_out, &c->b_slots, &c->b_ws, &c->b_misc, &c->b_cert, &c->b_etab, &c->b_work})
         b->release();
     if (c->d_table) (void)hipFree(c->d_table);
     if (c->d_keys) (void)hipFree(c->d_keys);
@@ -400,6 +400,8 @@ static int compress_async(sq_ctx* c, const u8* d_data, const u64* h_off, const u
         fwaves = c->cfg.compress_waves ? c->cfg.compress_waves * 2 : (u32)c->num_cu * (u32)occ;
         fwaves = std::min(fwaves, n);
         if ((r = c->b_cert.ensure((size_t)n * 8))) return r;
+        if ((r = c->b_work.ensure(((size_t)2 * n + 2) * 4))) return r;
+        HIPCHK(hipMemsetAsync(c->b_work.p, 0, 8, c->stream));
     }
     if ((r = c->b_ws.ensure((size_t)waves * ws_each + 256))) return r;
     if (fast && (r = c->b_etab.ensure((size_t)fwaves * (etab_bytes + 256)))) return r;
@@ -430,7 +432,7 @@ static int compress_async(sq_ctx* c, const u8* d_data, const u64* h_off, const u
                            (const u64*)c->b_off.p, (const u32*)c->b_len.p, d_select, n, d_slots,
                            (const u64*)c->b_slot_off.p, (u32*)c->b_frame_len.p, (u32*)c->b_cert.p, (u8*)c->b_etab.p,
                            (u64)etab_bytes, (u32*)c->b_misc.p + 32 /*queue*/, (const u32*)c->d_sched_tab,
-                           (u32)(getenv("SQ_FAST_DBG") ? atoi(getenv("SQ_FAST_DBG")) : 0), etab_persist);
+                           (u32)(getenv("SQ_FAST_DBG") ? atoi(getenv("SQ_FAST_DBG")) : 0), etab_persist, (u32*)c->b_work.p);
         HIPCHK(hipGetLastError());
         HIPCHK(hipEventRecord(c->ev[9], c->stream));
     }
@@ -442,7 +444,8 @@ static int compress_async(sq_ctx* c, const u8* d_data, const u64* h_off, const u
                            (const u32*)c->b_len.p, d_select, n, d_slots,
                            (const u64*)c->b_slot_off.p, (u32*)c->b_frame_len.p, (u8*)c->b_ws.p,
                            (u64)ws_each, (u32*)c->b_misc.p /*queue*/, (u32*)c->b_misc.p + 16 /*err*/,
-                           (const u32*)c->d_sched_tab, fast ? (const u32*)c->b_cert.p : (const u32*)nullptr, ws_persist);
+                           (const u32*)c->d_sched_tab, fast ? (const u32*)c->b_cert.p : (const u32*)nullptr, ws_persist,
+                           fast ? (const u32*)c->b_work.p : (const u32*)nullptr);
         HIPCHK(hipGetLastError());
     }
     HIPCHK(hipEventRecord(c->ev[5], c->stream));

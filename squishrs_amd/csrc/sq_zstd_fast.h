@@ -705,7 +705,10 @@ SQ_DEVFN u32 fastpath_frame_wave(const u8* src, u32 n, u8* dst, u32 cap, u32* E,
 __global__ void __launch_bounds__(64, 2)
 k_incompressible_batch(const u8* data, const u64* off, const u32* len, const u8* select, u32 n, u8* slots,
                        const u64* slot_off, u32* frame_len, u32* cert_out, u8* etab_pool, u64 etab_bytes,
-                       u32* queue, const u32* schedTab, u32 dbg, u32 persist) { // queue[1]: number of chunks decided here
+                       u32* queue, const u32* schedTab, u32 dbg, u32 persist, u32* work) {
+    // queue[1]: number of chunks decided here.  work: the chunks left to k_compress_batch, as two index
+    // lists: [0] / [1] their lengths, then n slots for the "heavy" ones (certified in neither block: the
+    // whole exact path) and n slots for the others.
     __shared__ FastLds lds;
     // a wave's slice: its table, then 256 bytes that keep its generation counter between launches
     u32* const E = (u32*)(etab_pool + (u64)blockIdx.x * (etab_bytes + 256));
@@ -735,7 +738,16 @@ k_incompressible_batch(const u8* data, const u64* off, const u32* len, const u8*
         }
         if (wv_lane() == 0) {
             frame_len[idx] = r;
-            if (r) atomicAdd(queue + 1, 1u);
+            if (r)
+                atomicAdd(queue + 1, 1u);
+            else if (select == nullptr || select[idx] != 0) {
+                u32 const L = len[idx], h0 = cert_out[2 * (size_t)idx], h1 = cert_out[2 * (size_t)idx + 1];
+                u32 const len0 = L < SQZ_BLOCKSIZE_MAX ? L : SQZ_BLOCKSIZE_MAX;
+                bool const heavy = (h1 & SQZ_CERT_HINT_VALID) && L > SQZ_BLOCKSIZE_MAX + 8 && len0 >= 9 &&
+                                   h0 < SQZ_WINDOW_START + len0 - 8 && (h1 & ~SQZ_CERT_HINT_VALID) < SQZ_WINDOW_START + L - 8;
+                u32 const at = atomicAdd(work + (heavy ? 0 : 1), 1u);
+                work[2 + (heavy ? 0u : n) + at] = idx;
+            }
         }
     }
     if (wv_lane() == 0) saved[0] = gen;

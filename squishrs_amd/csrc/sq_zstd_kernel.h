@@ -582,7 +582,7 @@ __device__ __noinline__ void compress_one(const u8* data, const u64* off, const 
 __global__ void __launch_bounds__(64, 2) // 2 waves per SIMD: <= 256 registers, 8 waves per CU (LDS: 8 x 19 KiB)
 k_compress_batch(const u8* data, const u64* off, const u32* len, const u8* select, u32 n, u8* slots,
                  const u64* slot_off, u32* frame_len, u8* ws_pool, u64 ws_each, u32* queue, u32* err,
-                 const u32* schedTab, const u32* certHint, u32 persist) {
+                 const u32* schedTab, const u32* certHint, u32 persist, const u32* work) {
     u8* const ws = ws_pool + (u64)blockIdx.x * ws_each;
     u32* const dbg = (u32*)(ws + ws_each - 256) + 8; // wave-level progress words for the watchdog
     u32 iter = 0;
@@ -601,21 +601,29 @@ k_compress_batch(const u8* data, const u64* off, const u32* len, const u8* selec
         for (int k = 0; k < 32; k++) g_lds.prof[k] = 0;
     wv_fence();
 #endif
-    for (;;) {
-        u32 idx = 0;
-        if (wv_lane() == 0) idx = atomicAdd(queue, 1u);
-        idx = wv_uni(idx);
-        if (wv_lane() == 0) {
-            dbg[12] = 1000 + iter;
-            dbg[13] = idx;
+    // When stage 1 ran it left two lists of the chunks it did not decide: first the "heavy" ones (certified
+    // in neither block: the whole exact path, several times the cost of the others), then the rest --
+    // longest jobs first, one chunk per claim, nothing to skip.  Without stage 1: every index in order.
+    // queue[0] / queue[1]: the two passes' counters.
+    for (u32 pass = work ? 0u : 1u; pass < 2; pass++) {
+        u32 const count = work ? gld32(work + pass) : n;
+        const u32* const list = work ? work + 2 + (pass ? n : 0u) : nullptr;
+        for (;;) {
+            u32 q = 0;
+            if (wv_lane() == 0) q = atomicAdd(queue + pass, 1u);
+            q = wv_uni(q);
+            if (wv_lane() == 0) {
+                dbg[12] = 1000 + iter;
+                dbg[13] = q;
+            }
+            iter++;
+            if (q >= count) break;
+            u32 const idx = list ? gld32(list + q) : q;
+            bool const take = list || (select == nullptr) || (select[idx] != 0);
+            PROF_T0(t_all);
+            if (take) compress_one(data, off, len, idx, slots, slot_off, frame_len, ws, err, tg, schedTab, certHint);
+            PROF_ADD(0, t_all);
         }
-        iter++;
-        if (idx >= n) break;
-        // certHint != nullptr: k_incompressible_batch ran first; a non-zero frame length is its frame
-        bool const take = ((select == nullptr) || (select[idx] != 0)) && !(certHint && frame_len[idx] != 0);
-        PROF_T0(t_all);
-        if (take) compress_one(data, off, len, idx, slots, slot_off, frame_len, ws, err, tg, schedTab, certHint);
-        PROF_ADD(0, t_all);
     }
     if (wv_lane() == 0) {
         dbg[11] = 777;
