@@ -272,3 +272,65 @@ def test_table_generations_persist_across_launches(oracle):
             assert _batch_compress(st, batch) == ref[id(batch)]
     finally:
         st.close()
+
+
+def test_unaligned_chunk_starts(gpu_store, oracle):
+    """Chunks may start at any byte offset of the batch buffer.  The incompressible-chunk kernel reads its
+    input in aligned 16-byte windows and recognises the scheduled search positions arithmetically, so every
+    residue of the start address modulo 16 (and chunks that end right at the buffer's last bytes) must give
+    the oracle's frames."""
+    import torch
+    import squishrs_amd
+    kinds = ["random", "planted0", "random", "planted3", "planted6", "random", "planted9", "text", "planted4",
+             "random", "planted1", "random", "mixed", "planted8", "random", "random", "planted2"]
+    sizes = [262144, 200000, 70000, 131072 + 40961, 262144, 40960, 262144, 60000, 150000,
+             16385, 262143, 131081, 100000, 262144, 131072, 262137, 99999]
+    chunks = [corpus.make(kinds[i], 700 + i, sizes[i]) for i in range(len(kinds))]
+    offs = np.zeros(len(chunks), dtype=np.uint64)
+    pos = 3
+    for i, c in enumerate(chunks):
+        offs[i] = pos                      # residues 3, 4+, ... : every chunk start lands on another residue
+        pos += len(c) + 1 + (i % 5)
+    lens = np.array([len(c) for c in chunks], dtype=np.uint32)
+    buf = np.zeros(pos, dtype=np.uint8)    # the last chunk ends at the very end of the buffer (+ its gap)
+    for i, c in enumerate(chunks):
+        buf[int(offs[i]):int(offs[i]) + len(c)] = np.frombuffer(c, dtype=np.uint8)
+    assert len({int(o) % 16 for o in offs}) >= 8
+    d = torch.from_numpy(buf).cuda()
+    comp = torch.zeros(gpu_store.slots_bound(lens), dtype=torch.uint8, device="cuda")
+    coff, clen = gpu_store.compress_device_slots(d, offs, lens, None, comp)
+    host = comp.cpu().numpy()
+    for i, c in enumerate(chunks):
+        assert host[int(coff[i]):int(coff[i]) + int(clen[i])].tobytes() == oracle.compress_chunk(c), (i, kinds[i], sizes[i])
+
+
+def test_stage1_stress_random_sizes_and_alignments(gpu_store, oracle):
+    """600 chunks of the btlazy2 size range with arbitrary lengths, arbitrary start alignments and a
+    sprinkling of planted repeats, in one batch: every frame against the oracle.  (Lengths around the
+    block boundary, the 40,960-byte threshold of the literal pre-check and the ends of the range
+    included.)"""
+    import torch
+    rng = np.random.default_rng(20240607)
+    special = [16385, 16400, 40959, 40960, 40961, 131064, 131071, 131072, 131073, 131080, 131081, 131090,
+               131072 + 40959, 131072 + 40960, 131072 + 40961, 262129, 262143, 262144]
+    chunks = []
+    for i in range(600):
+        n = special[i] if i < len(special) else int(rng.integers(16385, 262145))
+        kind = "random" if i % 4 else "planted%d" % int(rng.integers(0, 10))
+        chunks.append(corpus.make(kind, 9000 + i, n))
+    offs = np.zeros(len(chunks), dtype=np.uint64)
+    pos = 1
+    for i, c in enumerate(chunks):
+        offs[i] = pos
+        pos += len(c) + int(rng.integers(0, 37))
+    lens = np.array([len(c) for c in chunks], dtype=np.uint32)
+    buf = np.zeros(pos + 64, dtype=np.uint8)
+    for i, c in enumerate(chunks):
+        buf[int(offs[i]):int(offs[i]) + len(c)] = np.frombuffer(c, dtype=np.uint8)
+    d = torch.from_numpy(buf).cuda()
+    comp = torch.zeros(gpu_store.slots_bound(lens), dtype=torch.uint8, device="cuda")
+    coff, clen = gpu_store.compress_device_slots(d, offs, lens, None, comp)
+    host = comp.cpu().numpy()
+    bad = [i for i, c in enumerate(chunks)
+           if host[int(coff[i]):int(coff[i]) + int(clen[i])].tobytes() != oracle.compress_chunk(c)]
+    assert not bad, [(i, len(chunks[i])) for i in bad[:10]]
