@@ -167,7 +167,7 @@ def main():
                 "compress_stage": {"k_incompressible_batch_ms": fms, "k_compress_batch_ms": cms,
                                    "chunks_decided_by_stage1": decided,
                                    "stage_GBps": (n * L + clen_total) / ((fms + cms) / 1e3) / 1e9},
-                "hash_kernel": {"kernel": "sqx::k_xxh3_128_batch", "ms": hms,
+                "hash_kernel": {"kernel": "sqx::k_xxh3_128_rows", "ms": hms,
                                 "achieved": hash_bytes / (hms / 1e3) / 1e9,
                                 "frac": hash_bytes / (hms / 1e3) / 1e9 / 8000.0},
                 "dedup_ms": float(np.mean(kern["dedup"])), "compact_ms": float(np.mean(kern["compact"])),

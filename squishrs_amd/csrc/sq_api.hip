@@ -269,10 +269,16 @@ static int upload_off_len(sq_ctx* c, const u64* h_off, const u32* h_len, u32 n) 
 static int launch_hash(sq_ctx* c, const u8* d_data, u32 n, u8* d_hashes) {
     if (n == 0) return SQ_OK;
     const u32 wpb = 4;
-    dim3 grid((n + wpb - 1) / wpb), block(64 * wpb);
     HIPCHK(hipEventRecord(c->ev[0], c->stream));
-    hipLaunchKernelGGL(sqx::k_xxh3_128_batch, grid, block, 0, c->stream, d_data, (const u64*)c->b_off.p,
-                       (const u32*)c->b_len.p, n, d_hashes);
+    if (getenv("SQ_HASH_WAVE_PER_CHUNK")) { // the first mapping: one wave per chunk
+        dim3 grid((n + wpb - 1) / wpb), block(64 * wpb);
+        hipLaunchKernelGGL(sqx::k_xxh3_128_batch, grid, block, 0, c->stream, d_data, (const u64*)c->b_off.p,
+                           (const u32*)c->b_len.p, n, d_hashes);
+    } else { // 16 lanes per chunk, four chunks per wave
+        dim3 grid((n + 4 * wpb - 1) / (4 * wpb)), block(64 * wpb);
+        hipLaunchKernelGGL(sqx::k_xxh3_128_rows, grid, block, 0, c->stream, d_data, (const u64*)c->b_off.p,
+                           (const u32*)c->b_len.p, n, d_hashes);
+    }
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(c->ev[1], c->stream));
     return SQ_OK;

@@ -1,4 +1,5 @@
-// sq_xxh3.h -- batched XXH3-128 (seed 0, default secret) for gfx950: one wavefront per chunk.
+// sq_xxh3.h -- batched XXH3-128 (seed 0, default secret) for gfx950: k_xxh3_128_rows (16 lanes per chunk,
+// the default) and k_xxh3_128_batch (one wavefront per chunk, the first mapping).
 //
 // Replaces hash_chunk, /root/reference/src/util/chunk.rs:46-49
 //     xxh3_128(chunk).to_le_bytes()          (xxhash-rust 0.8.15, Cargo.lock:1593-1596)
@@ -219,6 +220,137 @@ __device__ inline H128 hash_long_wave(const u8* __restrict__ p, u64 len, u32 lan
 }
 
 // grid: ceil(n / wavesPerBlock) blocks of 64*wavesPerBlock threads
+// ---- 16 lanes per chunk, four chunks per wave -------------------------------------------------
+// The wave-per-chunk mapping above spends most of its instructions on the 4-step butterfly (16
+// ds_bpermute per 1 KiB block) that sums the 16 stripes.  Here a row of 16 lanes owns a chunk: lane
+// 4*g + j holds the accumulator pair j (words 2j, 2j+1) for the stripes g, g+4, g+8, g+12 of every block,
+// sums its four stripes privately and the four groups are then summed with two DPP row rotations (no
+// LDS traffic): ~70 instructions per block and row instead of ~76 per block and wave.  A row's 16-byte
+// loads cover 256 contiguous bytes; the four rows of a wave stream four different chunks.
+__device__ __forceinline__ u64 row_ror64(u64 v, int ctrl) { // DPP row rotation of a 64-bit value
+    u32 lo = (u32)v, hi = (u32)(v >> 32);
+    if (ctrl == 4) {
+        lo = (u32)__builtin_amdgcn_update_dpp(0, (int)lo, 0x124, 0xF, 0xF, false);
+        hi = (u32)__builtin_amdgcn_update_dpp(0, (int)hi, 0x124, 0xF, 0xF, false);
+    } else {
+        lo = (u32)__builtin_amdgcn_update_dpp(0, (int)lo, 0x128, 0xF, 0xF, false);
+        hi = (u32)__builtin_amdgcn_update_dpp(0, (int)hi, 0x128, 0xF, 0xF, false);
+    }
+    return ((u64)hi << 32) | lo;
+}
+__device__ __forceinline__ u64 quad_xor64(u64 v, int m) { // value of lane ^ m inside the quad
+    u32 lo = (u32)v, hi = (u32)(v >> 32);
+    if (m == 1) {
+        lo = (u32)__builtin_amdgcn_update_dpp(0, (int)lo, 0xB1, 0xF, 0xF, false); // quad_perm [1,0,3,2]
+        hi = (u32)__builtin_amdgcn_update_dpp(0, (int)hi, 0xB1, 0xF, 0xF, false);
+    } else {
+        lo = (u32)__builtin_amdgcn_update_dpp(0, (int)lo, 0x4E, 0xF, 0xF, false); // quad_perm [2,3,0,1]
+        hi = (u32)__builtin_amdgcn_update_dpp(0, (int)hi, 0x4E, 0xF, 0xF, false);
+    }
+    return ((u64)hi << 32) | lo;
+}
+
+// One 16-lane row, one chunk of `len` > 240 bytes.  Every lane of the row returns the hash.
+__device__ inline H128 hash_long_row(const u8* __restrict__ p, u64 len, u32 lane) {
+    const u32 rl = lane & 15, g = rl >> 2, j = rl & 3, i0 = 2 * j;
+    const u64 sc0 = sec64(128 + 8 * i0), sc1 = sec64(128 + 8 * i0 + 8);
+    // secret words of the four stripes this lane owns (stripe s uses secret offset 8*s)
+    u64 k0[4], k1[4];
+#pragma unroll
+    for (int t = 0; t < 4; t++) {
+        k0[t] = sec64(8 * (g + 4 * t) + 8 * i0);
+        k1[t] = sec64(8 * (g + 4 * t) + 8 * i0 + 8);
+    }
+    const u64 init[8] = {P32_3, P64_1, P64_2, P64_3, P64_4, P32_2, P64_5, P32_1};
+    u64 a0 = init[i0], a1 = init[i0 + 1];
+    const u64 nbBlocks = (len - 1) >> 10;
+    const u8* q = p + 64 * g + 16 * j; // this lane's 16 bytes of stripe g of block 0
+
+    auto fold = [&](u64 c0, u64 c1, bool scramble) { // sum the four groups of the row, then the block's scramble
+        c0 += row_ror64(c0, 4);
+        c1 += row_ror64(c1, 4);
+        c0 += row_ror64(c0, 8);
+        c1 += row_ror64(c1, 8);
+        a0 += c0;
+        a1 += c1;
+        if (scramble) {
+            a0 = (a0 ^ (a0 >> 47) ^ sc0) * P32_1;
+            a1 = (a1 ^ (a1 >> 47) ^ sc1) * P32_1;
+        }
+    };
+    u64 b = 0;
+    // two blocks (8 loads per lane) in flight
+    for (; b + 2 <= nbBlocks; b += 2) {
+        uint4 v[8];
+#pragma unroll
+        for (int t = 0; t < 8; t++) v[t] = ld16(q + (b << 10) + 256 * t);
+        u64 c0 = 0, c1 = 0;
+#pragma unroll
+        for (int t = 0; t < 4; t++) contrib(v[t], k0[t], k1[t], c0, c1);
+        fold(c0, c1, true);
+        c0 = c1 = 0;
+#pragma unroll
+        for (int t = 0; t < 4; t++) contrib(v[4 + t], k0[t], k1[t], c0, c1);
+        fold(c0, c1, true);
+    }
+    for (; b < nbBlocks; b++) {
+        u64 c0 = 0, c1 = 0;
+#pragma unroll
+        for (int t = 0; t < 4; t++) contrib(ld16(q + (b << 10) + 256 * t), k0[t], k1[t], c0, c1);
+        fold(c0, c1, true);
+    }
+    { // last partial block: full stripes, then the final 64 bytes with secret offset 192-64-7
+        const u64 done = nbBlocks << 10;
+        const u32 nbStripes = (u32)(((len - 1) - done) >> 6);
+        u64 c0 = 0, c1 = 0;
+#pragma unroll
+        for (int t = 0; t < 4; t++)
+            if (g + 4 * t < nbStripes) contrib(ld16(q + done + 256 * t), k0[t], k1[t], c0, c1);
+        if (g == 0) {
+            uint4 v = ld16(p + len - 64 + j * 16);
+            contrib(v, sec64(121 + 8 * i0), sec64(121 + 8 * i0 + 8), c0, c1);
+        }
+        fold(c0, c1, false);
+    }
+    // mergeAccs: lanes with (lane & 3) == j hold acc[2j], acc[2j+1]
+    u64 lo = mul128_fold64(a0 ^ sec64(11 + 16 * j), a1 ^ sec64(11 + 16 * j + 8));
+    u64 hi = mul128_fold64(a0 ^ sec64(117 + 16 * j), a1 ^ sec64(117 + 16 * j + 8));
+    lo += quad_xor64(lo, 1);
+    lo += quad_xor64(lo, 2);
+    hi += quad_xor64(hi, 1);
+    hi += quad_xor64(hi, 2);
+    H128 r;
+    r.lo = avalanche3(lo + len * P64_1);
+    r.hi = avalanche3(hi + ~(len * P64_2));
+    return r;
+}
+
+// grid = ceil(n / (4 * waves per workgroup)), one row of 16 lanes per chunk
+__global__ void __launch_bounds__(256)
+k_xxh3_128_rows(const u8* __restrict__ data, const u64* __restrict__ off, const u32* __restrict__ len, u32 n,
+                u8* __restrict__ hashes) {
+    const u32 lane = threadIdx.x & 63;
+    const u32 c = (blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * 4 + (lane >> 4);
+    // Rows are independent: the DPP rotations / quad permutes of hash_long_row only read lanes of the same
+    // row (quad), and a row's 16 lanes always take the same path, so rows may diverge freely (other
+    // lengths, the short path, no chunk at all).
+    const bool live = c < n;
+    H128 h = {0, 0};
+    if (live) {
+        const u8* p = data + off[c];
+        const u32 L = len[c];
+        if (L <= 240)
+            h = hash_short(p, L);
+        else
+            h = hash_long_row(p, L, lane);
+    }
+    if (live && (lane & 15) == 0) {
+        u64* o = (u64*)(hashes + 16ull * c);
+        o[0] = h.lo; // u128.to_le_bytes(): low64 LE || high64 LE
+        o[1] = h.hi;
+    }
+}
+
 __global__ void __launch_bounds__(256)
 k_xxh3_128_batch(const u8* __restrict__ data, const u64* __restrict__ off,
                  const u32* __restrict__ len, u32 n, u8* __restrict__ hashes) {
