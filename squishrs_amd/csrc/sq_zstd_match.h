@@ -752,6 +752,172 @@ SQ_DEVFN void filter_repair(MatchState& ms, u32 pos, u32 anc, bool first) {
     }
 }
 
+// ---------------------------------------------------------------- waking the finder for one search
+// After a certified prefix the finder is asleep: no bucket is live, nothing has been inserted.  The
+// exact code then has ONE search to do, at `curr` (plus, if it finds a match, the depth searches at
+// curr + 1 and curr + 2); afterwards the tail certificate usually ends the block.  Predicting the whole
+// remaining schedule and replaying every earlier position through the live-bucket filter for that
+// (filter_repair) is most of such a chunk's time.  Instead only the buckets of curr, curr+1, curr+2
+// become live: one streaming pass finds the earlier positions that hash into them (one or two, typically),
+// they are inserted in order -- as deferred searches where they were certified searches -- and that is
+// all.  Everything else stays consistent with "live buckets hold every insertion": a later search in
+// another bucket triggers the ordinary repair.
+#define SQZ_WAKE_CAP 48u
+
+// is position p one of the first ms.nCertDone scheduled searches (those the certificate skipped)?
+SQ_DEVFN bool cert_was_skipped(MatchState& ms, u32 p) {
+    bool const second = p >= SQZ_WINDOW_START + SQZ_BLOCKSIZE_MAX && ms.nCert > ms.certCnt0;
+    const u32* const ent = ms.schedTab + 2 + (second ? SQZ_SCHEDTAB_N : 0u);
+    u32 const nEnt = second ? ms.nCert - ms.certCnt0 : ms.certCnt0;
+    u32 const rel = p - (second ? SQZ_WINDOW_START + SQZ_BLOCKSIZE_MAX : SQZ_WINDOW_START);
+    u32 const j = sched_count(ent, nEnt, rel);
+    if (j >= nEnt || gld32(ent + j) != rel) return false;
+    return (second ? ms.certCnt0 + j : j) < ms.nCertDone;
+}
+
+// Returns false when this shortcut does not apply (the caller falls back to filter_repair).
+SQ_DEVFN bool filter_wake(MatchState& ms, u32 curr) {
+    u32 const hashLog = ms.cp.hashLog;
+    u32 const btMask = (1u << (ms.cp.chainLog - 1)) - 1;
+    u32* const bt = ms.chainTable;
+    const u8* const base = ms.base;
+    u32 const to = ms.nextToUpdate; // positions [2, to) minus the skipped ranges are "inserted"
+    u32 hb[3];
+    u32 nb = 0;
+    for (u32 k = 0; k < 3; k++)
+        if (curr + k + 8 <= ms.chunkEndPos) hb[nb++] = hash4(srd32(base + curr + k), hashLog);
+    if (nb == 0 || ms.nLive + 3 > SQZ_LIVE_CAP) return false;
+    for (u32 k = nb; k < 3; k++) hb[k] = hb[0];
+    // ---- the earlier positions that hash into one of the buckets, in LDS: (position, bucket hash)
+#if SQ_ON_DEVICE
+    u32 const lane = wv_lane();
+    u64 const below = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+    SQ_L u32* const found = (SQ_L u32*)g_lds.grp;
+    u32 nFound = 0;
+    {
+        const u8* const src0 = base + SQZ_WINDOW_START;
+        const u8* const a0 = src0 - ((size_t)src0 & 15);
+        s32 const p0 = (s32)SQZ_WINDOW_START - (s32)(src0 - a0);
+        const u8* const lastByte = base + ms.chunkEndPos - 1;
+        const u8* const aLast = lastByte - ((size_t)lastByte & 15);
+        auto loadRound = [&](s32 rp) -> sq_v4u {
+            const u8* ad = a0 + (size_t)(u32)(rp - p0) + 16 * lane;
+            return sq_grd128(ad < aLast ? ad : aLast);
+        };
+        for (s32 pos = p0; pos < (s32)to; pos += 4096) { // four rounds of 1 KiB per step, loads first
+            sq_v4u w[5];
+#pragma unroll
+            for (u32 r = 0; r < 5; r++) w[r] = loadRound(pos + 1024 * (s32)r);
+#pragma unroll
+            for (u32 r = 0; r < 4; r++) {
+                s32 const rp = pos + 1024 * (s32)r;
+                if (rp >= (s32)to) break;
+                u32 const nx = (u32)__builtin_amdgcn_update_dpp(0, (int)w[r].x, 0x130 /* wave_shl:1 */, 0xF, 0xF, false);
+                u32 const n63 = wv_uni(w[r + 1].x);
+                u32 const d[5] = {w[r].x, w[r].y, w[r].z, w[r].w, (lane == 63) ? n63 : nx};
+                s32 const lo = rp + (s32)(16 * lane);
+                u32 cm = 0;
+#pragma unroll
+                for (u32 q = 0; q < 4; q++) {
+                    u32 v[4];
+                    v[0] = d[q];
+                    v[1] = __builtin_amdgcn_alignbyte(d[q + 1], d[q], 1);
+                    v[2] = __builtin_amdgcn_alignbyte(d[q + 1], d[q], 2);
+                    v[3] = __builtin_amdgcn_alignbyte(d[q + 1], d[q], 3);
+#pragma unroll
+                    for (u32 k = 0; k < 4; k++) {
+                        u32 const h = hash4(v[k], hashLog);
+                        cm |= ((h == hb[0] || h == hb[1] || h == hb[2]) ? 1u : 0u) << (4 * q + k);
+                    }
+                }
+                { // positions in [2, to)
+                    s32 f = (s32)SQZ_WINDOW_START - lo, l = (s32)to - lo;
+                    f = f < 0 ? 0 : (f > 16 ? 16 : f);
+                    l = l < 0 ? 0 : (l > 16 ? 16 : l);
+                    cm &= ((1u << l) - 1u) & ~((1u << f) - 1u);
+                }
+                while (wv_ballot(cm != 0)) {
+                    u64 const m = wv_ballot(cm != 0);
+                    if (cm) {
+                        u32 const j = (u32)__builtin_ctz(cm);
+                        cm &= cm - 1;
+                        u32 const slot = nFound + (u32)__popcll(m & below);
+                        if (slot < SQZ_WAKE_CAP) found[slot] = (u32)(lo + (s32)j);
+                    }
+                    nFound += (u32)__popcll(m);
+                }
+            }
+        }
+        wv_fence();
+    }
+    if (nFound > SQZ_WAKE_CAP) return false; // crowded buckets: the ordinary repair
+#else
+    u32 found[SQZ_WAKE_CAP];
+    u32 nFound = 0;
+    for (u32 p = SQZ_WINDOW_START; p < to; p++) {
+        u32 const h = hash4(sq_rd32(base + p), hashLog);
+        if (h == hb[0] || h == hb[1] || h == hb[2]) {
+            if (nFound < SQZ_WAKE_CAP) found[nFound] = p;
+            nFound++;
+        }
+    }
+    if (nFound > SQZ_WAKE_CAP) return false;
+#endif
+    // ---- the three buckets become live (they are empty: nothing has been inserted anywhere yet)
+    u32 const start = ms.nLive;
+    for (u32 k = 0; k < nb; k++) {
+        bool fresh = true;
+        for (u32 j = 0; j < k; j++) fresh = fresh && hb[j] != hb[k];
+        if (!fresh) continue;
+        gst32(ms.hashTable + hb[k], ht_enc(ms, SQZ_HT_PEND));
+        gst32(ms.liveList + ms.nLive, hb[k]);
+        ms.nLive++;
+    }
+    wv_mem_sync();
+    // ---- insert what was found, in ascending position order (the list is short: pick the minimum each time)
+    u32 last = 0;
+    for (u32 done = 0; done < nFound; done++) {
+        u32 p = 0xFFFFFFFFu;
+#if SQ_ON_DEVICE
+        for (u32 i = lane; i < nFound; i += 64) {
+            u32 const c = found[i];
+            if (c > last && c < p) p = c;
+        }
+        for (int sft = 32; sft >= 1; sft >>= 1) {
+            u32 const y = (u32)__shfl_xor((int)p, sft, 64);
+            p = y < p ? y : p;
+        }
+        p = wv_uni(p);
+#else
+        for (u32 i = 0; i < nFound; i++)
+            if (found[i] > last && found[i] < p) p = found[i];
+#endif
+        last = p;
+        bool skipped = false; // positions libzstd never inserted (nextToUpdate jumped over them)
+        for (u32 k = 0; k < ms.nSkip; k++) {
+            u32 const a = gld32(ms.skipList + 2 * k), b = gld32(ms.skipList + 2 * k + 1);
+            skipped = skipped || (p >= a && p < b);
+        }
+        if (skipped) continue;
+        u32 const h = hash4(srd32(base + p), hashLog);
+        u32 const head = ht_dec(ms, gld32(ms.hashTable + h));
+        // a certified (skipped) search sits in its bucket as a deferred search, like after a speculative epoch
+        u32 const mark = cert_was_skipped(ms, p) ? SQZ_DUBT_SEARCHED : SQZ_DUBT_UNSORTED;
+        gst32(bt + 2 * (p & btMask), head & SQZ_HT_IDX);
+        gst32(bt + 2 * (p & btMask) + 1, mark);
+        gst32(ms.hashTable + h, ht_enc(ms, p | (head & ~SQZ_HT_IDX)));
+        wv_mem_sync();
+    }
+    filter_finalize(ms, start);
+#if SQ_ON_DEVICE
+    for (u32 k = 0; k < nb; k++) bloom_add(hb[k]); // idempotent
+    wv_fence();
+#else
+    for (u32 k = 0; k < nb; k++) bloom_add(hb[k]);
+#endif
+    return true;
+}
+
 // ---------------------------------------------------------------- no-match certificate
 // On incompressible data every scheduled search fails and the parser emits no sequence at all: the
 // whole tree machinery produces nothing observable.  A search of the lazy parser at position s can
@@ -1558,7 +1724,8 @@ SQ_DEVFN u32 dubt_find(MatchState& ms, const u8* const ip, const u8* const iend,
     u32 const curr = (u32)(ip - ms.base);
     u32 headWord = ht_dec(ms, gld32(hashTable + h));
     if (!ms.eager && !(headWord & SQZ_HT_LIVE)) { // the schedule changed: make this bucket exact
-        filter_repair(ms, curr, ms.anchorPos, false);
+        // first search after a certified prefix: wake only the buckets it needs (filter_wake)
+        if (!(ms.nLive == 0 && ms.nCertDone > 0 && filter_wake(ms, curr))) filter_repair(ms, curr, ms.anchorPos, false);
         headWord = ht_dec(ms, gld32(hashTable + h));
     }
     u32 const headIndex = headWord & SQZ_HT_IDX;
