@@ -172,6 +172,25 @@ SQ_DEV u32 fast_cnt16_add(SQ_L u32* arr, u32 key) { // packed 16-bit counters; r
 }
 SQ_DEV u32 fast_get16(const SQ_L u32* arr, u32 key) { return (arr[key >> 1] >> (16 * (key & 1))) & 0xFFFFu; }
 
+// positions of the scheduled searches i, i + 64, ..., i + 448 (clamped to the last one): the eight table
+// loads are issued together (left to itself hipcc waits for each before it computes the next address)
+SQ_DEV void cert_pos8(const CertCtx& cx, u32 i, u32 nCert, u32 (&sp)[8]) {
+    u32 t[8], ad[8];
+#pragma unroll
+    for (u32 g = 0; g < 8; g++) {
+        u32 const j = (i + 64 * g < nCert) ? i + 64 * g : nCert - 1;
+        bool const first = j < cx.certCnt0;
+        u32 const slot = first ? j : SQZ_SCHEDTAB_N + cx.tabOff1 + (j - cx.certCnt0);
+        t[g] = sq_gld32(cx.schedTab + 2 + slot);
+        ad[g] = first ? SQZ_WINDOW_START : cx.base1Pos;
+    }
+    // all eight words pass through one empty asm: nothing that uses one of them can be scheduled before
+    // the last load has been issued
+    asm volatile("" : "+v"(t[0]), "+v"(t[1]), "+v"(t[2]), "+v"(t[3]), "+v"(t[4]), "+v"(t[5]), "+v"(t[6]), "+v"(t[7]));
+#pragma unroll
+    for (u32 g = 0; g < 8; g++) sp[g] = t[g] + ad[g];
+}
+
 // cx: base, schedTab, certCnt0, nCert, base1Pos, tabOff1 (0), repOff, chunkEndPos are inputs;
 // certEnd / certEnd1 the results.
 SQ_DEVFN void cert_lds_core(CertCtx& cx, FastLds* L) {
@@ -234,11 +253,7 @@ SQ_DEVFN void cert_lds_core(CertCtx& cx, FastLds* L) {
     u32 const nBuild = (cx.dbg & 1) ? 0u : nCert; // SQ_FAST_DBG timing experiments: 1 = no build, 2 = no scan
     for (u32 i0 = 0; i0 < nBuild; i0 += 512) {
         u32 sp[8], v[8], v1[8], vr[8];
-#pragma unroll
-        for (u32 g = 0; g < 8; g++) {
-            u32 const i = i0 + 64 * g + lane;
-            sp[g] = cert_pos_c(cx, i < nCert ? i : iLast);
-        }
+        cert_pos8(cx, i0 + lane, nCert, sp);
 #pragma unroll
         for (u32 g = 0; g < 8; g++) {
             v[g] = sq_grd32(base + sp[g]);
@@ -291,11 +306,7 @@ SQ_DEVFN void cert_lds_core(CertCtx& cx, FastLds* L) {
     // ---- build pass 2: scatter the values; a bucket's start counts up to its end
     for (u32 i0 = 0; i0 < nBuild; i0 += 512) {
         u32 sp[8], v[8];
-#pragma unroll
-        for (u32 g = 0; g < 8; g++) {
-            u32 const i = i0 + 64 * g + lane;
-            sp[g] = cert_pos_c(cx, i < nCert ? i : iLast);
-        }
+        cert_pos8(cx, i0 + lane, nCert, sp);
 #pragma unroll
         for (u32 g = 0; g < 8; g++) v[g] = sq_grd32(base + sp[g]);
 #pragma unroll
@@ -402,7 +413,15 @@ SQ_DEVFN void cert_lds_core(CertCtx& cx, FastLds* L) {
         u32 const blkEnd = (!second && blk1 != 0xFFFFFFFFu) ? blk1 : cx.chunkEndPos;
         s32 const r = lo - (s32)bs;
         bool const plain = r >= 4096 && (u32)(lo + 16) <= blkEnd - 8 && !((blk1 != 0xFFFFFFFFu) && lo < (s32)blk1 && lo + 16 > (s32)blk1);
-        if (wv_ballot(!plain)) return fast_sched_mask(lvlWords, lo, blk1, cx.chunkEndPos, wa, wb, plain);
+        if (wv_ballot(!plain)) {
+            u32 const m = fast_sched_mask(lvlWords, lo, blk1, cx.chunkEndPos, wa, wb, plain);
+            // This rare path loads level words itself.  Left pending at the join, such a load makes hipcc
+            // guard the main path's registers with s_waitcnt vmcnt(0) in EVERY round, which drains the four
+            // rounds of stream loads in flight (measured: the scan ran at one memory latency per round).
+            // A real s_waitcnt here (vmcnt(0), expcnt/lgkmcnt untouched) closes the path with nothing pending.
+            __builtin_amdgcn_s_waitcnt(0x0F70);
+            return m;
+        }
         return fast_sched_mask_plain((u32)r, wa, wb);
     };
     // look the collected positives up, 64 at a time, while at least `atLeast` are waiting; false = list of hits full
@@ -437,26 +456,25 @@ SQ_DEVFN void cert_lds_core(CertCtx& cx, FastLds* L) {
         f = f < 0 ? 0 : (f > 16 ? 16 : f);
         l = l < 0 ? 0 : (l > 16 ? 16 : l);
         u32 const okMask = ((1u << l) - 1u) & ~((1u << f) - 1u);
-        u32 cm = 0;
+        // The filter's two probes of the value at p are keyed by its low and its high 16 bits, i.e. by the
+        // 2-byte windows at p and at p + 2, in ONE table: probe 2 of position p is probe 1 of position
+        // p + 2.  So each of the lane's 18 windows (16 of its own bytes, 2 reaching into the next lane's) is
+        // looked up once, and a position passes when its own window's bit and the one two further do.
+        u32 bm = 0;
 #pragma unroll
-        for (u32 q = 0; q < 4; q++) {
-            u32 v[4], p1[4], p2[4];
-            v[0] = d[q];
-            v[1] = __builtin_amdgcn_alignbyte(d[q + 1], d[q], 1);
-            v[2] = __builtin_amdgcn_alignbyte(d[q + 1], d[q], 2);
-            v[3] = __builtin_amdgcn_alignbyte(d[q + 1], d[q], 3);
+        for (u32 q = 0; q < 5; q++) {
+            u32 const nk = q < 4 ? 4u : 2u;
+            u32 s[4], pw[4];
+            s[0] = d[q];
+            s[1] = d[q] >> 8;
+            s[2] = d[q] >> 16;
+            s[3] = q < 4 ? __builtin_amdgcn_alignbyte(d[q < 4 ? q + 1 : q], d[q], 3) : 0u;
 #pragma unroll
-            for (u32 k = 0; k < 4; k++) {
-                p1[k] = B[(v[k] & 0xFFFFu) >> 5];
-                p2[k] = B[v[k] >> 21];
-            }
+            for (u32 k = 0; k < nk; k++) pw[k] = *(const SQ_L u32*)((const SQ_L u8*)B + ((s[k] >> 3) & 0x1FFCu));
 #pragma unroll
-            for (u32 k = 0; k < 4; k++) {
-                u32 const c = (p1[k] >> (v[k] & 31)) & (p2[k] >> ((v[k] >> 16) & 31)) & 1u;
-                cm |= c << (4 * q + k);
-            }
+            for (u32 k = 0; k < nk; k++) bm |= __builtin_amdgcn_ubfe(pw[k], s[k], 1u) << (4 * q + k);
         }
-        cm &= okMask;
+        u32 cm = bm & (bm >> 2) & okMask;
         cm &= ~schedMaskFast(lo, wa, wb);
         bool ok = true;
         if (nCand == 0) pendFrom = pos; // nothing older than this round is waiting for its look-up
@@ -537,11 +555,7 @@ SQ_DEVFN void cert_lds_core(CertCtx& cx, FastLds* L) {
         if (hp != 0) { // a scanned position p with the bytes hv: every scheduled s > p with those bytes
             for (u32 i0 = 0; i0 < nCert; i0 += 512) {
                 u32 sp[8], v[8];
-#pragma unroll
-                for (u32 g = 0; g < 8; g++) {
-                    u32 const i = i0 + 64 * g + lane;
-                    sp[g] = cert_pos_c(cx, i < nCert ? i : iLast);
-                }
+                cert_pos8(cx, i0 + lane, nCert, sp);
 #pragma unroll
                 for (u32 g = 0; g < 8; g++) v[g] = sq_grd32(base + sp[g]);
 #pragma unroll
@@ -556,11 +570,7 @@ SQ_DEVFN void cert_lds_core(CertCtx& cx, FastLds* L) {
             wv_fence();
             for (u32 i0 = 0; i0 < nCert; i0 += 512) {
                 u32 sp[8], v[8];
-#pragma unroll
-                for (u32 g = 0; g < 8; g++) {
-                    u32 const i = i0 + 64 * g + lane;
-                    sp[g] = cert_pos_c(cx, i < nCert ? i : iLast);
-                }
+                cert_pos8(cx, i0 + lane, nCert, sp);
 #pragma unroll
                 for (u32 g = 0; g < 8; g++) v[g] = sq_grd32(base + sp[g]);
 #pragma unroll
