@@ -513,10 +513,26 @@ static int compress_async(sq_ctx* c, const u8* d_data, const u64* h_off, const u
 #ifdef SQ_PROF
     {   // profiling build: sum the per-wave phase timers (100 MHz ticks) and print them
         std::vector<unsigned long long> tot(33, 0), one(33);
+        std::vector<std::pair<unsigned long long, unsigned long long>> longest; // (ticks, pass<<32 | chunk) per wave
+        std::vector<unsigned long long> fin;                                    // when each wave finished its last chunk
         for (u32 w = 0; w < waves; w++) {
             (void)hipMemcpy(one.data(), (u8*)c->b_ws.p + (size_t)(w + 1) * ws_each - 1024, 33 * 8, hipMemcpyDeviceToHost);
-            for (int k = 0; k < 33; k++) tot[k] += one[k];
+            for (int k = 0; k < 33; k++)
+                if (k < 29 || k > 31) tot[k] += one[k];
+            longest.push_back({one[29], one[30]});
+            fin.push_back(one[31]);
         }
+        std::sort(longest.begin(), longest.end());
+        std::sort(fin.begin(), fin.end());
+        fprintf(stderr, "[squish_gpu prof] longest chunk per wave, ms (pass:chunk):");
+        for (size_t k = 0; k < 8 && k < longest.size(); k++) {
+            auto const& e = longest[longest.size() - 1 - k];
+            fprintf(stderr, " %.3f(%u:%u)", (double)e.first / 1e5, (unsigned)(e.second >> 32), (unsigned)e.second);
+        }
+        fprintf(stderr, "; median %.3f\n", (double)longest[longest.size() / 2].first / 1e5);
+        fprintf(stderr, "[squish_gpu prof] wave finish times ms: min %.3f p10 %.3f median %.3f p90 %.3f p99 %.3f max %.3f\n",
+                (double)fin.front() / 1e5, (double)fin[fin.size() / 10] / 1e5, (double)fin[fin.size() / 2] / 1e5,
+                (double)fin[fin.size() * 9 / 10] / 1e5, (double)fin[fin.size() * 99 / 100] / 1e5, (double)fin.back() / 1e5);
         static const char* nm[33] = {"frame_total", "table_clear", "dubt_update", "dubt_find", "row_update", "row_find",
                                      "entropy", "copies", "presplit+filterinit", "epoch_insert", "epoch_predicate", "epoch_rollback",
                                      "ins_phase1", "ins_phase23", "ins_tail", "bloom_rebuild",

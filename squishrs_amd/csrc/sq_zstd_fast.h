@@ -193,7 +193,13 @@ SQ_DEV void cert_pos8(const CertCtx& cx, u32 i, u32 nCert, u32 (&sp)[8]) {
 
 // cx: base, schedTab, certCnt0, nCert, base1Pos, tabOff1 (0), repOff, chunkEndPos are inputs;
 // certEnd / certEnd1 the results.
-SQ_DEVFN void cert_lds_core(CertCtx& cx, FastLds* L) {
+// rawOut (or null): where the frame's first block header goes.  While the scan streams the chunk it also
+// writes the raw blocks' payload there (3 bytes of header before each block), so a certified chunk is read
+// twice (values at S, stream) instead of three times; cx.rawEnd = the position up to which that was done
+// (SQZ_WINDOW_START = nothing).  Only for 16-byte aligned chunks: a lane's 16 source bytes then never
+// straddle the chunk start or the block boundary.
+SQ_DEV void cert_lds_core(CertCtx& cx, FastLds* L, u8* rawOut) {
+    cx.rawEnd = SQZ_WINDOW_START;
     const u8* const base = cx.base;
     u32 const nCert = cx.nCert;
     u32 const blk1 = (nCert > cx.certCnt0) ? cx.base1Pos : 0xFFFFFFFFu;
@@ -248,24 +254,45 @@ SQ_DEVFN void cert_lds_core(CertCtx& cx, FastLds* L) {
         }
         return true;
     };
-    // ---- build pass 1: Bloom filter, bucket counts, repcode test
-    u32 const iLast = nCert - 1;
+    // ---- build pass 1: Bloom filter, bucket counts, repcode test.  The values at the scheduled positions are
+    // gathered ONCE (an 8-byte load gives the bytes at s and at s + 1) and stay in registers for the scatter
+    // below: every gather is a 64-byte sector of HBM, 3,500 of them per chunk and pass.
     u32 const nBuild = (cx.dbg & 1) ? 0u : nCert; // SQ_FAST_DBG timing experiments: 1 = no build, 2 = no scan
-    for (u32 i0 = 0; i0 < nBuild; i0 += 512) {
-        u32 sp[8], v[8], v1[8], vr[8];
-        cert_pos8(cx, i0 + lane, nCert, sp);
+    u32 vv[SQZ_FAST_VALS / 64];
 #pragma unroll
-        for (u32 g = 0; g < 8; g++) {
-            v[g] = sq_grd32(base + sp[g]);
-            v1[g] = sq_grd32(base + sp[g] + 1);
-            vr[g] = (cx.repOff > 1) ? sq_grd32(base + sp[g] + 1 - cx.repOff) : v[g];
-        }
+    for (u32 it = 0; it < SQZ_FAST_VALS / 512; it++) {
+        u32 const i0 = 512 * it;
 #pragma unroll
-        for (u32 g = 0; g < 8; g++) {
-            if (i0 + 64 * g + lane < nCert) {
-                vbloom_add(bloom, v[g]);
-                (void)fast_cnt16_add(ends, v[g] >> 22);
-                if (cx.repOff && v1[g] == vr[g]) note(sp[g], vmin, vmin1); // repcode at s+1
+        for (u32 g = 0; g < 8; g++) vv[8 * it + g] = 0;
+        if (i0 < nBuild) {
+            u32 sp[8], v[8], v1[8], vr[8];
+            cert_pos8(cx, i0 + lane, nCert, sp);
+            if (cx.repOff > 1) {
+#pragma unroll
+                for (u32 g = 0; g < 8; g++) {
+                    v[g] = sq_grd32(base + sp[g]);
+                    v1[g] = sq_grd32(base + sp[g] + 1);
+                    vr[g] = sq_grd32(base + sp[g] + 1 - cx.repOff);
+                }
+            } else {
+                u64 q[8];
+#pragma unroll
+                for (u32 g = 0; g < 8; g++) q[g] = sq_grd64(base + sp[g]); // s + 8 <= block end for every search
+#pragma unroll
+                for (u32 g = 0; g < 8; g++) {
+                    v[g] = (u32)q[g];
+                    v1[g] = (u32)(q[g] >> 8);
+                    vr[g] = v[g];
+                }
+            }
+#pragma unroll
+            for (u32 g = 0; g < 8; g++) {
+                vv[8 * it + g] = v[g];
+                if (i0 + 64 * g + lane < nCert) {
+                    vbloom_add(bloom, v[g]);
+                    (void)fast_cnt16_add(ends, v[g] >> 22);
+                    if (cx.repOff && v1[g] == vr[g]) note(sp[g], vmin, vmin1); // repcode at s+1
+                }
             }
         }
     }
@@ -303,18 +330,19 @@ SQ_DEVFN void cert_lds_core(CertCtx& cx, FastLds* L) {
         cx.certEnd1 = (blk1 != 0xFFFFFFFFu) ? SQZ_WINDOW_START : 0u;
         return;
     }
-    // ---- build pass 2: scatter the values; a bucket's start counts up to its end
-    for (u32 i0 = 0; i0 < nBuild; i0 += 512) {
-        u32 sp[8], v[8];
-        cert_pos8(cx, i0 + lane, nCert, sp);
+    // ---- build pass 2: scatter the values (from registers); a bucket's start counts up to its end
 #pragma unroll
-        for (u32 g = 0; g < 8; g++) v[g] = sq_grd32(base + sp[g]);
+    for (u32 it = 0; it < SQZ_FAST_VALS / 512; it++) {
+        u32 const i0 = 512 * it;
+        if (i0 < nBuild) {
 #pragma unroll
-        for (u32 g = 0; g < 8; g++)
-            if (i0 + 64 * g + lane < nCert) {
-                u32 const slot = fast_cnt16_add(ends, v[g] >> 22);
-                if (slot < SQZ_FAST_VALS) vals[slot] = (u16)(v[g] >> 6);
-            }
+            for (u32 g = 0; g < 8; g++)
+                if (i0 + 64 * g + lane < nCert) {
+                    u32 const vg = vv[8 * it + g];
+                    u32 const slot = fast_cnt16_add(ends, vg >> 22);
+                    if (slot < SQZ_FAST_VALS) vals[slot] = (u16)(vg >> 6);
+                }
+        }
     }
     wv_fence();
     // ---- scheduled positions with equal values: equal neighbours inside a bucket
@@ -352,13 +380,15 @@ SQ_DEVFN void cert_lds_core(CertCtx& cx, FastLds* L) {
     const u8* const lastByte = base + cx.chunkEndPos - 1;
     const u8* const aLast = lastByte - ((size_t)lastByte & 15);
     s32 pos = p0;
+    bool const rawCopy = rawOut != nullptr && src0 == a0;
     auto scanStop = [&]() -> u32 {
         u32 const ce = (blk1 != 0xFFFFFFFFu) ? certEnd1 : certEnd;
         return ce < pEnd ? ce : pEnd;
     };
-    auto loadRound = [&](s32 rp) -> sq_v4u {
-        const u8* ad = a0 + (size_t)(u32)(rp - p0) + 16 * lane;
-        return sq_grd128(ad < aLast ? ad : aLast);
+    u32 const lastOff = (u32)(aLast - a0);
+    auto loadRound = [&](s32 rp) -> sq_v4u { // uniform base + 32-bit lane offset, clamped to the last window
+        u32 const o = (u32)(rp - p0) + 16 * lane;
+        return sq_grd128(a0 + (o < lastOff ? o : lastOff));
     };
     // level words of the lane's 16 positions in the round at rp (two, for a window across two levels)
     // Level words for the round at rp.  A round spans 1024 bytes = at most 5 levels of one block (rounds
@@ -446,12 +476,17 @@ SQ_DEVFN void cert_lds_core(CertCtx& cx, FastLds* L) {
         u32 d4;
         {
             u32 const nx = (u32)__builtin_amdgcn_update_dpp(0, (int)w.x, 0x130 /* wave_shl:1 */, 0xF, 0xF, false);
-            u32 const n63 = wv_uni(wn.x);
+            // lane 63 continues in lane 0 of the next round's load: a wave rotation, no trip through an SGPR
+            // (a v_readfirstlane of that vector gets hoisted into earlier rounds, where it waits for a load
+            // that is meant to stay in flight)
+            u32 const n63 = (u32)__builtin_amdgcn_update_dpp(0, (int)wn.x, 0x134 /* wave_rol:1 */, 0xF, 0xF, false);
             d4 = (lane == 63) ? n63 : nx;
         }
         u32 const d[5] = {w.x, w.y, w.z, w.w, d4};
         u32 const stop = scanStop();
         s32 const lo = pos + (s32)(16 * lane);
+        if (rawCopy && (u32)lo + 16 <= cx.chunkEndPos) // (clamped loads beyond the end fail this test)
+            sq_gwr128(rawOut + ((u32)lo - SQZ_WINDOW_START) + ((u32)lo >= blk1 ? 6u : 3u), w);
         s32 f = (s32)SQZ_WINDOW_START - lo, l = (s32)stop - lo;
         f = f < 0 ? 0 : (f > 16 ? 16 : f);
         l = l < 0 ? 0 : (l > 16 ? 16 : l);
@@ -539,6 +574,7 @@ SQ_DEVFN void cert_lds_core(CertCtx& cx, FastLds* L) {
             if (!round(wE, wA, lE)) { full = true; break; }
             if (pos >= (s32)scanStop()) break;
         }
+        if (rawCopy) cx.rawEnd = (u32)pos < cx.chunkEndPos ? (u32)pos : SQZ_WINDOW_START + ((cx.chunkEndPos - SQZ_WINDOW_START) & ~15u);
         if (!full && !lookUp(1)) full = true; // the positives still waiting
         if (full) { // more genuine repeats than the list holds (compressible data): positions >= pendFrom
             // stay unverified, which only matters to searches beyond them
@@ -639,7 +675,7 @@ SQ_DEVFN void cert_lds_core(CertCtx& cx, FastLds* L) {
 // Returns the frame length when the chunk is decided here, 0 when it is left to k_compress_batch.
 // certOut[0..1]: the certificate ends for k_compress_batch (certOut[1] carries SQZ_CERT_HINT_VALID),
 // or 0, 0 when no certificate was computed.
-SQ_DEVFN u32 fastpath_frame_wave(const u8* src, u32 n, u8* dst, u32 cap, u32* E, u32 genBits, const u32* schedTab,
+SQ_DEV u32 fastpath_frame_wave(const u8* src, u32 n, u8* dst, u32 cap, u32* E, u32 genBits, const u32* schedTab,
                                  FastLds* L, u32* certOut, u32 dbg = 0) {
     CParams const cp = get_cparams(n);
     u32 c0 = 0, c1 = 0;
@@ -669,31 +705,35 @@ SQ_DEVFN u32 fastpath_frame_wave(const u8* src, u32 n, u8* dst, u32 cap, u32* E,
         cx.nOvf = 0;
         if (cx.nCert > 0 && cx.nCert <= SQZ_FAST_VALS) {
             cx.dbg = dbg;
-            cert_lds_core(cx, L);
+            u32 const nBlocks = len1 ? 2u : 1u;
+            bool const sized = len0 >= SQZ_FAST_MIN_BLOCK && (len1 == 0 || len1 >= SQZ_FAST_MIN_BLOCK);
+            bool const room = cap >= n + 9 + 3 * nBlocks;
+            u32 const hdr = 5 + (n < 256 ? 1u : (n < 65536 + 256 ? 2u : 4u)); // = fast_frame_header()
+            cert_lds_core(cx, L, (sized && room && !(dbg & 4)) ? dst + hdr : nullptr);
             c0 = cx.certEnd;
             c1 = cx.certEnd1 | SQZ_CERT_HINT_VALID;
             if (dbg & 64) c0 = cx.nOvf; // bring-up: why the scan gave up
             // every search of every block certainly fails?
             bool whole = cx.certEnd >= SQZ_WINDOW_START + len0 - 8;
             if (len1) whole = whole && (cx.certEnd1 >= SQZ_WINDOW_START + SQZ_BLOCKSIZE_MAX + len1 - 8);
-            bool const sized = len0 >= SQZ_FAST_MIN_BLOCK && (len1 == 0 || len1 >= SQZ_FAST_MIN_BLOCK);
-            u32 const nBlocks = len1 ? 2u : 1u;
             if (dbg & 4) whole = false; // timing experiment: certificate only
-            if (whole && sized && cap >= n + 9 + 3 * nBlocks) {
+            if (whole && sized && room) {
                 u32 ok = fast_literals_uncompressible(src, len0, L->bloom);
                 if (ok && len1) ok = fast_literals_uncompressible(src + len0, len1, L->bloom);
                 if (ok) {
-                    u32 const hdr = fast_frame_header(dst, n);
+                    (void)fast_frame_header(dst, n);
                     u8* op = dst + hdr;
+                    u32 const done = cx.rawEnd - SQZ_WINDOW_START; // chunk bytes the scan has already put in place
                     for (u32 b = 0; b < nBlocks; b++) {
-                        u32 const bs = b ? len1 : len0;
+                        u32 const bs = b ? len1 : len0, b0 = b ? len0 : 0u;
                         u32 const h = ((b + 1 == nBlocks) ? 1u : 0u) + (0u << 1) + (bs << 3); // ZSTD_noCompressBlock
                         WV_SERIAL {
                             op[0] = (u8)h;
                             op[1] = (u8)(h >> 8);
                             op[2] = (u8)(h >> 16);
                         }
-                        wv_memcpy(op + 3, src + (b ? len0 : 0u), bs);
+                        u32 const have = done > b0 ? (done - b0 < bs ? done - b0 : bs) : 0u;
+                        if (have < bs) wv_memcpy(op + 3 + have, src + b0 + have, bs - have);
                         op += 3 + bs;
                     }
                     frame = (u32)(op - dst);

@@ -597,6 +597,7 @@ k_compress_batch(const u8* data, const u64* off, const u32* len, const u8* selec
         tg.tailTabClean = gld32(saved + 2);
     }
 #ifdef SQ_PROF
+    unsigned long long const t_kernel0 = __builtin_amdgcn_s_memrealtime();
     if (wv_lane() == 0)
         for (int k = 0; k < 32; k++) g_lds.prof[k] = 0;
     wv_fence();
@@ -623,6 +624,18 @@ k_compress_batch(const u8* data, const u64* off, const u32* len, const u8* selec
             PROF_T0(t_all);
             if (take) compress_one(data, off, len, idx, slots, slot_off, frame_len, ws, err, tg, schedTab, certHint);
             PROF_ADD(0, t_all);
+#ifdef SQ_PROF
+            {   // the wave's longest chunk (ticks, index, list it came from) and when the wave finished it
+                unsigned long long const e_ = __builtin_amdgcn_s_memrealtime();
+                if (wv_lane() == 0) {
+                    if (e_ - t_all > g_lds.prof[29]) {
+                        g_lds.prof[29] = e_ - t_all;
+                        g_lds.prof[30] = ((unsigned long long)pass << 32) | idx;
+                    }
+                    g_lds.prof[31] = e_ - t_kernel0;
+                }
+            }
+#endif
         }
     }
     if (wv_lane() == 0) {

@@ -970,6 +970,7 @@ struct CertCtx {
     SQ_L u32* lvl;       // 2 * SQZ_SCHEDLVL_N level words in LDS, or nullptr: when given, the scan leaves
                          // the scheduled positions themselves out (their mutual repeats are found
                          // while the table is built)
+    u32 rawEnd;          // stage 1 only: position up to which the scan has written the raw blocks' payload
     u32 dbg;             // timing experiments (SQ_FAST_DBG): 1 = no build, 2 = no scan, 8 = build without the exchange
 };
 
