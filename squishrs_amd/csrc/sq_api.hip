@@ -512,13 +512,14 @@ static int compress_async(sq_ctx* c, const u8* d_data, const u64* h_off, const u
     }
 #ifdef SQ_PROF
     {   // profiling build: sum the per-wave phase timers (100 MHz ticks) and print them
-        std::vector<unsigned long long> tot(33, 0), one(33);
+        std::vector<unsigned long long> tot(33, 0), one(71), worst(71, 0);
         std::vector<std::pair<unsigned long long, unsigned long long>> longest; // (ticks, pass<<32 | chunk) per wave
         std::vector<unsigned long long> fin;                                    // when each wave finished its last chunk
         for (u32 w = 0; w < waves; w++) {
-            (void)hipMemcpy(one.data(), (u8*)c->b_ws.p + (size_t)(w + 1) * ws_each - 1024, 33 * 8, hipMemcpyDeviceToHost);
+            (void)hipMemcpy(one.data(), (u8*)c->b_ws.p + (size_t)(w + 1) * ws_each - 1024, 71 * 8, hipMemcpyDeviceToHost);
             for (int k = 0; k < 33; k++)
                 if (k < 29 || k > 31) tot[k] += one[k];
+            if (one[29] > worst[29]) worst = one;
             longest.push_back({one[29], one[30]});
             fin.push_back(one[31]);
         }
@@ -538,6 +539,14 @@ static int compress_async(sq_ctx* c, const u8* d_data, const u64* h_off, const u
                                      "ins_phase1", "ins_phase23", "ins_tail", "bloom_rebuild",
                                      "#tail_iters", "#bloom_overflow", "#superbatches", "#candidates", "#survivors", "#nLive_sum", "#repairs_x1000+eager_x1e6", "#exact_finds",
                                      "cert_predict", "cert_build", "cert_scan_p1", "cert_scan_p2", "cert_blockwalk", "-", "-", "-", "chunks+1"};
+        static const char* nmL[29] = {"frame_total", "table_clear", "dubt_update", "dubt_find", "row_update", "row_find",
+                                      "entropy", "copies", "presplit+filterinit", "epoch_insert", "epoch_predicate", "epoch_rollback",
+                                      "ins_phase1", "ins_phase23", "ins_tail", "bloom_rebuild",
+                                      "#tail_iters", "#bloom_overflow", "#superbatches", "#candidates", "#survivors", "#nLive_sum", "#repairs_x1000+eager_x1e6", "#exact_finds",
+                                      "cert_predict", "cert_build", "cert_scan_p1", "cert_scan_p2", "cert_blockwalk"};
+        fprintf(stderr, "[squish_gpu prof] the longest chunk (%u:%u), ms:", (unsigned)(worst[30] >> 32), (unsigned)worst[30]);
+        for (int k = 0; k < 29; k++) fprintf(stderr, " %s=%.3f", nmL[k], (k >= 16 && k < 24) ? (double)worst[42 + k] : (double)worst[42 + k] / 1e5);
+        fprintf(stderr, "\n");
         fprintf(stderr, "[squish_gpu prof] waves=%u kernel=%.2f ms; per-wave mean ms:", waves, c->last.compress_ms);
         for (int k = 0; k < 33; k++)
             if (nm[k][0] != '-') fprintf(stderr, " %s=%.3f", nm[k], (k >= 16 && k < 24) || k == 32 ? (double)tot[k] / waves : (double)tot[k] / waves / 1e5);

@@ -73,6 +73,7 @@ struct LdsState {
     u32* trace;   // 56 debug words in the wave's workspace (read by the host watchdog)
 #ifdef SQ_PROF
     unsigned long long prof[32]; // per-phase 100 MHz tick sums (profiling build only)
+    unsigned long long prof0[32], profLong[32]; // prof[] when the current chunk began; phase sums of the wave's longest chunk
 #endif
 };
 SQ_LDS LdsState g_lds;

@@ -622,6 +622,10 @@ k_compress_batch(const u8* data, const u64* off, const u32* len, const u8* selec
             u32 const idx = list ? gld32(list + q) : q;
             bool const take = list || (select == nullptr) || (select[idx] != 0);
             PROF_T0(t_all);
+#ifdef SQ_PROF
+            if (wv_lane() == 0)
+                for (int k = 0; k < 29; k++) g_lds.prof0[k] = g_lds.prof[k];
+#endif
             if (take) compress_one(data, off, len, idx, slots, slot_off, frame_len, ws, err, tg, schedTab, certHint);
             PROF_ADD(0, t_all);
 #ifdef SQ_PROF
@@ -631,6 +635,7 @@ k_compress_batch(const u8* data, const u64* off, const u32* len, const u8* selec
                     if (e_ - t_all > g_lds.prof[29]) {
                         g_lds.prof[29] = e_ - t_all;
                         g_lds.prof[30] = ((unsigned long long)pass << 32) | idx;
+                        for (int k = 0; k < 29; k++) g_lds.profLong[k] = g_lds.prof[k] - g_lds.prof0[k];
                     }
                     g_lds.prof[31] = e_ - t_kernel0;
                 }
@@ -650,6 +655,7 @@ k_compress_batch(const u8* data, const u64* off, const u32* len, const u8* selec
         unsigned long long* o = (unsigned long long*)(ws + ws_each - 1024);
         for (int k = 0; k < 32; k++) o[k] = g_lds.prof[k];
         o[32] = iter;
+        for (int k = 0; k < 29; k++) o[42 + k] = g_lds.profLong[k];
     }
 #endif
 }

@@ -8,6 +8,8 @@
 //   writer_thread record   /root/reference/src/fsutil/writer.rs:17-39
 //   header helpers         /root/reference/src/util/header.rs:10-14,35-63,192-233
 //   walk_dir               /root/reference/src/fsutil/directory.rs:39-73
+//   ArchiveReader::unpack / read_chunks / rebuild_files
+//                          /root/reference/src/archive/reader.rs:232-244,259-313,315-413
 //   CLI flags / messages   /root/reference/src/cmd/mod.rs:11-58, /root/reference/src/lib.rs:19-111,
 //                          /root/reference/src/main.rs:5-10
 //
@@ -15,6 +17,7 @@
 // SURVEY.md Appendix E).  Every chunk's hash / dedup decision / frame comes from sq_pack_batch:
 // there is no CPU hashing or compression in this program.
 #include "../../include/squish_gpu.h"
+#include "zstd_frame_decoder.hpp"
 
 #include <dirent.h>
 #include <sys/stat.h>
@@ -27,7 +30,11 @@
 #include <cstring>
 #include <ctime>
 #include <algorithm>
+#include <atomic>
+#include <filesystem>
 #include <map>
+#include <thread>
+#include <unordered_map>
 #include <string>
 #include <vector>
 
@@ -319,6 +326,104 @@ static void list_cmd(const std::string& squish, bool simple) {
     for (auto& d : v) printf(" %-30s %s\n", d.first.c_str(), with_commas(d.second).c_str());
 }
 
+// ---- unpack (archive/reader.rs:232-413; lib.rs:86-106) ------------------------------------------
+// read_chunks: every chunk record is decoded into a map keyed by its hash (a later record with the same
+// hash replaces the earlier one, like HashMap::insert); rebuild_files: each file is the concatenation of
+// its chunks.  Decoding runs on up to `threads` host threads (the reference's Rayon pool, -j); frames are
+// decoded by zstd_frame_decoder.hpp with the record's original_size as the capacity
+// (zstd::bulk::decompress(&compressed_data, orig_size), reader.rs:302-303).
+static std::string os_error(int e) { return std::string(strerror(e)) + " (os error " + std::to_string(e) + ")"; }
+static void unpack_cmd(const std::string& squish, const std::string& outdir, long threads) {
+    Summary hdr = read_summary(squish); // ArchiveReader::new: header / version checks, table offsets
+    FILE* f = fopen(squish.c_str(), "rb");
+    if (!f) throw AppError{"Specified file does not exist: `" + squish + "`"};
+    if (fseek(f, 27, SEEK_SET)) throw AppError{"Error reading from squish: seek"};
+    struct Rec {
+        std::string hash;
+        uint64_t osz;
+        std::vector<uint8_t> frame, data;
+        std::string err;
+    };
+    std::vector<Rec> recs((size_t)hdr.unique_chunks);
+    for (auto& r : recs) {
+        uint64_t csz;
+        r.hash.resize(16);
+        rd(f, &r.hash[0], 16);
+        rd(f, &r.osz, 8);
+        rd(f, &csz, 8);
+        if (csz > hdr.archive_size) throw AppError{"Error reading from squish: failed to fill whole buffer"};
+        r.frame.resize((size_t)csz);
+        rd(f, r.frame.data(), (size_t)csz);
+    }
+    {
+        std::atomic<size_t> next{0};
+        auto work = [&]() {
+            for (;;) {
+                size_t const i = next.fetch_add(1);
+                if (i >= recs.size()) return;
+                try {
+                    recs[i].data = zfd::decompress(recs[i].frame.data(), recs[i].frame.size(), (size_t)recs[i].osz);
+                } catch (const zfd::DecodeError& e) {
+                    recs[i].err = e.msg;
+                }
+                std::vector<uint8_t>().swap(recs[i].frame);
+            }
+        };
+        unsigned hw = std::thread::hardware_concurrency();
+        size_t nt = (size_t)std::max(1L, std::min<long>(threads, hw ? (long)hw : 1L));
+        nt = std::min(nt, std::max<size_t>(1, recs.size()));
+        std::vector<std::thread> pool;
+        for (size_t t = 1; t < nt; t++) pool.emplace_back(work);
+        work();
+        for (auto& t : pool) t.join();
+    }
+    std::unordered_map<std::string, const std::vector<uint8_t>*> chunk_map;
+    for (auto& r : recs) {
+        if (!r.err.empty()) throw AppError{"Error reading from squish: " + r.err};
+        chunk_map[r.hash] = &r.data;
+    }
+    // file table
+    uint32_t nfiles;
+    rd(f, &nfiles, 4);
+    namespace fs = std::filesystem;
+    for (uint32_t i = 0; i < nfiles; i++) {
+        uint32_t plen, cc;
+        uint64_t osz;
+        rd(f, &plen, 4);
+        if (plen > hdr.archive_size) throw AppError{"Error reading from squish: failed to fill whole buffer"};
+        std::string rel(plen, '\0');
+        rd(f, &rel[0], plen);
+        rd(f, &osz, 8);
+        rd(f, &cc, 4);
+        if ((uint64_t)cc * 16 > hdr.archive_size) throw AppError{"Error reading from squish: failed to fill whole buffer"};
+        std::vector<std::string> hashes(cc, std::string(16, '\0'));
+        for (auto& h : hashes) rd(f, &h[0], 16);
+        fs::path const full = fs::path(outdir) / fs::path(rel); // Path::join: an absolute `rel` replaces outdir
+        if (full.has_parent_path()) {
+            std::error_code ec;
+            fs::create_directories(full.parent_path(), ec);
+            if (ec) throw AppError{"Error creating directory `" + full.parent_path().string() + "`: " + os_error(ec.value())};
+        }
+        FILE* o = fopen(full.c_str(), "wb");
+        if (!o) throw AppError{"Error creating file `" + full.string() + "`: " + os_error(errno)};
+        for (auto& h : hashes) {
+            auto it = chunk_map.find(h);
+            if (it == chunk_map.end()) {
+                fclose(o);
+                throw AppError{"Missing Chunk for File: `" + rel + "`"};
+            }
+            const std::vector<uint8_t>& d = *it->second;
+            if (!d.empty() && fwrite(d.data(), 1, d.size(), o) != d.size()) {
+                int const e = errno;
+                fclose(o);
+                throw AppError{"Error creating directory `" + rel + "`: " + os_error(e)}; // (sic) reader.rs:392-394
+            }
+        }
+        if (fclose(o)) throw AppError{"Error creating directory `" + rel + "`: " + os_error(errno)};
+    }
+    fclose(f);
+}
+
 static int usage() {
     fprintf(stderr,
             "Compact, compress, and deduplicate files into a single archive\n\n"
@@ -354,7 +459,6 @@ int main(int argc, char** argv) {
         else
             pos.push_back(a);
     }
-    (void)max_threads;
     try {
         if (pos.size() < 2) return usage();
         if (pos[0] == "pack") {
@@ -368,10 +472,16 @@ int main(int argc, char** argv) {
                    blue("Final archive size").c_str(), format_bytes(sz).c_str()); // lib.rs:49-55
         } else if (pos[0] == "list") {
             list_cmd(pos[1], simple);
-        } else if (pos[0] == "unpack") {
-            // decode side: SURVEY.md 8(f) row f2, scheduled after the pack path; archives written
-            // here are unpacked by the reference's own `squishrs unpack`
-            throw AppError{"Unknown error: unpack is not part of this build (pack-side hot path only)"};
+        } else if (pos[0] == "unpack") { // lib.rs:86-106
+            std::string squish = pos[1];
+            if (!have_output) {
+                const std::string suf = ".squish";
+                output = (squish.size() >= suf.size() && squish.compare(squish.size() - suf.size(), suf.size(), suf) == 0)
+                             ? squish.substr(0, squish.size() - suf.size())
+                             : squish;
+            }
+            unpack_cmd(squish, output, max_threads);
+            printf("%s\n%s was unsquished into /%s\n", green("Unpacking complete!").c_str(), squish.c_str(), output.c_str());
         } else
             return usage();
     } catch (const AppError& e) {

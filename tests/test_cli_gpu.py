@@ -1,6 +1,6 @@
 """GPU: the C++ `squishrs` host driver (pack through sq_pack_batch) against the oracle's .squish
 restatement -- whole archive byte-identical except the 8 timestamp bytes --
-plus the reference's CLI behaviours from tests/cli_tests.rs that do not need `unpack`."""
+plus the reference's CLI behaviours from tests/cli_tests.rs, including the pack -> unpack round trips."""
 import json
 import os
 import subprocess
@@ -95,3 +95,36 @@ def test_empty_dir_and_errors(tmp_path):
     assert r.returncode != 0 and "Error" in r.stderr                    # cli_tests.rs:82-99
     r = _run("list", str(tmp_path / "missing.squish"))
     assert r.returncode != 0 and "Error" in r.stderr                    # cli_tests.rs:101-120
+
+
+def test_pack_unpack_roundtrip(tmp_path):
+    # tests/cli_tests.rs:12-53 (two small files) and :122-159 (nested directories), plus every chunk kind
+    # of the pack path: what the GPU packed, the host reader restores byte for byte
+    tree = tmp_path / "input"
+    files = {
+        "file1.txt": b"hello",
+        "file2.bin": bytes([0, 1, 2, 3, 4]),
+        "dir1/dir2/nested.txt": b"nested file content",
+        "dir1/text.txt": corpus.text_like(3, 400000),
+        "dir1/again.txt": corpus.text_like(3, 400000),
+        "r/random256k.bin": corpus.random_bytes(9, 1, 262144),
+        "r/planted.bin": corpus.planted(5, 262144, 4),
+        "big/mixed.bin": corpus.mixed(8, 2097152 + 54321),
+        "small/records.bin": corpus.records(2, 12000),
+        "none.bin": b"",
+    }
+    for rel, data in files.items():
+        p = tree / rel
+        p.parent.mkdir(parents=True, exist_ok=True)
+        p.write_bytes(data)
+    arch = tmp_path / "archive.squish"
+    r = _run("pack", str(tree), "--output", str(arch))
+    assert r.returncode == 0, r.stderr
+    out = tmp_path / "output"
+    r = _run("unpack", str(arch), "--output", str(out))
+    assert r.returncode == 0, r.stderr
+    assert "Unpacking complete!" in r.stdout
+    for rel, data in files.items():
+        assert (out / rel).read_bytes() == data, rel
+    n = sum(len(fs) for _, _, fs in os.walk(out))
+    assert n == len(files)

@@ -1,0 +1,184 @@
+"""CPU suite: `squishrs unpack` (the C++ host driver's reader + zstd frame decoder,
+/root/reference/src/archive/reader.rs:232-413, lib.rs:86-106) -- needs no GPU.
+
+* archives written by the oracle's .squish restatement (every strategy of the level-12 encoder, dedup,
+  empty files, nested paths) unpack to the original tree;
+* frames produced by the REAL libzstd 1.5.7 at other levels / with checksum / without content size /
+  concatenated / skippable (tests/golden/zstd_decode_frames.json, tools/gen_decode_golden.py) decode to
+  their content when wrapped into an archive record;
+* every golden frame of the pack path with literal bytes (tests/golden/zstd12_frames.json "literals");
+* the reference's own round-trip fixture (tests/roundtrip.rs) and CLI error behaviour (tests/cli_tests.rs)."""
+import hashlib
+import json
+import os
+import struct
+import subprocess
+
+import pytest
+
+import corpus
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CLI = os.path.join(ROOT, "squishrs_amd", "host", "squishrs")
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _cli_built():
+    from squishrs_amd import _lib
+    assert os.path.exists(_lib.LIB_PATH), "run __graft_entry__.build() first"
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "squishrs_amd", "host")])
+
+
+def _run(*args, cwd=None):
+    return subprocess.run([CLI, *args], capture_output=True, text=True, cwd=cwd)
+
+
+def _archive(records, files, ts=0):
+    """records: [(hash16, orig_size, frame)], files: [(rel, size, [hash16])] -> .squish v1.2 bytes (App. A)"""
+    b = bytearray(b"squish1.2.0") + struct.pack("<QQ", ts, len(records))
+    for h, osz, fr in records:
+        b += h + struct.pack("<QQ", osz, len(fr)) + fr
+    b += struct.pack("<I", len(files))
+    for rel, size, hashes in files:
+        p = rel.encode()
+        b += struct.pack("<I", len(p)) + p + struct.pack("<QI", size, len(hashes)) + b"".join(hashes)
+    return bytes(b)
+
+
+def _tree(root):
+    out = {}
+    for d, _, fs in os.walk(root):
+        for f in fs:
+            p = os.path.join(d, f)
+            out[os.path.relpath(p, root)] = open(p, "rb").read()
+    return out
+
+
+def test_unpack_oracle_archive(tmp_path, oracle):
+    files = [
+        ("a/text.txt", corpus.make("text", 1, 300000)),        # btlazy2 + lazy2 sized chunks
+        ("a/b/records.bin", corpus.make("records", 2, 70000)),
+        ("a/b/c/runs.bin", corpus.make("runs", 3, 50000)),
+        ("skewed.bin", corpus.make("skewed", 4, 20000)),
+        ("tiny.txt", b"hello squish"),
+        ("small.bin", corpus.make("text", 5, 9000)),           # btopt strategy (<= 16 KiB)
+        ("empty.dat", b""),                                    # zero chunks (writer.rs:241-245)
+        ("dup/text_again.txt", corpus.make("text", 1, 300000)),  # exact duplicate: no second record
+        ("big/mixed.bin", corpus.make("mixed", 6, (2 << 20) + 12345)),  # a 2 MiB chunk (row-hash lazy2) + a tail chunk
+        ("rand.bin", corpus.make("random", 7, 262144)),        # raw blocks
+        ("planted.bin", corpus.make("planted4", 8, 262144)),
+    ]
+    arch = oracle.pack_archive(files, timestamp=1700000000)
+    a = tmp_path / "t.squish"
+    a.write_bytes(arch)
+    out = tmp_path / "out"
+    r = _run("unpack", str(a), "--output", str(out))
+    assert r.returncode == 0, r.stderr
+    assert "Unpacking complete!" in r.stdout and f"{a} was unsquished into /{out}" in r.stdout  # lib.rs:100-105
+    got = _tree(out)
+    assert sorted(got) == sorted(p for p, _ in files)
+    for p, d in files:
+        assert got[p] == d, p
+    # default output name: the archive path without ".squish" (lib.rs:88-93); -j accepted
+    r = _run("-j", "2", "unpack", "t.squish", cwd=tmp_path)
+    assert r.returncode == 0, r.stderr
+    assert _tree(tmp_path / "t") == got
+    # list agrees with what was unpacked
+    r = _run("list", str(a), "--simple")
+    assert r.returncode == 0 and f"number_of_files: {len(files)}" in r.stdout
+
+
+def _expected(case):
+    if case["kind"] == "concat":
+        return b"".join(corpus.make(k, s, n) for k, s, n in case["parts"])
+    return corpus.make(case["kind"], case["seed"], case["nbytes"])
+
+
+def test_unpack_decodes_real_libzstd_frames(tmp_path):
+    fx = json.load(open(os.path.join(ROOT, "tests", "golden", "zstd_decode_frames.json")))
+    assert len(fx["cases"]) >= 60
+    records, files, want = [], [], {}
+    for i, c in enumerate(fx["cases"]):
+        data = _expected(c)
+        assert hashlib.sha256(data).hexdigest() == c["sha256"], c["name"]
+        h = hashlib.md5(c["name"].encode()).digest()  # any 16 distinct bytes serve as the record key
+        records.append((h, 2 << 20, bytes.fromhex(c["frame"])))
+        files.append((f"f/{i:03d}.bin", len(data), [h]))
+        want[f"f/{i:03d}.bin"] = data
+    a = tmp_path / "z.squish"
+    a.write_bytes(_archive(records, files))
+    out = tmp_path / "o"
+    r = _run("unpack", str(a), "-o", str(out))
+    assert r.returncode == 0, r.stderr
+    got = _tree(out)
+    for p, d in want.items():
+        assert got[p] == d, p
+
+
+def test_unpack_literal_goldens_of_the_pack_path(tmp_path, oracle):
+    # frames whose bytes came from real libzstd 1.5.7 at level 12 (known answers of SURVEY App. B)
+    fx = json.load(open(os.path.join(ROOT, "tests", "golden", "zstd12_frames.json")))
+    records, files, want = [], [], {}
+    for i, (name, c) in enumerate(sorted(fx["literals"].items())):
+        if not isinstance(c, dict) or "frame" not in c:
+            continue
+        fr = bytes.fromhex(c["frame"])
+        data = bytes.fromhex(c["hex"])
+        h = hashlib.md5(name.encode()).digest()
+        records.append((h, 2 << 20, fr))
+        files.append((f"{i}.bin", len(data), [h, h]))  # the same chunk twice in one file
+        want[f"{i}.bin"] = data + data
+    assert len(records) >= 8
+    # ... and the generated cases small enough to carry their frame bytes (all three strategies)
+    n = 0
+    for j, g in enumerate(fx["generated"]):
+        if not g.get("frame"):
+            continue
+        data = corpus.make(g["kind"], g["seed"], g["len"])
+        h = hashlib.md5(b"g%d" % j).digest()
+        records.append((h, 2 << 20, bytes.fromhex(g["frame"])))
+        files.append((f"g/{j}.bin", len(data), [h]))
+        want[f"g/{j}.bin"] = data
+        n += 1
+    assert n >= 80
+    a = tmp_path / "l.squish"
+    a.write_bytes(_archive(records, files))
+    r = _run("unpack", str(a), "-o", str(tmp_path / "o"))
+    assert r.returncode == 0, r.stderr
+    assert _tree(tmp_path / "o") == want
+
+
+def test_unpack_reference_roundtrip_fixture(tmp_path):
+    fx = json.load(open(os.path.join(ROOT, "tests", "golden", "roundtrip_hello_squish.json")))
+    a = tmp_path / "r.squish"
+    a.write_bytes(bytes.fromhex(fx["archive"]))
+    r = _run("unpack", str(a), "--output", str(tmp_path / "restored"))   # tests/roundtrip.rs
+    assert r.returncode == 0, r.stderr
+    assert (tmp_path / "restored" / "file.txt").read_bytes() == b"hello squish"
+
+
+def test_unpack_errors(tmp_path, oracle):
+    r = _run("unpack", "nonexistent.squish", "--output", str(tmp_path / "o"), cwd=tmp_path)   # cli_tests.rs:101-120
+    assert r.returncode != 0 and "Error" in r.stderr and "Specified file does not exist" in r.stderr
+    bad = tmp_path / "garbage.squish"
+    bad.write_bytes(b"this is not an archive at all")
+    r = _run("unpack", str(bad), "-o", str(tmp_path / "o"))
+    assert r.returncode != 0 and "Archive format error" in r.stderr
+    # a file that names a chunk no record holds (reader.rs:396-400)
+    h0, h1 = b"\x01" * 16, b"\x02" * 16
+    fr = oracle.compress_chunk(b"some bytes " * 50)
+    a = tmp_path / "m.squish"
+    a.write_bytes(_archive([(h0, 2 << 20, fr)], [("x/y.txt", 550, [h0, h1])]))
+    r = _run("unpack", str(a), "-o", str(tmp_path / "o2"))
+    assert r.returncode != 0 and "Missing Chunk for File: `x/y.txt`" in r.stderr
+    # damaged frame, truncated record, capacity too small (zstd::bulk::decompress(.., orig_size))
+    dmg = bytearray(fr)
+    dmg[len(dmg) // 2] ^= 0x5A
+    dmg[6] ^= 0xFF
+    for rec, what in (((h0, 2 << 20, bytes(dmg)), "damaged"), ((h0, 2 << 20, fr[:-3]), "truncated"), ((h0, 100, fr), "capacity")):
+        a.write_bytes(_archive([rec], [("y.txt", 550, [h0])]))
+        r = _run("unpack", str(a), "-o", str(tmp_path / ("o_" + what)))
+        assert r.returncode != 0 and "Error reading from squish" in r.stderr, what
+    a.write_bytes(_archive([(h0, 2 << 20, fr)], [("y.txt", 550, [h0])])[:-5])
+    r = _run("unpack", str(a), "-o", str(tmp_path / "o3"))
+    assert r.returncode != 0 and "Error" in r.stderr
