@@ -511,6 +511,17 @@ static int compress_async(sq_ctx* c, const u8* d_data, const u64* h_off, const u
         }
     }
 #ifdef SQ_PROF
+    if (fast) { // stage 1 phase timers (one 256-byte slice per wave: its saved state, then 8 tick sums)
+        std::vector<unsigned long long> tot(8, 0), one(8);
+        for (u32 w = 0; w < fwaves; w++) {
+            (void)hipMemcpy(one.data(), (u8*)c->b_etab.p + (size_t)w * (etab_bytes + 256) + etab_bytes + 32, 64, hipMemcpyDeviceToHost);
+            for (int k = 0; k < 8; k++) tot[k] += one[k];
+        }
+        static const char* nm1[6] = {"build", "scan_loop", "lookups(in scan)", "hit_resolution", "precheck+frame", "chunk_total"};
+        fprintf(stderr, "[squish_gpu prof] stage 1: waves=%u kernel=%.2f ms; per-wave mean ms:", fwaves, c->last.fast_ms);
+        for (int k = 0; k < 6; k++) fprintf(stderr, " %s=%.3f", nm1[k], (double)tot[k] / fwaves / 1e5);
+        fprintf(stderr, "\n");
+    }
     {   // profiling build: sum the per-wave phase timers (100 MHz ticks) and print them
         std::vector<unsigned long long> tot(33, 0), one(71), worst(71, 0);
         std::vector<std::pair<unsigned long long, unsigned long long>> longest; // (ticks, pass<<32 | chunk) per wave

@@ -17,6 +17,7 @@
 // machine (248 VGPRs, 20 KB of LDS of entropy tables) and keeps the certificate's table in HBM.
 #pragma once
 #include "sq_zstd_match.h"
+#include <type_traits>
 #if !SQ_ON_DEVICE
 #include <algorithm>
 #include <utility>
@@ -41,6 +42,9 @@ struct FastLds {
     u32 cand[256];                   // a round's Bloom positives: 128 x (position, bytes)
     u32 hits[2 * SQZ_FAST_HITS];     // (position, bytes) of scanned positions whose bytes equal a scheduled position's;
                                      // position 0 = two scheduled positions with equal bytes
+#ifdef SQ_PROF
+    unsigned long long prof[8]; // 100 MHz ticks: 0 build, 1 scan loop, 2 look-ups (inside 1), 3 hit resolution, 4 pre-check + frame, 5 whole chunk
+#endif
 };
 
 #define SQZ_FAST_MIN_BLOCK (4096u * 10u) // HUF's sampled pre-check needs srcSize >= 10 samples
@@ -82,6 +86,18 @@ SQ_DEVFN u32 fast_literals_uncompressible(const u8* blk, u32 size, u32* count /*
     wv_max_and_last(count, 256, &l2, &dummy);
     return l1 + l2 <= ((2 * 4096) >> 7) + 4;
 }
+
+#if defined(SQ_PROF) && SQ_ON_DEVICE
+#define FPROF_T0(v) unsigned long long v = __builtin_amdgcn_s_memrealtime()
+#define FPROF_ADD(L, slot, v)                                              \
+    do {                                                                   \
+        unsigned long long e_ = __builtin_amdgcn_s_memrealtime();          \
+        if (wv_lane() == 0) (L)->prof[slot] += e_ - (v);                   \
+    } while (0)
+#else
+#define FPROF_T0(v) do { } while (0)
+#define FPROF_ADD(L, slot, v) do { } while (0)
+#endif
 
 // ---------------------------------------------------------------- the certificate, LDS edition
 // Same statement as cert_compute_core (sq_zstd_match.h) -- for each block, the first scheduled
@@ -141,6 +157,15 @@ SQ_DEV u32 fast_sched_mask(const u32* lvlWords /*global*/, s32 lo, u32 blk1, u32
     return fast_sched_mask_blk(lvlWords, lo, SQZ_WINDOW_START, end0, wdA, wdB, haveWords);
 }
 
+#if SQ_ON_DEVICE
+// the scan's copy of it, kept out of line: it runs in ~10 of a chunk's 256 rounds, and inlined into each of the
+// five unrolled rounds it was most of the loop's code (the loop no longer fitted the instruction cache)
+__device__ __noinline__ u32 fast_sched_mask_rare(const u32* lvlWords, s32 lo, u32 blk1, u32 chunkEndPos, u32 wdA, u32 wdB,
+                                                 u32 haveWords) {
+    return fast_sched_mask(lvlWords, lo, blk1, chunkEndPos, wdA, wdB, haveWords != 0);
+}
+#endif
+
 // The same for a window [ur, ur + 16) (relative to its block's start) that lies in levels >= 16, inside
 // the block's searched range and inside one block: at most one scheduled position per level part, no
 // loop, no division.  wa / wb: level words of the levels of ur and ur + 15.
@@ -189,6 +214,22 @@ SQ_DEV void cert_pos8(const CertCtx& cx, u32 i, u32 nCert, u32 (&sp)[8]) {
     asm volatile("" : "+v"(t[0]), "+v"(t[1]), "+v"(t[2]), "+v"(t[3]), "+v"(t[4]), "+v"(t[5]), "+v"(t[6]), "+v"(t[7]));
 #pragma unroll
     for (u32 g = 0; g < 8; g++) sp[g] = t[g] + ad[g];
+}
+
+// the three 2-byte windows of a scheduled value as keys of the scan's filter (see the scan)
+SQ_DEV void vbloom_add3(SQ_L u32* const B, u32 v) {
+#if SQ_ON_DEVICE
+#pragma unroll
+    for (u32 k = 0; k < 3; k++) {
+        u32 const key = (v >> (8 * k)) & 0xFFFFu;
+        __hip_atomic_fetch_or(&B[key >> 5], 1u << (key & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+#else
+    for (u32 k = 0; k < 3; k++) {
+        u32 const key = (v >> (8 * k)) & 0xFFFFu;
+        B[key >> 5] |= 1u << (key & 31);
+    }
+#endif
 }
 
 // cx: base, schedTab, certCnt0, nCert, base1Pos, tabOff1 (0), repOff, chunkEndPos are inputs;
@@ -254,6 +295,7 @@ SQ_DEV void cert_lds_core(CertCtx& cx, FastLds* L, u8* rawOut) {
         }
         return true;
     };
+    FPROF_T0(t_build);
     // ---- build pass 1: Bloom filter, bucket counts, repcode test.  The values at the scheduled positions are
     // gathered ONCE (an 8-byte load gives the bytes at s and at s + 1) and stay in registers for the scatter
     // below: every gather is a 64-byte sector of HBM, 3,500 of them per chunk and pass.
@@ -278,6 +320,9 @@ SQ_DEV void cert_lds_core(CertCtx& cx, FastLds* L, u8* rawOut) {
                 u64 q[8];
 #pragma unroll
                 for (u32 g = 0; g < 8; g++) q[g] = sq_grd64(base + sp[g]); // s + 8 <= block end for every search
+                if (cx.dbg & 32) // timing experiment: made-up values instead of the gathered ones
+#pragma unroll
+                    for (u32 g = 0; g < 8; g++) q[g] = (u64)(sp[g] * 2654435761u) | ((u64)(sp[g] * 40503u) << 32);
 #pragma unroll
                 for (u32 g = 0; g < 8; g++) {
                     v[g] = (u32)q[g];
@@ -289,7 +334,7 @@ SQ_DEV void cert_lds_core(CertCtx& cx, FastLds* L, u8* rawOut) {
             for (u32 g = 0; g < 8; g++) {
                 vv[8 * it + g] = v[g];
                 if (i0 + 64 * g + lane < nCert) {
-                    vbloom_add(bloom, v[g]);
+                    vbloom_add3(bloom, v[g]);
                     (void)fast_cnt16_add(ends, v[g] >> 22);
                     if (cx.repOff && v1[g] == vr[g]) note(sp[g], vmin, vmin1); // repcode at s+1
                 }
@@ -347,7 +392,7 @@ SQ_DEV void cert_lds_core(CertCtx& cx, FastLds* L, u8* rawOut) {
     wv_fence();
     // ---- scheduled positions with equal values: equal neighbours inside a bucket
     bool hitsFull = false;
-    for (u32 k0 = 0; k0 < SQZ_FAST_KEYS; k0 += 64) {
+    for (u32 k0 = 0; k0 < ((cx.dbg & 128) ? 0u : SQZ_FAST_KEYS); k0 += 64) { // 128: timing experiment
         u32 const k = k0 + lane;
         u32 const lo = k ? fast_get16(ends, k - 1) : 0u, hi = fast_get16(ends, k);
         // every value that occurs twice in the bucket is reported once (at its second occurrence)
@@ -372,6 +417,7 @@ SQ_DEV void cert_lds_core(CertCtx& cx, FastLds* L, u8* rawOut) {
     if (hitsFull) { // cannot even list the repeats inside the schedule: no certificate
         certEnd = certEnd1 = SQZ_WINDOW_START;
     }
+    FPROF_ADD(L, 0, t_build);
     // ---- scan
     const SQ_L u32* const B = bloom;
     const u8* const src0 = base + SQZ_WINDOW_START;
@@ -395,7 +441,17 @@ SQ_DEV void cert_lds_core(CertCtx& cx, FastLds* L, u8* rawOut) {
     // that touch the block boundary or the dense start take the general routine, which loads its own):
     // lane l loads word (k0 + (l & 7)), k0 = level of the round's first byte; pickLevels() hands every
     // lane the two words of its own 16 positions.
-    auto loadLevels = [&](s32 rp, u32& wl) {
+    // AL (std::true_type): the chunk starts on a 16-byte boundary, so a lane's 16 positions are one window
+    // of the schedule's bitmap (SQZ_SCHEDBITS_OFF): `wl` is then that window's mask itself, loaded with the
+    // stream, and none of the level arithmetic below runs.
+    const u16* const schedBits = (const u16*)(cx.schedTab + SQZ_SCHEDBITS_OFF);
+    auto loadLevels = [&](auto AL, s32 rp, u32& wl) {
+        if constexpr (decltype(AL)::value) {
+            bool const second = (blk1 != 0xFFFFFFFFu) && rp >= (s32)blk1;
+            u32 const wi = (((u32)rp - (second ? blk1 : SQZ_WINDOW_START)) >> 4) + lane;
+            wl = sq_grd16((const u8*)(schedBits + (second ? SQZ_SCHEDBITS_N : 0u) + (wi < SQZ_SCHEDBITS_N ? wi : SQZ_SCHEDBITS_N - 1)));
+            return;
+        }
         bool const second = (blk1 != 0xFFFFFFFFu) && rp >= (s32)blk1;
         u32 const bs = second ? blk1 : SQZ_WINDOW_START;
         s32 const r0 = rp - (s32)bs;
@@ -444,7 +500,7 @@ SQ_DEV void cert_lds_core(CertCtx& cx, FastLds* L, u8* rawOut) {
         s32 const r = lo - (s32)bs;
         bool const plain = r >= 4096 && (u32)(lo + 16) <= blkEnd - 8 && !((blk1 != 0xFFFFFFFFu) && lo < (s32)blk1 && lo + 16 > (s32)blk1);
         if (wv_ballot(!plain)) {
-            u32 const m = fast_sched_mask(lvlWords, lo, blk1, cx.chunkEndPos, wa, wb, plain);
+            u32 const m = fast_sched_mask_rare(lvlWords, lo, blk1, cx.chunkEndPos, wa, wb, plain ? 1u : 0u);
             // This rare path loads level words itself.  Left pending at the join, such a load makes hipcc
             // guard the main path's registers with s_waitcnt vmcnt(0) in EVERY round, which drains the four
             // rounds of stream loads in flight (measured: the scan ran at one memory latency per round).
@@ -459,6 +515,8 @@ SQ_DEV void cert_lds_core(CertCtx& cx, FastLds* L, u8* rawOut) {
     s32 pendFrom = p0; // first position whose positives have not all been looked up yet
     auto lookUp = [&](u32 atLeast) -> bool {
         bool ok = true;
+        FPROF_T0(t_look);
+        if (cx.dbg & 256) nCand = 0; // timing experiment: positives dropped
         while (nCand >= atLeast && nCand) {
             u32 const take = nCand < 64 ? nCand : 64, j0 = nCand - take; // from the end of the list
             bool const have = lane < take;
@@ -467,12 +525,13 @@ SQ_DEV void cert_lds_core(CertCtx& cx, FastLds* L, u8* rawOut) {
             if (!pushHit(hit, hp, hv)) ok = false;
             nCand = j0;
         }
+        FPROF_ADD(L, 2, t_look);
         return ok;
     };
     // one round: Bloom tests, scheduled positions removed, positives collected; false = list of hits full
-    auto round = [&](sq_v4u w, sq_v4u wn, u32 wl) -> bool {
-        u32 wa, wb;
-        pickLevels(pos, wl, wa, wb);
+    auto round = [&](auto AL, sq_v4u w, sq_v4u wn, u32 wl) -> bool {
+        u32 wa = 0, wb = 0;
+        if constexpr (!decltype(AL)::value) pickLevels(pos, wl, wa, wb);
         u32 d4;
         {
             u32 const nx = (u32)__builtin_amdgcn_update_dpp(0, (int)w.x, 0x130 /* wave_shl:1 */, 0xF, 0xF, false);
@@ -491,10 +550,11 @@ SQ_DEV void cert_lds_core(CertCtx& cx, FastLds* L, u8* rawOut) {
         f = f < 0 ? 0 : (f > 16 ? 16 : f);
         l = l < 0 ? 0 : (l > 16 ? 16 : l);
         u32 const okMask = ((1u << l) - 1u) & ~((1u << f) - 1u);
-        // The filter's two probes of the value at p are keyed by its low and its high 16 bits, i.e. by the
-        // 2-byte windows at p and at p + 2, in ONE table: probe 2 of position p is probe 1 of position
-        // p + 2.  So each of the lane's 18 windows (16 of its own bytes, 2 reaching into the next lane's) is
-        // looked up once, and a position passes when its own window's bit and the one two further do.
+        // The filter's probes of the value at p are keyed by its three 2-byte windows (at p, p + 1, p + 2) in
+        // ONE table: a probe of position p is also a probe of its neighbours.  So each of the lane's 18
+        // windows (16 of its own bytes, 2 reaching into the next lane's) is looked up once, and a position
+        // passes when the bits of its own window and of the next two are set: three probes (0.3 % false
+        // positives at 10,500 keys in 64 Kibit) for the price of one.
         u32 bm = 0;
 #pragma unroll
         for (u32 q = 0; q < 5; q++) {
@@ -509,8 +569,21 @@ SQ_DEV void cert_lds_core(CertCtx& cx, FastLds* L, u8* rawOut) {
 #pragma unroll
             for (u32 k = 0; k < nk; k++) bm |= __builtin_amdgcn_ubfe(pw[k], s[k], 1u) << (4 * q + k);
         }
-        u32 cm = bm & (bm >> 2) & okMask;
-        cm &= ~schedMaskFast(lo, wa, wb);
+        u32 cm = bm & (bm >> 1) & (bm >> 2) & okMask;
+        if constexpr (decltype(AL)::value) {
+            // the window's bitmap word; a block's searches stop 8 bytes before its end (a short last block
+            // uses a prefix of the table)
+            bool const second = (blk1 != 0xFFFFFFFFu) && pos >= (s32)blk1;
+            u32 const lim = ((!second && blk1 != 0xFFFFFFFFu) ? blk1 : cx.chunkEndPos) - 8;
+            u32 sm = wl;
+            if ((u32)pos + 1024 > lim) {
+                s32 nb = (s32)lim - lo;
+                nb = nb < 0 ? 0 : (nb > 16 ? 16 : nb);
+                sm &= (1u << nb) - 1u;
+            }
+            cm &= ~sm;
+        } else
+            cm &= ~schedMaskFast(lo, wa, wb);
         bool ok = true;
         if (nCand == 0) pendFrom = pos; // nothing older than this round is waiting for its look-up
         // compaction (one positive per lane and turn) into the list that collects the positives of several
@@ -519,7 +592,10 @@ SQ_DEV void cert_lds_core(CertCtx& cx, FastLds* L, u8* rawOut) {
         for (;;) {
             u64 const m = wv_ballot(cm != 0);
             if (!m) break;
-            if (nCand + (u32)__popcll(m) > 128 && !lookUp(1)) ok = false; // make room: look the waiting ones up now
+            // no room: look the waiting ones up now.  (Rare: the caller empties the list every five rounds;
+            // only where every 2nd / 3rd position is a scheduled one -- bytes 256..1023 of a block -- do all
+            // the positions between them pass the three-window filter, ~300 in one round.)
+            if (nCand + (u32)__popcll(m) > 128 && !lookUp(1)) ok = false;
             if (cm) {
                 u32 const j = (u32)__builtin_ctz(cm);
                 cm &= cm - 1;
@@ -537,43 +613,56 @@ SQ_DEV void cert_lds_core(CertCtx& cx, FastLds* L, u8* rawOut) {
             cx.nOvf = 1u | (nCand << 8);
             nCand = 128;
         }
-        if (nCand >= SQZ_FAST_LOOKUP_BATCH && !lookUp(SQZ_FAST_LOOKUP_BATCH)) {
-            ok = false;
-            cx.nOvf = 2u | (nHits << 8);
-        }
         pos += 1024;
         return ok;
     };
-    if (pos < (s32)scanStop() && !(cx.dbg & 2)) {
+    FPROF_T0(t_scan);
+    bool full = false, scanned = false;
+    auto scan = [&](auto AL) {
+        scanned = true;
         sq_v4u wA = loadRound(pos), wB = loadRound(pos + 1024), wC = loadRound(pos + 2048), wD = loadRound(pos + 3072), wE;
         u32 lA, lB, lC, lD, lE;
-        loadLevels(pos, lA);
-        loadLevels(pos + 1024, lB);
-        loadLevels(pos + 2048, lC);
-        loadLevels(pos + 3072, lD);
-        bool full = false;
+        loadLevels(AL, pos, lA);
+        loadLevels(AL, pos + 1024, lB);
+        loadLevels(AL, pos + 2048, lC);
+        loadLevels(AL, pos + 3072, lD);
         for (;;) {
             wE = loadRound(pos + 4096);
-            loadLevels(pos + 4096, lE);
-            if (!round(wA, wB, lA)) { full = true; break; }
+            loadLevels(AL, pos + 4096, lE);
+            // ONE look-up site for the five rounds below (inlined into each of them, the look-up code made
+            // the loop several times the size of the instruction cache's share of a wave)
+            if (nCand >= SQZ_FAST_LOOKUP_BATCH && !lookUp(1)) {
+                cx.nOvf = 2u | (nHits << 8);
+                full = true;
+                break;
+            }
+            if (!round(AL, wA, wB, lA)) { full = true; break; }
             if (pos >= (s32)scanStop()) break;
             wA = loadRound(pos + 4096);
-            loadLevels(pos + 4096, lA);
-            if (!round(wB, wC, lB)) { full = true; break; }
+            loadLevels(AL, pos + 4096, lA);
+            if (!round(AL, wB, wC, lB)) { full = true; break; }
             if (pos >= (s32)scanStop()) break;
             wB = loadRound(pos + 4096);
-            loadLevels(pos + 4096, lB);
-            if (!round(wC, wD, lC)) { full = true; break; }
+            loadLevels(AL, pos + 4096, lB);
+            if (!round(AL, wC, wD, lC)) { full = true; break; }
             if (pos >= (s32)scanStop()) break;
             wC = loadRound(pos + 4096);
-            loadLevels(pos + 4096, lC);
-            if (!round(wD, wE, lD)) { full = true; break; }
+            loadLevels(AL, pos + 4096, lC);
+            if (!round(AL, wD, wE, lD)) { full = true; break; }
             if (pos >= (s32)scanStop()) break;
             wD = loadRound(pos + 4096);
-            loadLevels(pos + 4096, lD);
-            if (!round(wE, wA, lE)) { full = true; break; }
+            loadLevels(AL, pos + 4096, lD);
+            if (!round(AL, wE, wA, lE)) { full = true; break; }
             if (pos >= (s32)scanStop()) break;
         }
+    };
+    if (pos < (s32)scanStop() && !(cx.dbg & 2)) {
+        if (src0 == a0)
+            scan(std::true_type{});
+        else
+            scan(std::false_type{});
+    }
+    if (scanned) {
         if (rawCopy) cx.rawEnd = (u32)pos < cx.chunkEndPos ? (u32)pos : SQZ_WINDOW_START + ((cx.chunkEndPos - SQZ_WINDOW_START) & ~15u);
         if (!full && !lookUp(1)) full = true; // the positives still waiting
         if (full) { // more genuine repeats than the list holds (compressible data): positions >= pendFrom
@@ -583,6 +672,8 @@ SQ_DEV void cert_lds_core(CertCtx& cx, FastLds* L, u8* rawOut) {
             if (cut < certEnd1) certEnd1 = cut;
         }
     }
+    FPROF_ADD(L, 1, t_scan);
+    FPROF_T0(t_res);
     // ---- resolve the hits by walking S: a scheduled s fails to be certified when an equal value sits at
     // an earlier position (a scanned position p, or for a pair inside the schedule the earliest member)
     for (u32 hIdx = 0; hIdx < nHits; hIdx++) {
@@ -631,6 +722,7 @@ SQ_DEV void cert_lds_core(CertCtx& cx, FastLds* L, u8* rawOut) {
         settle(v0, v1);
     }
     wv_fence();
+    FPROF_ADD(L, 3, t_res);
 #else
     // scalar twin: the same statement, computed plainly
     (void)bloom; (void)vals; (void)ends; (void)hits; (void)nHits; (void)lvlWords;
@@ -710,6 +802,7 @@ SQ_DEV u32 fastpath_frame_wave(const u8* src, u32 n, u8* dst, u32 cap, u32* E, u
             bool const room = cap >= n + 9 + 3 * nBlocks;
             u32 const hdr = 5 + (n < 256 ? 1u : (n < 65536 + 256 ? 2u : 4u)); // = fast_frame_header()
             cert_lds_core(cx, L, (sized && room && !(dbg & 4)) ? dst + hdr : nullptr);
+            FPROF_T0(t_frame);
             c0 = cx.certEnd;
             c1 = cx.certEnd1 | SQZ_CERT_HINT_VALID;
             if (dbg & 64) c0 = cx.nOvf; // bring-up: why the scan gave up
@@ -739,6 +832,7 @@ SQ_DEV u32 fastpath_frame_wave(const u8* src, u32 n, u8* dst, u32 cap, u32* E, u
                     frame = (u32)(op - dst);
                 }
             }
+            FPROF_ADD(L, 4, t_frame);
         }
     }
     WV_SERIAL {
@@ -766,6 +860,11 @@ k_incompressible_batch(const u8* data, const u64* off, const u32* len, const u8*
     // 0: the table holds unknown words; `persist`: the host vouches that the pool is as the previous
     // launch left it, so the saved counter is still true and the tags go on counting
     u32 gen = persist ? gld32(saved) : 0u;
+#ifdef SQ_PROF
+    if (wv_lane() == 0)
+        for (int k = 0; k < 8; k++) lds.prof[k] = 0;
+    wv_fence();
+#endif
     for (;;) {
         u32 idx = 0;
         if (wv_lane() == 0) idx = atomicAdd(queue, 1u);
@@ -780,8 +879,10 @@ k_incompressible_batch(const u8* data, const u64* off, const u32* len, const u8*
             gen++;
             u32 const cap = (u32)(slot_off[idx + 1] - slot_off[idx]);
             wv_mem_sync_inv(); // no L1 line from the previous chunk's table / data survives
+            FPROF_T0(t_chunk);
             r = fastpath_frame_wave(data + off[idx], len[idx], slots + slot_off[idx], cap, E, gen << SQZ_HT_GEN_SHIFT,
                                     schedTab, &lds, cert_out + 2 * (size_t)idx, dbg);
+            FPROF_ADD(&lds, 5, t_chunk);
         } else if (wv_lane() == 0) {
             cert_out[2 * (size_t)idx] = 0;
             cert_out[2 * (size_t)idx + 1] = 0;
@@ -801,6 +902,11 @@ k_incompressible_batch(const u8* data, const u64* off, const u32* len, const u8*
         }
     }
     if (wv_lane() == 0) saved[0] = gen;
+#ifdef SQ_PROF
+    wv_fence();
+    if (wv_lane() == 0)
+        for (int k = 0; k < 8; k++) ((unsigned long long*)(saved + 8))[k] = lds.prof[k];
+#endif
 }
 #endif
 

@@ -131,6 +131,10 @@ SQ_HD void sched_tab_fill(u32* tab) {
             u32 const R = (65536u + k) / (k + 1);
             lv[k] = first | ((R > 0x7FFFu ? 0x7FFFu : R) << 17);
         }
+        // the table as a bitmap: bit (p & 15) of the u16 at window (p >> 4)
+        u16* const bits = (u16*)(tab + SQZ_SCHEDBITS_OFF) + variant * SQZ_SCHEDBITS_N;
+        for (u32 w = 0; w < SQZ_SCHEDBITS_N; w++) bits[w] = 0;
+        for (u32 i = 0; i < n; i++) bits[e[i] >> 4] = (u16)(bits[e[i] >> 4] | (1u << (e[i] & 15)));
     }
 }
 

@@ -478,7 +478,12 @@ SQ_DEVFN void dubt_replay(MatchState& ms, u32 to) {
 // lane decide with two multiplications whether one of its 16 positions is a scheduled one.
 #define SQZ_SCHEDLVL_N 512u
 #define SQZ_SCHEDLVL_OFF (2u + 2u * SQZ_SCHEDTAB_N)
-#define SQZ_SCHEDTAB_WORDS (SQZ_SCHEDLVL_OFF + 2u * SQZ_SCHEDLVL_N)
+// ... followed by the two tables once more as bitmaps, 16 positions (one u16) per 16-byte window of the block:
+// for chunks that start on a 16-byte boundary the certificate scan reads a lane's scheduled positions
+// with one 2-byte load instead of computing them.
+#define SQZ_SCHEDBITS_N 8192u // 16-position windows of a 128 KiB block
+#define SQZ_SCHEDBITS_OFF (SQZ_SCHEDLVL_OFF + 2u * SQZ_SCHEDLVL_N)
+#define SQZ_SCHEDTAB_WORDS (SQZ_SCHEDBITS_OFF + 2u * (SQZ_SCHEDBITS_N / 2u))
 
 // number of table entries < limit (entries ascending); whole wave, ~28 coalesced loads per lane
 SQ_DEVFN u32 sched_count(const u32* const entries, u32 const nEntries, u32 const limit) {
