@@ -301,42 +301,88 @@ SQ_DEV void cert_lds_core(CertCtx& cx, FastLds* L, u8* rawOut) {
     // below: every gather is a 64-byte sector of HBM, 3,500 of them per chunk and pass.
     u32 const nBuild = (cx.dbg & 1) ? 0u : nCert; // SQ_FAST_DBG timing experiments: 1 = no build, 2 = no scan
     u32 vv[SQZ_FAST_VALS / 64];
+    if (cx.repOff <= 1) {
+        // all positions first (seven short trips to the L2-resident table), then ALL gathers in flight at
+        // once: one trip to HBM per chunk instead of seven
+        u32 spA[SQZ_FAST_VALS / 64];
+        u64 q[SQZ_FAST_VALS / 64];
 #pragma unroll
-    for (u32 it = 0; it < SQZ_FAST_VALS / 512; it++) {
-        u32 const i0 = 512 * it;
+        for (u32 it = 0; it < SQZ_FAST_VALS / 512; it++) {
+            u32 sp[8];
 #pragma unroll
-        for (u32 g = 0; g < 8; g++) vv[8 * it + g] = 0;
-        if (i0 < nBuild) {
-            u32 sp[8], v[8], v1[8], vr[8];
-            cert_pos8(cx, i0 + lane, nCert, sp);
-            if (cx.repOff > 1) {
+            for (u32 g = 0; g < 8; g++) sp[g] = 0;
+            if (512 * it < nBuild) cert_pos8(cx, 512 * it + lane, nCert, sp);
+#pragma unroll
+            for (u32 g = 0; g < 8; g++) spA[8 * it + g] = sp[g];
+        }
+#pragma unroll
+        for (u32 it = 0; it < SQZ_FAST_VALS / 512; it++) {
+#pragma unroll
+            for (u32 g = 0; g < 8; g++) q[8 * it + g] = 0;
+            if (512 * it < nBuild) {
+#pragma unroll
+                for (u32 g = 0; g < 8; g++) q[8 * it + g] = sq_grd64(base + spA[8 * it + g]); // s + 8 <= block end
+            }
+        }
+        wv_fence();
+        u64 repBits = 0; // (the upper halves of the 8-byte loads are dead after this loop)
+#pragma unroll
+        for (u32 it = 0; it < SQZ_FAST_VALS / 512; it++) {
+            u32 lo32[8];
+#pragma unroll
+            for (u32 g = 0; g < 8; g++) lo32[g] = (u32)q[8 * it + g];
+            asm volatile("" : "+v"(lo32[0]), "+v"(lo32[1]), "+v"(lo32[2]), "+v"(lo32[3]), "+v"(lo32[4]), "+v"(lo32[5]), "+v"(lo32[6]), "+v"(lo32[7]));
+#pragma unroll
+            for (u32 g = 0; g < 8; g++) {
+                vv[8 * it + g] = lo32[g];
+                // repcode test (offset 1) of the search at s: the bytes at s + 1 equal the bytes at s
+                if ((u32)(q[8 * it + g] >> 8) == lo32[g]) repBits |= 1ull << (8 * it + g);
+            }
+        }
+#pragma unroll
+        for (u32 it = 0; it < SQZ_FAST_VALS / 512; it++) {
+            u32 const i0 = 512 * it;
+            if (i0 < nBuild) {
+#pragma unroll
+                for (u32 g = 0; g < 8; g++) {
+                    u32 vg = vv[8 * it + g];
+                    bool rep = (repBits >> (8 * it + g)) & 1;
+                    if (cx.dbg & 32) { // timing experiment: made-up values instead of the gathered ones
+                        vg = spA[8 * it + g] * 2654435761u;
+                        rep = false;
+                        vv[8 * it + g] = vg;
+                    }
+                    if (i0 + 64 * g + lane < nCert) {
+                        vbloom_add3(bloom, vg);
+                        (void)fast_cnt16_add(ends, vg >> 22);
+                        if (cx.repOff && rep) note(spA[8 * it + g], vmin, vmin1); // repcode (offset 1) at s+1
+                    }
+                }
+            }
+        }
+    } else {
+#pragma unroll
+        for (u32 it = 0; it < SQZ_FAST_VALS / 512; it++) {
+            u32 const i0 = 512 * it;
+#pragma unroll
+            for (u32 g = 0; g < 8; g++) vv[8 * it + g] = 0;
+            if (i0 < nBuild) {
+                u32 sp[8], v[8], v1[8], vr[8];
+                cert_pos8(cx, i0 + lane, nCert, sp);
 #pragma unroll
                 for (u32 g = 0; g < 8; g++) {
                     v[g] = sq_grd32(base + sp[g]);
                     v1[g] = sq_grd32(base + sp[g] + 1);
                     vr[g] = sq_grd32(base + sp[g] + 1 - cx.repOff);
                 }
-            } else {
-                u64 q[8];
-#pragma unroll
-                for (u32 g = 0; g < 8; g++) q[g] = sq_grd64(base + sp[g]); // s + 8 <= block end for every search
-                if (cx.dbg & 32) // timing experiment: made-up values instead of the gathered ones
-#pragma unroll
-                    for (u32 g = 0; g < 8; g++) q[g] = (u64)(sp[g] * 2654435761u) | ((u64)(sp[g] * 40503u) << 32);
 #pragma unroll
                 for (u32 g = 0; g < 8; g++) {
-                    v[g] = (u32)q[g];
-                    v1[g] = (u32)(q[g] >> 8);
-                    vr[g] = v[g];
-                }
-            }
-#pragma unroll
-            for (u32 g = 0; g < 8; g++) {
-                vv[8 * it + g] = v[g];
-                if (i0 + 64 * g + lane < nCert) {
-                    vbloom_add3(bloom, v[g]);
-                    (void)fast_cnt16_add(ends, v[g] >> 22);
-                    if (cx.repOff && v1[g] == vr[g]) note(sp[g], vmin, vmin1); // repcode at s+1
+                    vv[8 * it + g] = v[g];
+                    if (i0 + 64 * g + lane < nCert) {
+                        vbloom_add3(bloom, v[g]);
+                        (void)fast_cnt16_add(ends, v[g] >> 22);
+                        if (v1[g] == vr[g]) note(sp[g], vmin, vmin1); // repcode at s+1
+                    }
                 }
             }
         }
@@ -676,50 +722,61 @@ SQ_DEV void cert_lds_core(CertCtx& cx, FastLds* L, u8* rawOut) {
     FPROF_T0(t_res);
     // ---- resolve the hits by walking S: a scheduled s fails to be certified when an equal value sits at
     // an earlier position (a scanned position p, or for a pair inside the schedule the earliest member)
-    for (u32 hIdx = 0; hIdx < nHits; hIdx++) {
-        u32 const hp = hits[2 * hIdx], hv = hits[2 * hIdx + 1];
-        u32 v0 = 0xFFFFFFFFu, v1 = 0xFFFFFFFFu;
-        if (hp != 0) { // a scanned position p with the bytes hv: every scheduled s > p with those bytes
-            for (u32 i0 = 0; i0 < nCert; i0 += 512) {
-                u32 sp[8], v[8];
-                cert_pos8(cx, i0 + lane, nCert, sp);
+    if (nHits) {
+        // the positions and values of S once more, all gathers in flight at once, for every hit together
+        u32 spA[SQZ_FAST_VALS / 64], vA[SQZ_FAST_VALS / 64];
 #pragma unroll
-                for (u32 g = 0; g < 8; g++) v[g] = sq_grd32(base + sp[g]);
+        for (u32 it = 0; it < SQZ_FAST_VALS / 512; it++) {
+            u32 sp[8];
 #pragma unroll
-                for (u32 g = 0; g < 8; g++)
-                    if (i0 + 64 * g + lane < nCert && v[g] == hv && sp[g] > hp) note(sp[g], v0, v1);
-            }
-        } else {
-            // two scheduled positions share bits 6..31 of their values (hv).  Collect the (few) members of
-            // that class; a member whose full value equals an earlier member's is a search that can succeed.
-            SQ_L u32* const mem = (SQ_L u32*)L->cand; // [0] count, then (position, value) pairs
-            if (lane == 0) mem[0] = 0;
-            wv_fence();
-            for (u32 i0 = 0; i0 < nCert; i0 += 512) {
-                u32 sp[8], v[8];
-                cert_pos8(cx, i0 + lane, nCert, sp);
+            for (u32 g = 0; g < 8; g++) sp[g] = 0;
+            if (512 * it < nCert) cert_pos8(cx, 512 * it + lane, nCert, sp);
 #pragma unroll
-                for (u32 g = 0; g < 8; g++) v[g] = sq_grd32(base + sp[g]);
+            for (u32 g = 0; g < 8; g++) spA[8 * it + g] = sp[g];
+        }
 #pragma unroll
-                for (u32 g = 0; g < 8; g++)
-                    if (i0 + 64 * g + lane < nCert && (v[g] & 0xFFFFFFC0u) == hv) {
-                        u32 const at = __hip_atomic_fetch_add(&mem[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                        if (at < 60) {
-                            mem[2 + 2 * at] = sp[g];
-                            mem[3 + 2 * at] = v[g];
-                        }
-                    }
-            }
-            wv_fence();
-            u32 const nm = mem[0];
-            if (lane < nm && lane < 60) {
-                u32 const ms = mem[2 + 2 * lane], mv = mem[3 + 2 * lane];
-                bool rpt = nm > 60; // more members than we keep: every one counts as a repeat (conservative)
-                for (u32 j = 0; j < nm && j < 60; j++) rpt = rpt || (mem[3 + 2 * j] == mv && mem[2 + 2 * j] < ms);
-                if (rpt) note(ms, v0, v1);
+        for (u32 it = 0; it < SQZ_FAST_VALS / 512; it++) {
+#pragma unroll
+            for (u32 g = 0; g < 8; g++) vA[8 * it + g] = 0;
+            if (512 * it < nCert) {
+#pragma unroll
+                for (u32 g = 0; g < 8; g++) vA[8 * it + g] = sq_grd32(base + spA[8 * it + g]);
             }
         }
-        settle(v0, v1);
+        wv_fence();
+        for (u32 hIdx = 0; hIdx < nHits; hIdx++) {
+            u32 const hp = hits[2 * hIdx], hv = hits[2 * hIdx + 1];
+            u32 v0 = 0xFFFFFFFFu, v1 = 0xFFFFFFFFu;
+            if (hp != 0) { // a scanned position p with the bytes hv: every scheduled s > p with those bytes
+#pragma unroll
+                for (u32 i = 0; i < SQZ_FAST_VALS / 64; i++)
+                    if (64 * i + lane < nCert && vA[i] == hv && spA[i] > hp) note(spA[i], v0, v1);
+            } else {
+                // two scheduled positions share bits 6..31 of their values (hv).  Collect the (few) members of
+                // that class; a member whose full value equals an earlier member's is a search that can succeed.
+                SQ_L u32* const mem = (SQ_L u32*)L->cand; // [0] count, then (position, value) pairs
+                if (lane == 0) mem[0] = 0;
+                wv_fence();
+#pragma unroll
+                for (u32 i = 0; i < SQZ_FAST_VALS / 64; i++)
+                    if (64 * i + lane < nCert && (vA[i] & 0xFFFFFFC0u) == hv) {
+                        u32 const at = __hip_atomic_fetch_add(&mem[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        if (at < 60) {
+                            mem[2 + 2 * at] = spA[i];
+                            mem[3 + 2 * at] = vA[i];
+                        }
+                    }
+                wv_fence();
+                u32 const nm = mem[0];
+                if (lane < nm && lane < 60) {
+                    u32 const ms = mem[2 + 2 * lane], mv = mem[3 + 2 * lane];
+                    bool rpt = nm > 60; // more members than we keep: every one counts as a repeat (conservative)
+                    for (u32 j = 0; j < nm && j < 60; j++) rpt = rpt || (mem[3 + 2 * j] == mv && mem[2 + 2 * j] < ms);
+                    if (rpt) note(ms, v0, v1);
+                }
+            }
+            settle(v0, v1);
+        }
     }
     wv_fence();
     FPROF_ADD(L, 3, t_res);
