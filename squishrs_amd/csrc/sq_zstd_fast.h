@@ -441,6 +441,22 @@ SQ_DEV void cert_lds_core(CertCtx& cx, FastLds* L, u8* rawOut) {
     for (u32 k0 = 0; k0 < ((cx.dbg & 128) ? 0u : SQZ_FAST_KEYS); k0 += 64) { // 128: timing experiment
         u32 const k = k0 + lane;
         u32 const lo = k ? fast_get16(ends, k - 1) : 0u, hi = fast_get16(ends, k);
+        {   // quick look first: a bucket holds 3.4 values on average; its first 12 are read with independent
+            // loads and compared pairwise in registers.  Only when some bucket of the 64 has equal tags (or
+            // more than 12 values) does the exact loop below run.
+            u32 t[12];
+#pragma unroll
+            for (u32 a = 0; a < 12; a++) {
+                u32 const x = vals[(lo + a < SQZ_FAST_VALS) ? lo + a : SQZ_FAST_VALS - 1];
+                t[a] = (lo + a < hi) ? x : 0x10000u + a; // beyond the bucket: a value no tag (and no other filler) equals
+            }
+            bool any = hi > lo + 12;
+#pragma unroll
+            for (u32 a = 1; a < 12; a++)
+#pragma unroll
+                for (u32 c = 0; c < a; c++) any = any || (t[a] == t[c]);
+            if (!wv_ballot(any)) continue;
+        }
         // every value that occurs twice in the bucket is reported once (at its second occurrence)
         u32 b = lo + 1;
         for (;;) {
@@ -590,12 +606,24 @@ SQ_DEV void cert_lds_core(CertCtx& cx, FastLds* L, u8* rawOut) {
         u32 const d[5] = {w.x, w.y, w.z, w.w, d4};
         u32 const stop = scanStop();
         s32 const lo = pos + (s32)(16 * lane);
-        if (rawCopy && (u32)lo + 16 <= cx.chunkEndPos) // (clamped loads beyond the end fail this test)
-            sq_gwr128(rawOut + ((u32)lo - SQZ_WINDOW_START) + ((u32)lo >= blk1 ? 6u : 3u), w);
-        s32 f = (s32)SQZ_WINDOW_START - lo, l = (s32)stop - lo;
-        f = f < 0 ? 0 : (f > 16 ? 16 : f);
-        l = l < 0 ? 0 : (l > 16 ? 16 : l);
-        u32 const okMask = ((1u << l) - 1u) & ~((1u << f) - 1u);
+        u32 okMask;
+        if constexpr (decltype(AL)::value) {
+            // aligned chunk: the round starts at or after the chunk start and lies in one block, so the
+            // destination of the raw copy is a wave-uniform base plus 16 bytes per lane
+            if (rawCopy && (u32)lo + 16 <= cx.chunkEndPos) // (clamped loads beyond the end fail this test)
+                sq_gwr128(rawOut + ((u32)pos - SQZ_WINDOW_START) + ((u32)pos >= blk1 ? 6u : 3u) + 16 * lane, w);
+            okMask = 0xFFFFu;
+            if ((u32)pos + 1024 > stop) {
+                s32 l = (s32)stop - lo;
+                l = l < 0 ? 0 : (l > 16 ? 16 : l);
+                okMask = (1u << l) - 1u;
+            }
+        } else {
+            s32 f = (s32)SQZ_WINDOW_START - lo, l = (s32)stop - lo;
+            f = f < 0 ? 0 : (f > 16 ? 16 : f);
+            l = l < 0 ? 0 : (l > 16 ? 16 : l);
+            okMask = ((1u << l) - 1u) & ~((1u << f) - 1u);
+        }
         // The filter's probes of the value at p are keyed by its three 2-byte windows (at p, p + 1, p + 2) in
         // ONE table: a probe of position p is also a probe of its neighbours.  So each of the lane's 18
         // windows (16 of its own bytes, 2 reaching into the next lane's) is looked up once, and a position
