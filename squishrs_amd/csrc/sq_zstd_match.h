@@ -303,6 +303,11 @@ SQ_DEVFN void dubt_insert_range(MatchState& ms, u32 from, u32 to) {
     u32 const btMask = (1u << (ms.cp.chainLog - 1)) - 1;
     const u8* const base = ms.base;
     bool const all = (MODE == 0) && ms.eager;
+    // The fields of `ms` used inside the loops are read ONCE: this function is out of line, `ms` reaches it
+    // as a generic pointer, and every flat_load makes hipcc drain vmcnt and lgkmcnt to 0 before its use --
+    // with table stores pending, a full memory round trip per access.
+    u32 const genBits = ms.genBits;
+    u32 sbMax = ms.sbMax;
 #if SQ_ON_DEVICE
     u32 const lane = wv_lane();
     u64 const below = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
@@ -323,7 +328,7 @@ SQ_DEVFN void dubt_insert_range(MatchState& ms, u32 from, u32 to) {
         for (; idx0 < to && to - idx0 > 128;) {
             // super-batch length: adapts downwards when the Bloom filter has become dense enough
             // (after schedule repairs) to overflow the 256-entry candidate list
-            u32 const lim = (to - idx0 < ms.sbMax) ? to - idx0 : ms.sbMax;
+            u32 const lim = (to - idx0 < sbMax) ? to - idx0 : sbMax;
             PROF_T0(t_p1);
             u32 const cnt = (lim == 2048) ? filter_phase1<true>(base, idx0, lim, hashLog) : filter_phase1<false>(base, idx0, lim, hashLog);
             PROF_ADD(12, t_p1);
@@ -331,13 +336,13 @@ SQ_DEVFN void dubt_insert_range(MatchState& ms, u32 from, u32 to) {
             PROF_CNT(19, cnt);
             if (cnt > 256) {
                 PROF_CNT(17, 1);
-                if (ms.sbMax > 256) { // retry this range with half the length
-                    ms.sbMax >>= 1;
+                if (sbMax > 256) { // retry this range with half the length
+                    sbMax >>= 1;
                     continue;
                 }
                 break; // saturated filter: finish with the per-64 loop below
             }
-            if (cnt <= 96 && lim == ms.sbMax && ms.sbMax < 2048) ms.sbMax <<= 1; // sparse again: grow back
+            if (cnt <= 96 && lim == sbMax && sbMax < 2048) sbMax <<= 1; // sparse again: grow back
             wv_fence();
             PROF_T0(t_p23);
             if (pendingStores) { // the previous super-batch's table stores must land before we gather
@@ -353,7 +358,7 @@ SQ_DEVFN void dubt_insert_range(MatchState& ms, u32 from, u32 to) {
                 if (j < cnt) {
                     cidx[g] = stage[2 * j];
                     ch[g] = stage[2 * j + 1];
-                    chead[g] = ht_dec(ms, sq_tld32(hashTable + ch[g]));
+                    chead[g] = ht_dec_g(genBits, sq_tld32(hashTable + ch[g]));
                 }
             }
             u32 ntake = 0;
@@ -388,14 +393,14 @@ SQ_DEVFN void dubt_insert_range(MatchState& ms, u32 from, u32 to) {
                 }
                 if (j0 > 0) { // an earlier step of this super-batch may have rewritten these heads
                     wv_mem_sync();
-                    if (act) head = ht_dec(ms, sq_tld32(hashTable + h));
+                    if (act) head = ht_dec_g(genBits, sq_tld32(hashTable + h));
                 }
                 WvGroup const g = wv_group(h, act, g_lds.grp);
                 u32 const prevPos = (u32)__shfl((int)idx, (int)(g.prevLane & 63), 64);
                 if (act) {
                     u32 const prev = (g.prevLane < 64) ? prevPos : (head & SQZ_HT_IDX);
                     sq_gst64v(bt + 2 * (idx & btMask), prev, SQZ_DUBT_UNSORTED);
-                    if (g.rank + 1 == g.gsize) sq_gst32(hashTable + h, ht_enc(ms, idx | (head & ~SQZ_HT_IDX)));
+                    if (g.rank + 1 == g.gsize) sq_gst32(hashTable + h, ht_enc_g(genBits, idx | (head & ~SQZ_HT_IDX)));
                 }
                 pendingStores = true;
             }
@@ -403,6 +408,7 @@ SQ_DEVFN void dubt_insert_range(MatchState& ms, u32 from, u32 to) {
             idx0 += lim;
         }
         if (pendingStores) wv_mem_sync();
+        ms.sbMax = sbMax;
     }
     PROF_T0(t_tail);
     // 64 positions per step.  A gather may hit a head written by the previous step and a load is
@@ -416,7 +422,7 @@ SQ_DEVFN void dubt_insert_range(MatchState& ms, u32 from, u32 to) {
         bool cand = active;
         if (MODE != 2 && !all) cand = active && bloom_test(h);
         u32 head = 0;
-        if (cand) head = ht_dec(ms, sq_tld32(hashTable + h));
+        if (cand) head = ht_dec_g(genBits, sq_tld32(hashTable + h));
         bool take;
         if (MODE == 0)
             take = cand && (all || (head & SQZ_HT_LIVE));
@@ -429,7 +435,7 @@ SQ_DEVFN void dubt_insert_range(MatchState& ms, u32 from, u32 to) {
         if (take) {
             u32 const prev = (g.prevLane < 64) ? idx0 + g.prevLane : (head & SQZ_HT_IDX);
             sq_gst64v(bt + 2 * (idx & btMask), prev, SQZ_DUBT_UNSORTED);
-            if (g.rank + 1 == g.gsize) sq_gst32(hashTable + h, ht_enc(ms, idx | (head & ~SQZ_HT_IDX)));
+            if (g.rank + 1 == g.gsize) sq_gst32(hashTable + h, ht_enc_g(genBits, idx | (head & ~SQZ_HT_IDX)));
         }
         wv_mem_sync();
     }
@@ -438,7 +444,7 @@ SQ_DEVFN void dubt_insert_range(MatchState& ms, u32 from, u32 to) {
     for (u32 idx = from; idx < to; idx++) {
         u32 const h = hash4(sq_rd32(base + idx), hashLog);
         if (MODE != 2 && !all && !bloom_test(h)) continue;
-        u32 const head = ht_dec(ms, hashTable[h]);
+        u32 const head = ht_dec_g(genBits, hashTable[h]);
         bool take;
         if (MODE == 0)
             take = all || (head & SQZ_HT_LIVE);
@@ -447,7 +453,7 @@ SQ_DEVFN void dubt_insert_range(MatchState& ms, u32 from, u32 to) {
         else
             take = !(head & SQZ_HT_LIVE);
         if (!take) continue;
-        hashTable[h] = ht_enc(ms, idx | (head & ~SQZ_HT_IDX));
+        hashTable[h] = ht_enc_g(genBits, idx | (head & ~SQZ_HT_IDX));
         bt[2 * (idx & btMask)] = head & SQZ_HT_IDX;
         bt[2 * (idx & btMask) + 1] = SQZ_DUBT_UNSORTED;
     }
