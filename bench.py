@@ -190,47 +190,35 @@ def main():
             # ... and on every host core at once, as the reference's Rayon pool would run it (one chunk per
             # task: hash + compress; the ctypes calls release the GIL).  Each thread works through its own
             # 32 chunks of the workload (copied from HBM before the clock starts) until the time is up.
-            import threading
-            T = max(1, min(os.cpu_count() or 1, a.cpu_threads if a.cpu_threads > 0 else 1 << 30))
-            per = 32
-            pool_n = min(n, T * per)
+            import ctypes
+            try:    # CPUs this process may really use: affinity mask, and the cgroup's CPU quota if there is one
+                T = len(os.sched_getaffinity(0))
+            except (AttributeError, OSError):
+                T = os.cpu_count() or 1
+            try:
+                q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+                if q != "max":
+                    T = max(1, min(T, int(int(q) / int(per))))
+            except (OSError, ValueError):
+                pass
+            if a.cpu_threads > 0:
+                T = a.cpu_threads
+            per_thread = 32
+            pool_n = min(n, T * per_thread)
             host = data[:pool_n * L].cpu().numpy()
-            chunks_h = [host[i * L:(i + 1) * L].tobytes() for i in range(pool_n)]
-            del host
-            counts = [0] * T
-            stop_at = [0.0]
-            go = threading.Event()
-
-            def worker(t):
-                import ctypes
-                mine = chunks_h[t::T] or chunks_h[:1]
-                cap = o.compress_bound(L) + 64
-                dst = ctypes.create_string_buffer(cap)   # per-thread buffers: nothing but the two C calls
-                hb = ctypes.create_string_buffer(16)      # (which release the GIL) inside the timed loop
-                go.wait()
-                k = 0
-                while time.perf_counter() < stop_at[0]:
-                    c = mine[k % len(mine)]
-                    o.lib.sqo_hash_chunk(c, L, hb)
-                    assert o.lib.sqo_compress_chunk(c, L, dst, cap) > 0
-                    k += 1
-                counts[t] = k
-
-            th = [threading.Thread(target=worker, args=(t,)) for t in range(T)]
-            for x in th:
-                x.start()
+            o.lib.sqo_bench_insert_threads.restype = ctypes.c_uint64
+            o.lib.sqo_bench_insert_threads.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_size_t, ctypes.c_uint, ctypes.c_double]
             par_s = max(2.0, a.cpu_seconds * 0.75)
             tp0 = time.perf_counter()
-            stop_at[0] = tp0 + par_s
-            go.set()
-            for x in th:
-                x.join()
+            total = int(o.lib.sqo_bench_insert_threads(host.ctypes.data, pool_n, L, T, par_s))
             par_dt = time.perf_counter() - tp0
-            par = sum(counts) * L / 2**20 / par_dt
+            del host
+            par = total * L / 2**20 / par_dt
+            counts = [total]
             cpu = {"value": par, "unit": "MiB/s", "cores": T, "kind": "port",
-                   "sample": f"{sum(counts)} chunk compressions in {par_dt:.1f} s on {T} threads (each thread cycles through "
-                             f"its own 32 chunks of the same workload: XXH3-128 + zstd-12 per chunk through the oracle, "
-                             f"one chunk per task like the reference's Rayon pool); single thread through the oracle's "
+                   "sample": f"{sum(counts)} chunk compressions in {par_dt:.1f} s on {T} pthreads (oracle/bench_threads.c: each thread cycles "
+                             f"through its own 32 chunks of the same workload, XXH3-128 + zstd-12 per chunk, one chunk per task "
+                             f"like the reference's Rayon pool; T = CPUs this process may use); single thread through the oracle's "
                              f"ChunkStore::insert on the first {done} chunks: {single:.0f} MiB/s; host has "
                              f"{os.cpu_count()} logical CPUs"}
         out = {"metric": "pack throughput MiB/s", "value": value, "unit": "MiB/s", "n_gpus": world,

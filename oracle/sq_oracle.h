@@ -84,6 +84,9 @@ typedef struct {
 size_t sqo_pack_archive(const sqo_file* files, uint32_t nfiles, uint64_t timestamp, uint8_t** out);
 void sqo_free(void* p);
 
+/* bench.py cpu_baseline: `threads` pthreads hash + compress chunks of `data` for `seconds` (bench_threads.c) */
+uint64_t sqo_bench_insert_threads(const uint8_t* data, size_t n_chunks, size_t chunk_len, unsigned threads, double seconds);
+
 #ifdef __cplusplus
 }
 #endif
