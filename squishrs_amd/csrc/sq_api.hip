@@ -523,7 +523,7 @@ static int compress_async(sq_ctx* c, const u8* d_data, const u64* h_off, const u
         fprintf(stderr, "\n");
     }
     {   // profiling build: sum the per-wave phase timers (100 MHz ticks) and print them
-        std::vector<unsigned long long> tot(33, 0), one(71), worst(71, 0);
+        std::vector<unsigned long long> tot(33, 0), one(71), worst(71, 0), worst1(71, 0);
         std::vector<std::pair<unsigned long long, unsigned long long>> longest; // (ticks, pass<<32 | chunk) per wave
         std::vector<unsigned long long> fin;                                    // when each wave finished its last chunk
         for (u32 w = 0; w < waves; w++) {
@@ -531,15 +531,22 @@ static int compress_async(sq_ctx* c, const u8* d_data, const u64* h_off, const u
             for (int k = 0; k < 33; k++)
                 if (k < 29 || k > 31) tot[k] += one[k];
             if (one[29] > worst[29]) worst = one;
+            if ((one[30] >> 32) == 1 && one[29] > worst1[29]) worst1 = one;
             longest.push_back({one[29], one[30]});
             fin.push_back(one[31]);
         }
         std::sort(longest.begin(), longest.end());
         std::sort(fin.begin(), fin.end());
         fprintf(stderr, "[squish_gpu prof] longest chunk per wave, ms (pass:chunk):");
-        for (size_t k = 0; k < 8 && k < longest.size(); k++) {
+        for (size_t k = 0; k < 16 && k < longest.size(); k++) {
             auto const& e = longest[longest.size() - 1 - k];
-            fprintf(stderr, " %.3f(%u:%u)", (double)e.first / 1e5, (unsigned)(e.second >> 32), (unsigned)e.second);
+            fprintf(stderr, " %.3f(%u:%u", (double)e.first / 1e5, (unsigned)(e.second >> 32), (unsigned)e.second);
+            if (fast) { // where stage 1's certificates ended (positions; 2 = chunk start, 131074 = block 1)
+                u32 ce[2] = {0, 0};
+                (void)hipMemcpy(ce, (u32*)c->b_cert.p + 2 * (size_t)(u32)e.second, 8, hipMemcpyDeviceToHost);
+                fprintf(stderr, " cert %u/%u", ce[0], ce[1] & 0x7FFFFFFFu);
+            }
+            fprintf(stderr, ")");
         }
         fprintf(stderr, "; median %.3f\n", (double)longest[longest.size() / 2].first / 1e5);
         fprintf(stderr, "[squish_gpu prof] wave finish times ms: min %.3f p10 %.3f median %.3f p90 %.3f p99 %.3f max %.3f\n",
@@ -549,15 +556,18 @@ static int compress_async(sq_ctx* c, const u8* d_data, const u64* h_off, const u
                                      "entropy", "copies", "presplit+filterinit", "epoch_insert", "epoch_predicate", "epoch_rollback",
                                      "ins_phase1", "ins_phase23", "ins_tail", "bloom_rebuild",
                                      "#tail_iters", "#bloom_overflow", "#superbatches", "#candidates", "#survivors", "#nLive_sum", "#repairs_x1000+eager_x1e6", "#exact_finds",
-                                     "cert_predict", "cert_build", "cert_scan_p1", "cert_scan_p2", "cert_blockwalk", "-", "-", "-", "chunks+1"};
+                                     "cert_predict", "tail_certify", "#tail_certs", "cert_scan_p2", "cert_blockwalk", "-", "-", "-", "chunks+1"};
         static const char* nmL[29] = {"frame_total", "table_clear", "dubt_update", "dubt_find", "row_update", "row_find",
                                       "entropy", "copies", "presplit+filterinit", "epoch_insert", "epoch_predicate", "epoch_rollback",
                                       "ins_phase1", "ins_phase23", "ins_tail", "bloom_rebuild",
                                       "#tail_iters", "#bloom_overflow", "#superbatches", "#candidates", "#survivors", "#nLive_sum", "#repairs_x1000+eager_x1e6", "#exact_finds",
-                                      "cert_predict", "cert_build", "cert_scan_p1", "cert_scan_p2", "cert_blockwalk"};
-        fprintf(stderr, "[squish_gpu prof] the longest chunk (%u:%u), ms:", (unsigned)(worst[30] >> 32), (unsigned)worst[30]);
-        for (int k = 0; k < 29; k++) fprintf(stderr, " %s=%.3f", nmL[k], (k >= 16 && k < 24) ? (double)worst[42 + k] : (double)worst[42 + k] / 1e5);
-        fprintf(stderr, "\n");
+                                      "cert_predict", "tail_certify", "#tail_certs", "cert_scan_p2", "cert_blockwalk"};
+        for (int which = 0; which < 2; which++) {
+            auto const& wv = which ? worst1 : worst;
+            fprintf(stderr, "[squish_gpu prof] the longest chunk%s (%u:%u), ms:", which ? " of the second list" : "", (unsigned)(wv[30] >> 32), (unsigned)wv[30]);
+            for (int k = 0; k < 29; k++) fprintf(stderr, " %s=%.3f", nmL[k], (k >= 16 && k < 24) ? (double)wv[42 + k] : (double)wv[42 + k] / 1e5);
+            fprintf(stderr, "\n");
+        }
         fprintf(stderr, "[squish_gpu prof] waves=%u kernel=%.2f ms; per-wave mean ms:", waves, c->last.compress_ms);
         for (int k = 0; k < 33; k++)
             if (nm[k][0] != '-') fprintf(stderr, " %s=%.3f", nm[k], (k >= 16 && k < 24) || k == 32 ? (double)tot[k] / waves : (double)tot[k] / waves / 1e5);

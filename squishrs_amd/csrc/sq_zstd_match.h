@@ -2230,7 +2230,11 @@ SQ_DEVFN u32 compressBlock_lazy(MatchState& ms, SeqStore& ss, u32* rep, const u8
             ms.tailSeqs = ss.nseq;        // ... and stored another sequence
             ms.tailBlkTried = 1;
             if (lastOrCovered) {
-                if (tail_certify(ms, (u32)(ip - base), (u32)(anchor - base), offset_1, (u32)(ilimit - base))) {
+                PROF_T0(t_tailc);
+                bool const tailOk = tail_certify(ms, (u32)(ip - base), (u32)(anchor - base), offset_1, (u32)(ilimit - base));
+                PROF_ADD(25, t_tailc);
+                PROF_CNT(26, 100000); // count of tail certificates, in the time slots' unit (1 "ms" = 1)
+                if (tailOk) {
                     SQ_TRACE(39, 1);
                     ip = ilimit; // every remaining search of the block fails; nothing observes the tables any more
                     break;
