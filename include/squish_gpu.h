@@ -125,6 +125,16 @@ int sq_compress_batch_slots(sq_ctx* ctx, const uint8_t* d_data, const uint64_t* 
                             uint32_t* h_comp_len);
 uint64_t sq_slots_bound(const uint32_t* h_len, uint32_t n);
 
+/* Page-locked host buffers for the batch forms (hipHostMalloc).  The reference's packer reads every
+ * chunk into a heap buffer (BufReader + chunk_buf, src/archive/writer.rs:233-246) and hands the frames on
+ * as Vec<u8> (chunk.rs:60-64); a host driver of this library reads into / writes from buffers it gets
+ * here instead, so that the H2D / D2H copies of sq_pack_batch run at DMA speed.  sq_pack_batch copies a
+ * host batch with ONE transfer when the chunks lie back to back with their starts padded to 256 bytes
+ * (off[i+1] == off[i] + ((len[i] + 255) & ~255)).  Returns NULL when no device is present or the
+ * allocation fails (callers may fall back to ordinary memory). */
+void* sq_host_alloc(size_t bytes);
+void sq_host_free(void* p);
+
 /* HBM read-bandwidth calibration (a trivial 16 B/lane streaming read over d_buf): returns the
  * kernel time in ms through *ms.  bench.py reports it beside the 8 TB/s nominal peak. */
 int sq_calibrate_read_bw(sq_ctx* ctx, const uint8_t* d_buf, uint64_t nbytes, float* ms);

@@ -19,6 +19,7 @@ EXPORTS = [
     "sq_ctx_set_stream", "sq_ctx_synchronize", "sq_hash_chunk", "sq_compress_chunk",
     "sq_pack_batch", "sq_unique_count", "sq_hash_batch", "sq_dedup_global", "sq_compress_batch",
     "sq_calibrate_read_bw", "sq_last_timings", "sq_dedup_reset", "sq_compress_batch_slots", "sq_slots_bound",
+    "sq_host_alloc", "sq_host_free",
 ]
 
 

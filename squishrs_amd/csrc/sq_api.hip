@@ -697,9 +697,14 @@ int sq_pack_batch(sq_ctx* c, const uint8_t* data, const uint64_t* off, const uin
         if ((r = c->b_hashes.ensure((size_t)n * 16))) return r;
         if ((r = c->b_isnew.ensure(n))) return r;
         if ((r = c->b_stage_out.ensure(comp_cap))) return r;
-        for (u32 i = 0; i < n; i++)
-            HIPCHK(hipMemcpyAsync((u8*)c->b_stage_in.p + off2[i], data + off[i], len[i],
-                                  hipMemcpyHostToDevice, c->stream));
+        bool span = true; // the host batch already has the staging layout: one transfer
+        for (u32 i = 0; i < n && span; i++) span = (off[i] - off[0]) == off2[i];
+        if (span)
+            HIPCHK(hipMemcpyAsync(c->b_stage_in.p, data + off[0], off2[n - 1] + len[n - 1], hipMemcpyHostToDevice, c->stream));
+        else
+            for (u32 i = 0; i < n; i++)
+                HIPCHK(hipMemcpyAsync((u8*)c->b_stage_in.p + off2[i], data + off[i], len[i],
+                                      hipMemcpyHostToDevice, c->stream));
         d_data = (const u8*)c->b_stage_in.p;
         d_hashes = (u8*)c->b_hashes.p;
         d_isnew = (u8*)c->b_isnew.p;
@@ -723,6 +728,18 @@ int sq_pack_batch(sq_ctx* c, const uint8_t* data, const uint64_t* off, const uin
     }
     return SQ_OK;
 #endif
+}
+
+void* sq_host_alloc(size_t bytes) {
+    void* p = nullptr;
+    if (bytes == 0 || hipHostMalloc(&p, bytes, hipHostMallocDefault) != hipSuccess) {
+        (void)hipGetLastError();
+        return nullptr;
+    }
+    return p;
+}
+void sq_host_free(void* p) {
+    if (p) (void)hipHostFree(p);
 }
 
 // ---- stateless convenience forms --------------------------------------------------------------

@@ -100,6 +100,11 @@ static std::vector<std::string> walk_dir(const std::string& root) {
 static void put_u64(std::string& b, uint64_t v) { b.append((const char*)&v, 8); } // LE host
 static void put_u32(std::string& b, uint32_t v) { b.append((const char*)&v, 4); }
 
+static double now_s() {
+    struct timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
+}
 static void check(int rc, const char* what) {
     if (rc != SQ_OK) {
         if (rc == SQ_E_COMPRESS) throw AppError{"Compression error"}; // errors.rs:25-26
@@ -152,27 +157,57 @@ static uint64_t pack(const std::string& input, const std::string& output, int de
     }
     cfg.dedup_capacity = total_chunks + 1024;
     sq_ctx* ctx = nullptr;
+    double const t_ctx0 = now_s();
     check(sq_ctx_create(&cfg, &ctx), "sq_ctx_create");
+    double t_ctx = now_s() - t_ctx0, t_read = 0, t_gpu = 0, t_write = 0; // SQUISH_TIMING=1 prints them
 
     std::vector<FileMeta> metas(files.size());
-    // batch state
-    std::vector<uint8_t> data;
+    // batch state: page-locked buffers from the library (ordinary memory if it has none to give), chunks
+    // read straight into the input buffer at 256-byte aligned starts so that the batch goes up in ONE copy
+    struct HostBuf {
+        uint8_t* p = nullptr;
+        size_t cap = 0;
+        bool pinned = false;
+        void ensure(size_t n) {
+            if (n <= cap) return;
+            release();
+            p = (uint8_t*)sq_host_alloc(n);
+            pinned = p != nullptr;
+            if (!p) p = (uint8_t*)malloc(n);
+            if (!p) throw AppError{"I/O error: out of memory"};
+            cap = n;
+        }
+        void release() {
+            if (p) {
+                if (pinned) sq_host_free(p); else free(p);
+            }
+            p = nullptr;
+            cap = 0;
+        }
+        ~HostBuf() { release(); }
+    } data, comp;
+    size_t used = 0; // bytes of `data` in use (the next chunk starts at the next multiple of 256)
     std::vector<uint64_t> off;
     std::vector<uint32_t> len;
     std::vector<size_t> owner; // file index of each chunk in the batch
-    data.reserve((size_t)batch_bytes + SQ_CHUNK_SIZE);
+    std::vector<uint8_t> hashes, is_new;
+    std::vector<uint64_t> coff;
+    data.ensure((size_t)batch_bytes + 2 * (size_t)SQ_CHUNK_SIZE + 4096);
 
     auto flush = [&]() {
         uint32_t n = (uint32_t)len.size();
         if (!n) return;
-        std::vector<uint8_t> hashes((size_t)n * 16), is_new(n);
+        hashes.resize((size_t)n * 16);
+        is_new.resize(n);
         uint64_t cap = 0;
         for (uint32_t i = 0; i < n; i++) cap += sq_compress_bound(len[i]) + 64;
-        std::vector<uint8_t> comp(cap);
-        std::vector<uint64_t> coff((size_t)n + 1);
-        check(sq_pack_batch(ctx, data.data(), off.data(), len.data(), n, hashes.data(), is_new.data(), comp.data(),
-                            cap, coff.data()),
+        comp.ensure((size_t)cap);
+        coff.resize((size_t)n + 1);
+        double const tg0 = now_s();
+        check(sq_pack_batch(ctx, data.p, off.data(), len.data(), n, hashes.data(), is_new.data(), comp.p, cap, coff.data()),
               "sq_pack_batch");
+        double const tw0 = now_s();
+        t_gpu += tw0 - tg0;
         for (uint32_t i = 0; i < n; i++) {
             metas[owner[i]].hashes.emplace_back((const char*)&hashes[(size_t)16 * i], 16); // writer.rs:267
             if (is_new[i]) { // fsutil/writer.rs:21-36
@@ -180,10 +215,11 @@ static uint64_t pack(const std::string& input, const std::string& output, int de
                 fwrite(&hashes[(size_t)16 * i], 1, 16, out);
                 fwrite(&osz, 8, 1, out);
                 fwrite(&csz, 8, 1, out);
-                fwrite(&comp[coff[i]], 1, csz, out);
+                fwrite(comp.p + coff[i], 1, csz, out);
             }
         }
-        data.clear();
+        t_write += now_s() - tw0;
+        used = 0;
         off.clear();
         len.clear();
         owner.clear();
@@ -195,20 +231,23 @@ static uint64_t pack(const std::string& input, const std::string& output, int de
         FILE* in = fopen(files[f].c_str(), "rb");
         if (!in) throw AppError{std::string("I/O error: ") + strerror(errno)};
         for (;;) {
-            size_t pos = data.size();
-            data.resize(pos + SQ_CHUNK_SIZE);
-            size_t got = fread(&data[pos], 1, SQ_CHUNK_SIZE, in);
-            data.resize(pos + got);
+            size_t const pos = (used + 255) & ~(size_t)255;
+            double const tr0 = now_s();
+            size_t got = fread(data.p + pos, 1, SQ_CHUNK_SIZE, in);
+            t_read += now_s() - tr0;
             if (got == 0) break; // writer.rs:241-245
+            used = pos + got;
             off.push_back(pos);
             len.push_back((uint32_t)got);
             owner.push_back(f);
-            if (data.size() >= batch_bytes || len.size() >= 4096) flush();
+            if (used >= batch_bytes || len.size() >= 4096) flush();
             if (got < SQ_CHUNK_SIZE) break;
         }
         fclose(in);
     }
     flush();
+    if (getenv("SQUISH_TIMING"))
+        fprintf(stderr, "[squishrs timing] ctx_create %.3f s, file reads %.3f s, sq_pack_batch %.3f s, record writes %.3f s\n", t_ctx, t_read, t_gpu, t_write);
     {
         uint64_t count = sq_unique_count(ctx); // writer.rs:177-184
         fseek(out, 19, SEEK_SET);
