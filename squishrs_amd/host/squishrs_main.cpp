@@ -32,7 +32,9 @@
 #include <algorithm>
 #include <atomic>
 #include <filesystem>
+#include <condition_variable>
 #include <map>
+#include <mutex>
 #include <thread>
 #include <unordered_map>
 #include <string>
@@ -162,20 +164,29 @@ static uint64_t pack(const std::string& input, const std::string& output, int de
     double t_ctx = now_s() - t_ctx0, t_read = 0, t_gpu = 0, t_write = 0; // SQUISH_TIMING=1 prints them
 
     std::vector<FileMeta> metas(files.size());
-    // batch state: page-locked buffers from the library (ordinary memory if it has none to give), chunks
-    // read straight into the input buffer at 256-byte aligned starts so that the batch goes up in ONE copy
+    // Three batches rotate through three stages, each stage on its own thread and every batch through the
+    // stages in order (so the archive's bytes do not depend on the overlap):
+    //   reader : files -> chunks, read straight into the batch's page-locked input buffer at 256-byte
+    //            aligned starts (process_file's read loop, writer.rs:233-246); one H2D per batch then
+    //   gpu    : sq_pack_batch (this thread)
+    //   writer : chunk records + per-file hash lists (writer_thread, fsutil/writer.rs:17-39)
+    // The reference gets the same overlap from its Rayon workers and its writer thread.
     struct HostBuf {
         uint8_t* p = nullptr;
         size_t cap = 0;
         bool pinned = false;
+        double alloc_s = 0;
+        bool want_pinned = true;
         void ensure(size_t n) {
             if (n <= cap) return;
             release();
-            p = (uint8_t*)sq_host_alloc(n);
+            double const t0 = now_s();
+            p = want_pinned ? (uint8_t*)sq_host_alloc(n) : nullptr;
             pinned = p != nullptr;
             if (!p) p = (uint8_t*)malloc(n);
             if (!p) throw AppError{"I/O error: out of memory"};
             cap = n;
+            alloc_s += now_s() - t0;
         }
         void release() {
             if (p) {
@@ -185,69 +196,165 @@ static uint64_t pack(const std::string& input, const std::string& output, int de
             cap = 0;
         }
         ~HostBuf() { release(); }
-    } data, comp;
-    size_t used = 0; // bytes of `data` in use (the next chunk starts at the next multiple of 256)
-    std::vector<uint64_t> off;
-    std::vector<uint32_t> len;
-    std::vector<size_t> owner; // file index of each chunk in the batch
-    std::vector<uint8_t> hashes, is_new;
-    std::vector<uint64_t> coff;
-    data.ensure((size_t)batch_bytes + 2 * (size_t)SQ_CHUNK_SIZE + 4096);
-
-    auto flush = [&]() {
-        uint32_t n = (uint32_t)len.size();
-        if (!n) return;
-        hashes.resize((size_t)n * 16);
-        is_new.resize(n);
-        uint64_t cap = 0;
-        for (uint32_t i = 0; i < n; i++) cap += sq_compress_bound(len[i]) + 64;
-        comp.ensure((size_t)cap);
-        coff.resize((size_t)n + 1);
-        double const tg0 = now_s();
-        check(sq_pack_batch(ctx, data.p, off.data(), len.data(), n, hashes.data(), is_new.data(), comp.p, cap, coff.data()),
-              "sq_pack_batch");
-        double const tw0 = now_s();
-        t_gpu += tw0 - tg0;
-        for (uint32_t i = 0; i < n; i++) {
-            metas[owner[i]].hashes.emplace_back((const char*)&hashes[(size_t)16 * i], 16); // writer.rs:267
-            if (is_new[i]) { // fsutil/writer.rs:21-36
-                uint64_t osz = SQ_CHUNK_SIZE /* chunk_buf.len(), writer.rs:255 */, csz = coff[i + 1] - coff[i];
-                fwrite(&hashes[(size_t)16 * i], 1, 16, out);
-                fwrite(&osz, 8, 1, out);
-                fwrite(&csz, 8, 1, out);
-                fwrite(comp.p + coff[i], 1, csz, out);
-            }
-        }
-        t_write += now_s() - tw0;
-        used = 0;
-        off.clear();
-        len.clear();
-        owner.clear();
+    };
+    struct Batch {
+        HostBuf data, comp;
+        size_t used = 0; // bytes of `data` in use (the next chunk starts at the next multiple of 256)
+        std::vector<uint64_t> off, coff;
+        std::vector<uint32_t> len;
+        std::vector<size_t> owner; // file index of each chunk
+        std::vector<uint8_t> hashes, is_new;
+        int state = 0; // 0 free (reader's), 1 filled (gpu's), 2 packed (writer's)
+        bool last = false;
+    };
+    uint64_t total_bytes = 0;
+    for (uint64_t z : sizes) total_bytes += z;
+    // batch size: the configured one, but no larger than a third of the input (small inputs should not pay
+    // for page-locking gigabytes they never fill)
+    uint64_t const eff_batch = std::max<uint64_t>(std::min<uint64_t>(batch_bytes, total_bytes / 3 + SQ_CHUNK_SIZE), 8u << 20);
+    int const NB = 3;
+    Batch bt[3];
+    {   // Page-locking costs ~0.2 s per GiB here and only pays when the GPU stage (two PCIe crossings) is the
+        // slowest of the three, i.e. on large inputs; SQUISH_PINNED=0/1 overrides.
+        bool pin = total_bytes >= (16ull << 30);
+        if (const char* e = getenv("SQUISH_PINNED")) pin = atoi(e) != 0;
+        for (auto& b : bt) b.data.want_pinned = b.comp.want_pinned = pin;
+    }
+    std::mutex mu;
+    std::condition_variable cv;
+    std::string err; // first failure of any stage
+    auto wait_state = [&](Batch& b, int want) {
+        std::unique_lock<std::mutex> lk(mu);
+        cv.wait(lk, [&] { return b.state == want || !err.empty(); });
+        return err.empty();
+    };
+    auto set_state = [&](Batch& b, int st) {
+        { std::lock_guard<std::mutex> lk(mu); b.state = st; }
+        cv.notify_all();
+    };
+    auto fail = [&](const std::string& m) {
+        { std::lock_guard<std::mutex> lk(mu); if (err.empty()) err = m; }
+        cv.notify_all();
     };
 
-    for (size_t f = 0; f < files.size(); f++) { // writer.rs:229-271, files in slice order
+    std::thread reader([&] {
+        try {
+            int k = 0;
+            if (!wait_state(bt[k], 0)) return;
+            bt[k].data.ensure((size_t)eff_batch + 2 * (size_t)SQ_CHUNK_SIZE + 4096);
+            auto hand_over = [&](bool last) -> bool {
+                bt[k].last = last;
+                set_state(bt[k], 1);
+                if (last) return true;
+                k = (k + 1) % NB;
+                if (!wait_state(bt[k], 0)) return false;
+                bt[k].data.ensure((size_t)eff_batch + 2 * (size_t)SQ_CHUNK_SIZE + 4096);
+                return true;
+            };
+            for (size_t f = 0; f < files.size(); f++) { // writer.rs:229-271, files in slice order
+                FILE* in = fopen(files[f].c_str(), "rb");
+                if (!in) throw AppError{std::string("I/O error: ") + strerror(errno)};
+                for (;;) {
+                    Batch& b = bt[k];
+                    size_t const pos = (b.used + 255) & ~(size_t)255;
+                    double const tr0 = now_s();
+                    size_t got = fread(b.data.p + pos, 1, SQ_CHUNK_SIZE, in);
+                    t_read += now_s() - tr0;
+                    if (got == 0) break; // writer.rs:241-245
+                    b.used = pos + got;
+                    b.off.push_back(pos);
+                    b.len.push_back((uint32_t)got);
+                    b.owner.push_back(f);
+                    if (b.used >= eff_batch || b.len.size() >= 4096) {
+                        if (!hand_over(false)) {
+                            fclose(in);
+                            return;
+                        }
+                    }
+                    if (got < SQ_CHUNK_SIZE) break;
+                }
+                fclose(in);
+            }
+            hand_over(true);
+        } catch (const AppError& e) {
+            fail(e.msg);
+        }
+    });
+
+    std::thread writer([&] {
+        try {
+            for (int k = 0;; k = (k + 1) % NB) {
+                Batch& b = bt[k];
+                if (!wait_state(b, 2)) return;
+                double const tw0 = now_s();
+                uint32_t const n = (uint32_t)b.len.size();
+                for (uint32_t i = 0; i < n; i++) {
+                    metas[b.owner[i]].hashes.emplace_back((const char*)&b.hashes[(size_t)16 * i], 16); // writer.rs:267
+                    if (b.is_new[i]) { // fsutil/writer.rs:21-36
+                        uint64_t osz = SQ_CHUNK_SIZE /* chunk_buf.len(), writer.rs:255 */, csz = b.coff[i + 1] - b.coff[i];
+                        fwrite(&b.hashes[(size_t)16 * i], 1, 16, out);
+                        fwrite(&osz, 8, 1, out);
+                        fwrite(&csz, 8, 1, out);
+                        fwrite(b.comp.p + b.coff[i], 1, csz, out);
+                    }
+                }
+                t_write += now_s() - tw0;
+                bool const last = b.last;
+                b.used = 0;
+                b.off.clear();
+                b.len.clear();
+                b.owner.clear();
+                b.last = false;
+                set_state(b, 0);
+                if (last) return;
+            }
+        } catch (const AppError& e) {
+            fail(e.msg);
+        }
+    });
+
+    try { // the gpu stage
+        for (int k = 0;; k = (k + 1) % NB) {
+            Batch& b = bt[k];
+            if (!wait_state(b, 1)) break;
+            uint32_t const n = (uint32_t)b.len.size();
+            if (n) {
+                b.hashes.resize((size_t)n * 16);
+                b.is_new.resize(n);
+                uint64_t cap = 0;
+                for (uint32_t i = 0; i < n; i++) cap += sq_compress_bound(b.len[i]) + 64;
+                b.comp.ensure((size_t)cap);
+                b.coff.resize((size_t)n + 1);
+                double const tg0 = now_s();
+                check(sq_pack_batch(ctx, b.data.p, b.off.data(), b.len.data(), n, b.hashes.data(), b.is_new.data(), b.comp.p,
+                                    cap, b.coff.data()),
+                      "sq_pack_batch");
+                t_gpu += now_s() - tg0;
+            }
+            bool const last = b.last;
+            set_state(b, 2);
+            if (last) break;
+        }
+    } catch (const AppError& e) {
+        fail(e.msg);
+    }
+    reader.join();
+    writer.join();
+    if (!err.empty()) {
+        fclose(out);
+        sq_ctx_destroy(ctx);
+        throw AppError{err};
+    }
+    for (size_t f = 0; f < files.size(); f++) {
         metas[f].rel = strip_prefix(files[f], input);
         metas[f].size = sizes[f];
-        FILE* in = fopen(files[f].c_str(), "rb");
-        if (!in) throw AppError{std::string("I/O error: ") + strerror(errno)};
-        for (;;) {
-            size_t const pos = (used + 255) & ~(size_t)255;
-            double const tr0 = now_s();
-            size_t got = fread(data.p + pos, 1, SQ_CHUNK_SIZE, in);
-            t_read += now_s() - tr0;
-            if (got == 0) break; // writer.rs:241-245
-            used = pos + got;
-            off.push_back(pos);
-            len.push_back((uint32_t)got);
-            owner.push_back(f);
-            if (used >= batch_bytes || len.size() >= 4096) flush();
-            if (got < SQ_CHUNK_SIZE) break;
-        }
-        fclose(in);
     }
-    flush();
     if (getenv("SQUISH_TIMING"))
-        fprintf(stderr, "[squishrs timing] ctx_create %.3f s, file reads %.3f s, sq_pack_batch %.3f s, record writes %.3f s\n", t_ctx, t_read, t_gpu, t_write);
+    {
+        double t_alloc = 0;
+        for (auto& b : bt) t_alloc += b.data.alloc_s + b.comp.alloc_s;
+        fprintf(stderr, "[squishrs timing] ctx_create %.3f s; overlapped stages: file reads %.3f s, sq_pack_batch %.3f s, record writes %.3f s; page-locked allocations %.3f s (inside the stages)\n", t_ctx, t_read, t_gpu, t_write, t_alloc);
+    }
     {
         uint64_t count = sq_unique_count(ctx); // writer.rs:177-184
         fseek(out, 19, SEEK_SET);

@@ -128,3 +128,11 @@ def test_pack_unpack_roundtrip(tmp_path):
         assert (out / rel).read_bytes() == data, rel
     n = sum(len(fs) for _, _, fs in os.walk(out))
     assert n == len(files)
+    # the driver's three stages (reader / GPU / writer threads) rotate three batches: with batches of a few
+    # chunks the rotation wraps many times, and the archive must not change by a byte (timestamp aside)
+    small = tmp_path / "small_batches.squish"
+    r = subprocess.run([CLI, "pack", str(tree), "-o", str(small)], capture_output=True, text=True, timeout=600,
+                       env=dict(os.environ, SQUISH_BATCH_BYTES="700000"))
+    assert r.returncode == 0, r.stderr
+    a, b = arch.read_bytes(), small.read_bytes()
+    assert len(a) == len(b) and a[:11] == b[:11] and a[19:] == b[19:]

@@ -16,6 +16,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CLI = os.path.join(ROOT, "squishrs_amd", "host", "squishrs")
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 fb = int(sys.argv[2]) if len(sys.argv) > 2 else 262144
+EXTRA = {"SQUISH_PINNED": os.environ["SQUISH_PINNED"]} if "SQUISH_PINNED" in os.environ else {}
 base = sys.argv[3] if len(sys.argv) > 3 else tempfile.mkdtemp(prefix="sqcli_", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
 tree = os.path.join(base, "in")
 os.makedirs(tree, exist_ok=True)
@@ -32,7 +33,7 @@ out = os.path.join(base, "out")
 
 def run(*a):
     t = time.perf_counter()
-    r = subprocess.run([CLI, *a], capture_output=True, text=True, env=dict(os.environ, SQUISH_TIMING="1"))
+    r = subprocess.run([CLI, *a], capture_output=True, text=True, env=dict(os.environ, SQUISH_TIMING="1", **EXTRA))
     assert r.returncode == 0, r.stderr
     if "timing]" in r.stderr:
         sys.stderr.write(r.stderr)
