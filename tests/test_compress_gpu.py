@@ -334,3 +334,39 @@ def test_stage1_stress_random_sizes_and_alignments(gpu_store, oracle):
     bad = [i for i, c in enumerate(chunks)
            if host[int(coff[i]):int(coff[i]) + int(clen[i])].tobytes() != oracle.compress_chunk(c)]
     assert not bad, [(i, len(chunks[i])) for i in bad[:10]]
+
+
+def test_two_contexts_in_flight(oracle):
+    """Two sq_ctx driven by two host threads at the same time (own streams, buffers, dedup sets): what a packer
+    does to hide the tail of one batch's compress stage under the next batch's hash and stage 1
+    (DESIGN.md section 6).  Every frame of both must still equal the oracle's."""
+    import threading
+    import squishrs_amd
+    chunks_a = [corpus.random_bytes(31, i, 262144) for i in range(40)] + [corpus.text_like(5, 90000), corpus.planted(3, 262144, 4)]
+    chunks_b = [corpus.random_bytes(32, i, 262144) for i in range(40)] + [corpus.mixed(6, 200000), corpus.planted(4, 262144, 7)]
+    out = {}
+
+    def run(tag, chunks):
+        st = squishrs_amd.ChunkStore(device=0, max_chunk=262144, dedup_capacity=1 << 12)
+        try:
+            res = None
+            for _ in range(3):
+                st.reset()
+                res = st.insert_batch(chunks)
+            out[tag] = res
+        except Exception as e:  # surfaced by the assertions below
+            out[tag] = e
+        finally:
+            st.close()
+
+    th = [threading.Thread(target=run, args=("a", chunks_a)), threading.Thread(target=run, args=("b", chunks_b))]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    for tag, chunks in (("a", chunks_a), ("b", chunks_b)):
+        res = out[tag]
+        assert not isinstance(res, Exception), res
+        for c, r in zip(chunks, res):
+            assert r.hash == oracle.hash_chunk(c)
+            assert r.compressed_data == oracle.compress_chunk(c)
