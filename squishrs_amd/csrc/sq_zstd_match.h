@@ -1961,6 +1961,10 @@ SQ_DEVFN void row_insert_range(MatchState& ms, u32 from, u32 to) {
         u32 const relRow = (hash >> 8) << 6;
         WvGroup const g = wv_group(relRow, active, g_lds.grp);
         u32 hb = 0;
+        // Table stores of the previous step / of the last search must have landed before these reads (a wave's
+        // load is not ordered behind its own older store).  Draining HERE, not right after the stores, lets the
+        // stores' latency overlap the chunk loads and the grouping above.
+        wv_mem_sync();
         if (active) {
             u8* const tagRow = ms.tagTable + relRow;
             u32* const row = ms.hashTable + relRow;
@@ -1974,7 +1978,6 @@ SQ_DEVFN void row_insert_range(MatchState& ms, u32 from, u32 to) {
         wv_fence();
         // heads are written after every lane has read its (old) head byte
         if (active && g.rank + 1 == g.gsize) sq_gwr8(ms.tagTable + relRow, row_pos_after(hb, g.gsize));
-        wv_mem_sync();
     }
 #else
     for (u32 idx = from; idx < to; idx++) {
@@ -2022,11 +2025,17 @@ SQ_DEVFN u32 row_find(MatchState& ms, const u8* const ip, const u8* const iLimit
     u32 const limitLen = (u32)(iLimit - ip);
 #if SQ_ON_DEVICE
     u32 const lane = wv_lane();
-    u32 const hb = gld8(tagRow);
+    // (earlier table stores -- this search's row_update, the previous search's insertion -- land first)
+    wv_mem_sync();
+    // the whole row in ONE round trip: lane l reads tag byte l and entry l; byte 0 is the head, and the row is
+    // then rotated to start at the head with two wave shuffles (no second, dependent trip for "head + lane")
+    u32 const tl = sq_tld8(tagRow + lane);
+    u32 const cl = sq_tld32(row + lane);
+    u32 const hb = wv_readlane(tl, 0);
     u32 const head = hb & 63;
     u32 const matchPos = (head + lane) & 63;
-    u32 const t = sq_tld8(tagRow + matchPos);
-    u32 const cand = sq_tld32(row + matchPos);
+    u32 const t = (u32)__shfl((int)tl, (int)matchPos, 64);
+    u32 const cand = (u32)__shfl((int)cl, (int)matchPos, 64);
     bool const hit = (t == tag) && (matchPos != 0);
     u64 const M = wv_ballot(hit);
     if (wv_ballot(hit && cand >= curr)) ms.fault = 1;
@@ -2046,7 +2055,7 @@ SQ_DEVFN u32 row_find(MatchState& ms, const u8* const ip, const u8* const iLimit
         }
         ms.nextToUpdate++;
     }
-    wv_mem_sync();
+    // (no drain here: nothing reads the tables before the next row_insert_range / row_find, which drain first)
     if (valid) {
         // one candidate per lane: full match length, then first-maximum selection
         u32 L = 0;
@@ -2054,6 +2063,15 @@ SQ_DEVFN u32 row_find(MatchState& ms, const u8* const ip, const u8* const iLimit
             const u8* const m = base + cand;
             u32 o = 0;
             bool done = false;
+            if (limitLen >= 32) { // the first 32 bytes of both sides in one round trip
+                sq_v4u const a0 = sq_grd128(ip), a1 = sq_grd128(ip + 16), b0 = sq_grd128(m), b1 = sq_grd128(m + 16);
+                u32 const x[8] = {a0.x ^ b0.x, a0.y ^ b0.y, a0.z ^ b0.z, a0.w ^ b0.w, a1.x ^ b1.x, a1.y ^ b1.y, a1.z ^ b1.z, a1.w ^ b1.w};
+                o = 32;
+#pragma unroll
+                for (int k = 7; k >= 0; k--)
+                    if (x[k]) o = 4 * (u32)k + ((u32)__builtin_ctz(x[k]) >> 3);
+                done = o < 32;
+            }
             while (!done && o + 8 <= limitLen) {
                 u64 x = sq_grd64(ip + o) ^ sq_grd64(m + o);
                 if (x) {
