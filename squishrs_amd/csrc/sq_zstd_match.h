@@ -1948,7 +1948,7 @@ SQ_DEV u32 row_pos_after(u32 hb, u32 k) {
 }
 
 // insert positions [from, to) into the row tables (ZSTD_row_update_internalImpl)
-SQ_DEVFN void row_insert_range(MatchState& ms, u32 from, u32 to) {
+SQ_DEV void row_insert_range(MatchState& ms, u32 from, u32 to) {
     const u8* const base = ms.base;
     u32 const hBits = ms.rowHashLog + 8;
 #if SQ_ON_DEVICE
@@ -2004,7 +2004,7 @@ SQ_DEV void row_update(MatchState& ms, u32 target) {
 }
 
 // ZSTD_RowFindBestMatch (noDict, mls 5, rowLog 6)
-SQ_DEVFN u32 row_find(MatchState& ms, const u8* const ip, const u8* const iLimit, u32* offsetPtr) {
+SQ_DEV u32 row_find(MatchState& ms, const u8* const ip, const u8* const iLimit, u32* offsetPtr) {
     const u8* const base = ms.base;
     u32 const curr = (u32)(ip - base);
     u32 const lowLimit = SQZ_WINDOW_START;
@@ -2149,7 +2149,7 @@ SQ_DEV u32 search_max(MatchState& ms, const u8* ip, const u8* iend, u32* offBase
 
 // ZSTD_compressBlock_lazy_generic (noDict, depth 2); returns last literals size
 template <int ROW>
-SQ_DEVFN u32 compressBlock_lazy(MatchState& ms, SeqStore& ss, u32* rep, const u8* src, u32 srcSize) {
+SQ_DEV u32 compressBlock_lazy_impl(MatchState& ms, SeqStore& ss, u32* rep, const u8* src, u32 srcSize) {
     const u8* const istart = src;
     const u8* ip = istart;
     const u8* anchor = istart;
@@ -2360,6 +2360,22 @@ SQ_DEVFN u32 compressBlock_lazy(MatchState& ms, SeqStore& ss, u32* rep, const u8
     rep[0] = offset_1 ? offset_1 : offsetSaved1;
     rep[1] = offset_2 ? offset_2 : offsetSaved2;
     return (u32)(iend - anchor);
+}
+
+// The row-hash variant (2 MiB chunks) works on a LOCAL copy of the finder's state: everything it calls is
+// inlined, so the copy lives in registers, where the out-of-line btlazy2 machinery needs `ms` in memory and
+// reaches it through flat loads (each one a full vmcnt/lgkmcnt drain in the middle of the parser's loop).
+template <int ROW>
+SQ_DEVFN u32 compressBlock_lazy(MatchState& ms, SeqStore& ss, u32* rep, const u8* src, u32 srcSize) {
+#if SQ_ON_DEVICE
+    if (ROW) {
+        MatchState lm = ms;
+        u32 const r = compressBlock_lazy_impl<ROW>(lm, ss, rep, src, srcSize);
+        ms = lm;
+        return r;
+    }
+#endif
+    return compressBlock_lazy_impl<ROW>(ms, ss, rep, src, srcSize);
 }
 
 } // namespace sqz
