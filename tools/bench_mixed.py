@@ -1,7 +1,7 @@
 """BASELINE configs[3] in small (experiment, not the contract bench): N Silesia-style mixed-entropy chunks of
 2 MiB (tools/corpus.py `mixed`, a different seed per chunk: text-like, records, runs, skewed and random regions)
 through hash -> dedup -> compress on one GPU; a sample of frames is compared with the oracle, which is also
-timed on one host thread.  usage: python tools/bench_mixed.py [chunks] [steps]"""
+timed on one host thread.  usage: python tools/bench_mixed.py [chunks] [steps] [chunk_bytes] [kind]"""
 import os
 import sys
 import time
@@ -20,9 +20,10 @@ from squishrs_amd.parallel import ShardedPacker
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 128
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 2
-L = 2 << 20
+L = int(sys.argv[3]) if len(sys.argv) > 3 else 2 << 20
+kind = sys.argv[4] if len(sys.argv) > 4 else "mixed"
 t0 = time.time()
-chunks = [corpus.mixed(1000 + i, L) for i in range(n)]
+chunks = [corpus.make(kind, 1000 + i, L) for i in range(n)]
 print(f"generated {n} chunks in {time.time() - t0:.1f} s", flush=True)
 data = torch.frombuffer(bytearray(b"".join(chunks)), dtype=torch.uint8).cuda()
 offs = np.arange(n, dtype=np.uint64) * np.uint64(L)
@@ -51,7 +52,7 @@ for i in (0, n // 2, n - 1):
     k += 1
 cpu_dt = (time.perf_counter() - tc) / k
 ratio = float(ln.astype(np.uint64).sum()) / (n * L)
-print(f"configs[3] sample: {n} x 2 MiB mixed chunks, ratio {ratio:.3f}: {dt * 1e3:.1f} ms per step = {n * L / 2**20 / dt:.0f} MiB/s "
+print(f"configs[3] sample: {n} x {L} B {kind} chunks, ratio {ratio:.3f}: {dt * 1e3:.1f} ms per step = {n * L / 2**20 / dt:.0f} MiB/s "
       f"(hash {t.hash_ms:.2f} ms, stage 2 {t.compress_ms:.1f} ms); oracle on one host thread: {L / 2**20 / cpu_dt:.1f} MiB/s; "
       f"3 sampled frames bit-exact", flush=True)
 st.close()
