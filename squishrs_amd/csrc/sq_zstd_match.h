@@ -2362,20 +2362,21 @@ SQ_DEV u32 compressBlock_lazy_impl(MatchState& ms, SeqStore& ss, u32* rep, const
     return (u32)(iend - anchor);
 }
 
-// The row-hash variant (2 MiB chunks) works on a LOCAL copy of the finder's state: everything it calls is
-// inlined, so the copy lives in registers, where the out-of-line btlazy2 machinery needs `ms` in memory and
-// reaches it through flat loads (each one a full vmcnt/lgkmcnt drain in the middle of the parser's loop).
+// The parser works on a LOCAL copy of the finder's state.  Through the caller's reference every field access
+// is a flat load (a full vmcnt/lgkmcnt drain in the middle of the parser's loop, since any global store might
+// alias it).  The row-hash variant (2 MiB chunks) inlines everything it calls, so its copy lives in registers;
+// the btlazy2 variant still hands the copy to its out-of-line helpers, but it is a private object now: hipcc
+// keeps its fields in registers between those calls (the tree walk of a search makes none).
 template <int ROW>
 SQ_DEVFN u32 compressBlock_lazy(MatchState& ms, SeqStore& ss, u32* rep, const u8* src, u32 srcSize) {
 #if SQ_ON_DEVICE
-    if (ROW) {
-        MatchState lm = ms;
-        u32 const r = compressBlock_lazy_impl<ROW>(lm, ss, rep, src, srcSize);
-        ms = lm;
-        return r;
-    }
-#endif
+    MatchState lm = ms;
+    u32 const r = compressBlock_lazy_impl<ROW>(lm, ss, rep, src, srcSize);
+    ms = lm;
+    return r;
+#else
     return compressBlock_lazy_impl<ROW>(ms, ss, rep, src, srcSize);
+#endif
 }
 
 } // namespace sqz
