@@ -128,7 +128,7 @@ struct MatchState {
 #define SQZ_SKIP_CAP 256u
 #define SQZ_MAX_REPAIRS 24u
 #define SQZ_BLOCKTAB_CAP 64u
-#define SQZ_TAIL_TRIES 4u // tail certificates per chunk (each later one first clears its 2 MiB table)
+#define SQZ_TAIL_TRIES 8u  // tail certificates per chunk (each later one first clears its 2 MiB table)
 #ifndef SQZ_EPOCH_AFTER_FAILS
 #define SQZ_EPOCH_AFTER_FAILS 16u // plain no-match searches in a row before speculative epochs start
 #endif
