@@ -133,3 +133,13 @@ def test_scheduled_position_arithmetic_matches_the_tables(sim, n):
     sim.sim_sched_mask_check.restype = ctypes.c_uint
     first = ctypes.c_uint(0)
     assert sim.sim_sched_mask_check(n, ctypes.byref(first)) == 0, first.value
+
+
+def test_sim_fuzz_planted_coincidences(sim):
+    """tools/fuzz_planted_sim.py: 60 random chunks with planted 3..20-byte coincidences at / beside searched
+    positions (hand-overs, tail certificates that fail or succeed, several per block) -- simulator vs oracle."""
+    import subprocess
+    import sys
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_planted_sim.py"), "11", "60"],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "bad 0" in r.stdout, r.stdout + r.stderr
