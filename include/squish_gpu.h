@@ -59,7 +59,11 @@ int sq_ctx_set_stream(sq_ctx* ctx, void* hip_stream);
 int sq_ctx_synchronize(sq_ctx* ctx);
 
 /* == hash_chunk (src/util/chunk.rs:46-49): out = xxh3_128(chunk).to_le_bytes().
- * Stateless convenience form (host pointers, runs one tiny launch on device 0). */
+ * Stateless convenience form (host pointers, runs one tiny launch on device 0).  Thread-safe: the
+ * reference calls hash_chunk / insert from up to 25 Rayon workers (src/util/chunk.rs:80,
+ * src/cmd/mod.rs:16); sq_hash_chunk and sq_compress_chunk share one internal context and are
+ * serialised by a mutex (safe from any thread, not concurrent -- use one sq_ctx per thread and
+ * the batch forms for throughput). */
 int sq_hash_chunk(const uint8_t* chunk, size_t len, uint8_t out[SQ_HASH_BYTES]);
 
 /* == ZSTD_compressBound: capacity that always suffices for one frame of n input bytes. */
@@ -75,8 +79,10 @@ int sq_compress_chunk(const uint8_t* chunk, size_t len, uint8_t* dst, size_t cap
  * this is the first occurrence of that hash in index order across all batches of this ctx
  * (Entry::Vacant), and only those chunks are compressed: frame i occupies
  * comp[comp_off[i] .. comp_off[i+1]) (empty for duplicates).  comp_cap bytes must be available at
- * comp; SQ_E_CAP if the frames do not fit (nothing is committed to the dedup set in that case).
- * data / hashes / is_new / comp: host or device (all on the same side).
+ * comp; SQ_E_CAP if the frames do not fit.  Whenever the call fails, nothing stays committed: the
+ * dedup set, sq_unique_count and the global chunk index are exactly as before the call, so the
+ * same batch can be retried (e.g. with a larger comp buffer) and reports the same is_new flags.
+ * data / hashes / is_new / comp: host or device, ALL on the same side (SQ_E_INVAL otherwise).
  * off, len (n entries each) and comp_off (n+1 entries): host. */
 int sq_pack_batch(sq_ctx* ctx, const uint8_t* data, const uint64_t* off, const uint32_t* len,
                   uint32_t n, uint8_t* hashes, uint8_t* is_new, uint8_t* comp, uint64_t comp_cap,

@@ -87,6 +87,12 @@ void sqo_free(void* p);
 /* bench.py cpu_baseline: `threads` pthreads hash + compress chunks of `data` for `seconds` (bench_threads.c) */
 uint64_t sqo_bench_insert_threads(const uint8_t* data, size_t n_chunks, size_t chunk_len, unsigned threads, double seconds);
 
+/* bench.py cpu_baseline: the reference's whole pack pipeline on host threads (pool over files, sharded dedup map
+ * with the lock held during compression, one writer thread); see bench_threads.c.  The caller measures wall time
+ * around the call (it includes draining the writer).  stats: chunks written, bytes written, duplicates, max backlog. */
+int sqo_bench_pipeline(const uint8_t* data, size_t n_chunks, size_t chunk_len, unsigned threads, double seconds,
+                       uint64_t stats[4]);
+
 #ifdef __cplusplus
 }
 #endif

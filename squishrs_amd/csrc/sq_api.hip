@@ -15,6 +15,7 @@
 #include <cstring>
 #include <ctime>
 #include <unistd.h>
+#include <mutex>
 #include <new>
 #include <vector>
 
@@ -455,8 +456,10 @@ static int compress_async(sq_ctx* c, const u8* d_data, const u64* h_off, const u
         HIPCHK(hipGetLastError());
     }
     HIPCHK(hipEventRecord(c->ev[5], c->stream));
+#ifdef SQ_PROF
     if (const char* wd = getenv("SQ_WATCHDOG_MS")) {
-        // bring-up aid: if the compressor does not finish in time, dump wave 0..3 progress markers
+        // bring-up aid of the PROFILING build only (libsquish_gpu_prof.so; the release library never terminates
+        // its host process): if the compressor does not finish in time, dump wave 0..3 progress markers
         const long limit_ms = atol(wd);
         long waited = 0;
         while (hipStreamQuery(c->stream) == hipErrorNotReady && waited < limit_ms) {
@@ -483,6 +486,7 @@ static int compress_async(sq_ctx* c, const u8* d_data, const u64* h_off, const u
             _exit(3);
         }
     }
+#endif
     if (in_place) {
         HIPCHK(hipMemcpyAsync(h_comp_len, c->b_frame_len.p, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));
         for (u32 i = 0; i < n; i++) h_comp_off[i] = slot_off[i];
@@ -679,7 +683,12 @@ int sq_pack_batch(sq_ctx* c, const uint8_t* data, const uint64_t* off, const uin
         comp_off[0] = 0;
         return SQ_OK;
     }
+    // all four data-plane pointers must live on the same side
     const bool dev = is_device_ptr(data);
+    if (is_device_ptr(hashes) != dev || is_device_ptr(is_new) != dev || is_device_ptr(comp) != dev) return SQ_E_INVAL;
+    // every argument check that can fail runs BEFORE anything is committed to the dedup set
+    for (u32 i = 0; i < n; i++)
+        if (len[i] > c->cfg.max_chunk) return SQ_E_INVAL;
     int r;
     const u8* d_data = data;
     u8 *d_hashes = hashes, *d_isnew = is_new, *d_comp = comp;
@@ -696,7 +705,7 @@ int sq_pack_batch(sq_ctx* c, const uint8_t* data, const uint64_t* off, const uin
         if ((r = c->b_stage_in.ensure(acc + 256))) return r;
         if ((r = c->b_hashes.ensure((size_t)n * 16))) return r;
         if ((r = c->b_isnew.ensure(n))) return r;
-        if ((r = c->b_stage_out.ensure(comp_cap))) return r;
+        if ((r = c->b_stage_out.ensure(comp_cap ? comp_cap : 16))) return r;
         bool span = true; // the host batch already has the staging layout: one transfer
         for (u32 i = 0; i < n && span; i++) span = (off[i] - off[0]) == off2[i];
         if (span)
@@ -713,11 +722,22 @@ int sq_pack_batch(sq_ctx* c, const uint8_t* data, const uint64_t* off, const uin
     }
     if ((r = upload_off_len(c, use_off, len, n))) return r;
     if ((r = launch_hash(c, d_data, n, d_hashes))) return r;
+    // The dedup commit is provisional until the frames are out: if the compress stage fails (SQ_E_CAP: the
+    // frames do not fit comp_cap; SQ_E_COMPRESS; an allocation), the set, its unique count and the global
+    // chunk index are put back, so the caller can retry the same batch (squish_gpu.h: "nothing is committed").
     const u64 seen_before = c->n_seen;
-    if ((r = dedup_async(c, d_hashes, n, 0, n, d_isnew))) return r;
+    HIPCHK(hipMemcpyAsync(c->d_unique + 1, c->d_unique, sizeof(unsigned long long), hipMemcpyDeviceToDevice, c->stream));
+    if ((r = dedup_async(c, d_hashes, n, 0, n, d_isnew))) return r; // (fails before touching the set)
     r = compress_async(c, d_data, use_off, len, n, d_isnew, d_comp, comp_cap, comp_off, nullptr);
-    (void)seen_before;
-    if (r) return r;
+    if (r) {
+        const u64 nslots = c->table_mask + 1;
+        hipLaunchKernelGGL(sqd::k_dedup_rollback, dim3((unsigned)std::min<u64>((nslots + 255) / 256, 4096)), dim3(256), 0,
+                           c->stream, c->d_table, nslots, seen_before);
+        (void)hipMemcpyAsync(c->d_unique, c->d_unique + 1, sizeof(unsigned long long), hipMemcpyDeviceToDevice, c->stream);
+        (void)hipStreamSynchronize(c->stream);
+        c->n_seen = seen_before;
+        return r;
+    }
     HIPCHK(hipEventElapsedTime(&c->last.hash_ms, c->ev[0], c->ev[1]));
     HIPCHK(hipEventElapsedTime(&c->last.dedup_ms, c->ev[2], c->ev[3]));
     if (!dev) {
@@ -743,7 +763,11 @@ void sq_host_free(void* p) {
 }
 
 // ---- stateless convenience forms --------------------------------------------------------------
+// The reference calls hash_chunk / insert from up to 25 Rayon workers (src/util/chunk.rs:80, cmd/mod.rs:16): the
+// convenience forms share ONE lazily created context (its staging buffers, stream and events), so they are
+// serialised by a mutex -- thread-safe, not concurrent.  Callers that want concurrency use one sq_ctx per thread.
 static sq_ctx* g_default_ctx = nullptr;
+static std::mutex g_default_mu;
 static int default_ctx(sq_ctx** out) {
     if (!g_default_ctx) {
         sq_config cfg;
@@ -760,6 +784,7 @@ static int default_ctx(sq_ctx** out) {
 
 int sq_hash_chunk(const uint8_t* chunk, size_t len, uint8_t out[SQ_HASH_BYTES]) {
     if ((!chunk && len) || !out || len > SQ_CHUNK_SIZE) return SQ_E_INVAL;
+    std::lock_guard<std::mutex> lk(g_default_mu);
     sq_ctx* c;
     int r = default_ctx(&c);
     if (r) return r;
@@ -780,6 +805,7 @@ int sq_compress_chunk(const uint8_t* chunk, size_t len, uint8_t* dst, size_t cap
     return SQ_E_COMPRESS;
 #else
     if ((!chunk && len) || !dst || !out_len || len > SQ_CHUNK_SIZE) return SQ_E_INVAL;
+    std::lock_guard<std::mutex> lk(g_default_mu);
     sq_ctx* c;
     int r = default_ctx(&c);
     if (r) return r;

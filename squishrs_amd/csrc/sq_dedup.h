@@ -75,6 +75,19 @@ k_dedup_resolve(const u64* __restrict__ keys, u64 g_first, u32 n, const u32* __r
     }
 }
 
+// Undo of one batch's k_dedup_insert (sq_pack_batch failing after the commit): empty every slot whose
+// representative index is >= g_first.  Entries of earlier batches were placed before any of these existed, so
+// their probe paths never run across the slots emptied here -- no tombstones are needed.
+__global__ void __launch_bounds__(256)
+k_dedup_rollback(u32* __restrict__ table, u64 nslots, u64 g_first) {
+    u64 i = (u64)blockIdx.x * blockDim.x + threadIdx.x;
+    const u64 stride = (u64)gridDim.x * blockDim.x;
+    for (; i < nslots; i += stride) {
+        const u32 v = table[i];
+        if (v != 0 && (u64)v - 1 >= g_first) table[i] = 0;
+    }
+}
+
 // Frames were written into per-chunk slots (slot_off[i], 16-byte aligned); pack them contiguously
 // in index order.  One wave per frame, 16 B per lane per step.
 __global__ void __launch_bounds__(256)

@@ -28,6 +28,12 @@ class ShardedPacker:
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        # Stream ordering.  The device stages run on the ctx's stream; the collective (and the torch.cat of its
+        # result) run on torch's current stream.  With more than one rank the ctx is therefore moved onto torch's
+        # current stream HERE, so hash -> all-gather -> dedup are ordered by the stream itself; a single rank
+        # has no collective between the stages and keeps whatever stream the ctx has.
+        if self.world > 1 and torch.cuda.is_available() and hasattr(stages, "set_stream"):
+            stages.set_stream(torch.cuda.current_stream().cuda_stream)
 
     def gather_hashes(self, hashes: torch.Tensor, n_local: int):
         """All-gather of the ranks' hash arrays (16 B x n_local, padded to the max count).

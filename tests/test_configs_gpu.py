@@ -1,0 +1,270 @@
+"""GPU parity at the shapes of BASELINE configs[2] and [3], the ABI contract of sq_pack_batch (failure leaves
+nothing committed; pointer sides; thread safety of the convenience forms, /root/reference/src/util/chunk.rs:80-100
+is called from up to 25 Rayon workers) and the single-wave default-context path on incompressible chunks.
+All through the C ABI (ctypes), checked against the CPU oracle."""
+import ctypes
+import threading
+
+import numpy as np
+import pytest
+
+import corpus
+
+pytestmark = pytest.mark.gpu
+
+
+def _first_occurrence(keys):
+    seen, out = set(), np.zeros(len(keys), dtype=np.uint8)
+    for i, k in enumerate(keys):
+        if k not in seen:
+            seen.add(k)
+            out[i] = 1
+    return out, len(seen)
+
+
+def test_corpus_kernel_matches_numpy_generator():
+    """tools/corpus_gen.hip is the device twin of corpus.random_bytes; gather_chunks makes exact duplicates."""
+    import torch
+    import corpus_gpu
+    L = 4096
+    d = corpus_gpu.random_chunks(9, 1000, 37, L)
+    host = d.cpu().numpy().reshape(37, L)
+    for i in (0, 1, 17, 36):
+        assert host[i].tobytes() == corpus.random_bytes(9, 1000 + i, L)
+    idx = torch.tensor([5, 5, 0, 36], dtype=torch.int64, device="cuda")
+    g = torch.empty(4 * L, dtype=torch.uint8, device="cuda")
+    corpus_gpu.gather_chunks(g, d, idx, L)
+    gh = g.cpu().numpy().reshape(4, L)
+    assert (gh[0] == host[5]).all() and (gh[1] == host[5]).all() and (gh[2] == host[0]).all() and (gh[3] == host[36]).all()
+
+
+def test_config2_half_duplicates_pack_batch_and_stages(oracle):
+    """BASELINE configs[2] in small: 2,400 x 256 KiB chunks, the second half exact duplicates of the first in a
+    seeded permutation (plus a few duplicates INSIDE the first half), through (a) sq_pack_batch on device pointers
+    and (b) the stage calls with select = is_new.  is_new against a first-occurrence model, unique count, every
+    new frame's payload, duplicates' frames empty, a spread sample of frames against the oracle."""
+    import torch
+    import corpus_gpu
+    import squishrs_amd
+    n, L = 2400, 262144
+    half = n // 2
+    rng = np.random.default_rng(2)
+    src = np.arange(n, dtype=np.int64)
+    src[half:] = rng.permutation(half)
+    src[100] = 7           # duplicates inside the first half too
+    src[101] = 7
+    src[half - 1] = 100    # base chunk 100's only copy in the first half sits at its end
+    base = corpus_gpu.random_chunks(2, 0, half, L)
+    data = torch.empty(n * L, dtype=torch.uint8, device="cuda")
+    corpus_gpu.gather_chunks(data, base, torch.from_numpy(src), L)
+    content = src          # which base content chunk i carries
+    exp_new, exp_unique = _first_occurrence([int(x) for x in content])
+    offs = np.arange(n, dtype=np.uint64) * np.uint64(L)
+    lens = np.full(n, L, dtype=np.uint32)
+    st = squishrs_amd.ChunkStore(device=0, max_chunk=L, dedup_capacity=1 << 14)
+    try:
+        hashes = torch.zeros(n * 16, dtype=torch.uint8, device="cuda")
+        is_new = torch.zeros(n, dtype=torch.uint8, device="cuda")
+        comp = torch.empty(exp_unique * (squishrs_amd.compress_bound(L) + 16), dtype=torch.uint8, device="cuda")
+        # (a) sq_pack_batch, two batches (state persists), device pointers
+        cut = 1000
+        co1 = st.pack_device(data[:cut * L], offs[:cut], lens[:cut], hashes[:cut * 16], is_new[:cut], comp)
+        used = int(co1[-1])
+        co2 = st.pack_device(data[cut * L:], offs[:n - cut], lens[cut:], hashes[cut * 16:], is_new[cut:], comp[used:])
+        got_new = is_new.cpu().numpy()
+        assert (got_new == exp_new).all(), np.nonzero(got_new != exp_new)[0][:10]
+        assert st.len() == exp_unique
+        sizes = np.concatenate([np.diff(co1.astype(np.int64)), np.diff(co2.astype(np.int64))])
+        assert ((sizes > 0) == (exp_new == 1)).all()
+        assert (sizes[exp_new == 1] <= 262159).all() and (sizes[exp_new == 1] >= 262000).all()
+        hh = hashes.cpu().numpy().reshape(n, 16)
+        starts = np.concatenate([co1[:-1].astype(np.int64), co2[:-1].astype(np.int64) + used])
+        host_base = base.cpu().numpy().reshape(half, L)
+        sample = sorted(set([0, 7, 100, 101, 999, 1000, 1001, half - 1, half, n - 1] + [int(x) for x in rng.integers(0, n, size=20)]))
+        for i in sample:
+            c = host_base[int(content[i])].tobytes()
+            assert hh[i].tobytes() == oracle.hash_chunk(c), i
+            if exp_new[i]:
+                f = comp[int(starts[i]):int(starts[i]) + int(sizes[i])].cpu().numpy().tobytes()
+                assert f == oracle.compress_chunk(c), i
+        # every raw-block frame carries its input (device-side, all new chunks)
+        newi = np.nonzero((exp_new == 1) & (sizes == 262159))[0]
+        assert len(newi) > 0.8 * exp_unique
+        st_t = torch.from_numpy(starts[newi]).cuda()
+        ar = torch.arange(131072, device="cuda")
+        for k0 in range(0, len(newi), 256):
+            s = st_t[k0:k0 + 256]
+            ids = torch.from_numpy(newi[k0:k0 + 256]).cuda()
+            blk0 = comp[(s[:, None] + 12 + ar[None, :]).reshape(-1)].view(len(s), -1)
+            blk1 = comp[(s[:, None] + 12 + 131072 + 3 + ar[None, :]).reshape(-1)].view(len(s), -1)
+            inp = data.view(n, L)[ids]
+            assert torch.equal(blk0, inp[:, :131072]) and torch.equal(blk1, inp[:, 131072:])
+        # (b) the stage calls with select = is_new on a fresh set: same flags, same frames
+        st.reset()
+        h2 = torch.zeros_like(hashes)
+        n2 = torch.zeros_like(is_new)
+        st.hash_device(data, offs, lens, h2)
+        st.dedup_device(h2, n, 0, n, n2)
+        assert torch.equal(h2, hashes) and torch.equal(n2, is_new) and st.len() == exp_unique
+        slots = torch.empty(st.slots_bound(lens), dtype=torch.uint8, device="cuda")
+        so, sl = st.compress_device_slots(data, offs, lens, n2, slots)
+        assert (sl.astype(np.int64) == sizes).all()
+        for i in sample:
+            if exp_new[i]:
+                a = slots[int(so[i]):int(so[i]) + int(sl[i])]
+                b = comp[int(starts[i]):int(starts[i]) + int(sizes[i])]
+                assert torch.equal(a, b), i
+    finally:
+        st.close()
+
+
+def test_config3_mixed_2m_chunks_full_machine(oracle):
+    """BASELINE configs[3] in small: 320 Silesia-style mixed-entropy chunks of 2 MiB (40 distinct contents x 8,
+    so a spread of waves sees each) + ragged tails of all three strategies in ONE batch through sq_pack_batch
+    semantics (hash -> dedup -> compress new).  Distinct contents against the oracle frame for frame; the copies
+    must be flagged duplicates."""
+    import torch
+    import squishrs_amd
+    distinct = [corpus.mixed(7000 + i, 2097152) for i in range(40)]
+    tails = [corpus.mixed(7100, 1234567), corpus.text_like(7101, 300001), corpus.records(7102, 200000),
+             corpus.text_like(7103, 15000), corpus.make("runs", 7104, 2097152), corpus.skewed(7105, 524288), b"tail"]
+    chunks = distinct + tails + distinct * 7
+    st = squishrs_amd.ChunkStore(device=0, dedup_capacity=1 << 12)
+    try:
+        res = st.insert_batch(chunks)
+        assert st.len() == len(distinct) + len(tails)
+        ref = []
+        for i, (c, r) in enumerate(zip(chunks, res)):
+            if i < len(distinct) + len(tails):
+                assert r.hash == oracle.hash_chunk(c), i
+                ref.append(oracle.compress_chunk(c))
+                assert r.compressed_data == ref[i], (i, len(c))
+            else:
+                assert r.compressed_data is None and r.hash == res[(i - len(tails)) % len(distinct)].hash
+        # all 320 copies through the compress stage alone (no dedup): 320 waves busy with a 2 MiB chunk each
+        from test_compress_gpu import _batch_compress
+        frames = _batch_compress(st, distinct * 8)
+        for i, f in enumerate(frames):
+            assert f == ref[i % len(distinct)], i
+    finally:
+        st.close()
+
+
+def test_compress_chunk_default_ctx_single_wave_incompressible(oracle):
+    """The stateless form runs ONE compressor wave (and one or two stage-1 waves) on its private context.  Round 1
+    saw this path hang during development on a random 70,000-byte chunk (DESIGN.md "Incidents"); pin it: random
+    chunks of the btlazy2 size class, a planted one, and the 16 KiB boundary, against the oracle."""
+    import squishrs_amd
+    cases = [corpus.random_bytes(41, 0, 70000), corpus.random_bytes(41, 1, 262144), corpus.planted(5, 262144, 0),
+             corpus.planted(6, 70000, 3), corpus.random_bytes(41, 2, 16385), corpus.random_bytes(41, 3, 16384),
+             corpus.random_bytes(41, 4, 131073)]
+    for c in cases:
+        assert squishrs_amd.compress_chunk(c) == oracle.compress_chunk(c), len(c)
+        assert squishrs_amd.hash_chunk(c) == oracle.hash_chunk(c)
+
+
+def test_convenience_forms_from_many_threads(oracle):
+    """hash_chunk / compress(.,12) are called from up to 25 Rayon workers in the reference (chunk.rs:80,
+    cmd/mod.rs:16): sq_hash_chunk / sq_compress_chunk share one context behind a mutex."""
+    import squishrs_amd
+    work = [(corpus.random_bytes(51, i, 3000 + 977 * i), corpus.text_like(60 + i, 20000 + 1000 * i)) for i in range(12)]
+    want = [(oracle.hash_chunk(a), oracle.compress_chunk(b)) for a, b in work]
+    errs = []
+
+    def run(tid):
+        try:
+            for rep in range(3):
+                for k in range(tid, len(work), 4):
+                    a, b = work[k]
+                    if squishrs_amd.hash_chunk(a) != want[k][0] or squishrs_amd.compress_chunk(b) != want[k][1]:
+                        errs.append((tid, k))
+        except Exception as e:  # noqa: BLE001
+            errs.append((tid, repr(e)))
+
+    th = [threading.Thread(target=run, args=(t,)) for t in range(4)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert not errs, errs[:5]
+
+
+def test_pack_batch_failure_commits_nothing_then_retry(oracle):
+    """squish_gpu.h: when sq_pack_batch fails (here SQ_E_CAP: frames do not fit comp_cap) the dedup set, the unique
+    count and the chunk index are as before the call; the same batch retried with enough room reports the flags a
+    fresh context reports, and an earlier batch's entries survive the roll-back."""
+    import torch
+    import squishrs_amd
+    from squishrs_amd import _lib
+    first = [corpus.random_bytes(61, i, 50000) for i in range(5)]
+    batch = [corpus.random_bytes(61, 2, 50000), corpus.text_like(70, 80000), corpus.random_bytes(62, 0, 262144),
+             corpus.text_like(70, 80000), corpus.random_bytes(62, 1, 100000), corpus.random_bytes(61, 4, 50000)]
+    st = squishrs_amd.ChunkStore(device=0, dedup_capacity=1 << 12)
+    try:
+        r0 = st.insert_batch(first)
+        assert all(r.compressed_data is not None for r in r0) and st.len() == 5
+        lens = np.array([len(c) for c in batch], dtype=np.uint32)
+        offs = np.zeros(len(batch), dtype=np.uint64)
+        offs[1:] = np.cumsum(lens.astype(np.uint64))[:-1]
+        data = np.frombuffer(b"".join(batch), dtype=np.uint8)
+        hashes = np.zeros(len(batch) * 16, dtype=np.uint8)
+        is_new = np.zeros(len(batch), dtype=np.uint8)
+        small = np.zeros(100000, dtype=np.uint8)           # far too small for the three new frames
+        coff = np.zeros(len(batch) + 1, dtype=np.uint64)
+        rc = st._L.sq_pack_batch(st._h, data.ctypes.data, offs.ctypes.data, lens.ctypes.data, len(batch),
+                                 hashes.ctypes.data, is_new.ctypes.data, small.ctypes.data, small.size, coff.ctypes.data)
+        assert rc == _lib.SQ_E_CAP
+        assert st.len() == 5                                # nothing committed
+        res = st.insert_batch(batch)                        # the retry
+        flags = [r.compressed_data is not None for r in res]
+        assert flags == [False, True, True, False, True, False]
+        assert st.len() == 8
+        for c, r in zip(batch, res):
+            assert r.hash == oracle.hash_chunk(c)
+            if r.compressed_data is not None:
+                assert r.compressed_data == oracle.compress_chunk(c)
+        # the same on device pointers
+        st.reset()
+        d = torch.from_numpy(np.concatenate([data, np.zeros(64, dtype=np.uint8)])).cuda()
+        dh = torch.zeros(len(batch) * 16, dtype=torch.uint8, device="cuda")
+        dn = torch.zeros(len(batch), dtype=torch.uint8, device="cuda")
+        dc = torch.zeros(600000, dtype=torch.uint8, device="cuda")
+        with pytest.raises(squishrs_amd.SquishError) as ei:
+            st.pack_device(d, offs, lens, dh, dn, dc[:1000])
+        assert ei.value.code == _lib.SQ_E_CAP and st.len() == 0
+        co = st.pack_device(d, offs, lens, dh, dn, dc)
+        assert dn.cpu().numpy().tolist() == [1, 1, 1, 0, 1, 1] and st.len() == 5
+        assert int(co[-1]) == sum(len(oracle.compress_chunk(batch[i])) for i in (0, 1, 2, 4, 5))
+    finally:
+        st.close()
+
+
+def test_pack_batch_rejects_mixed_pointer_sides():
+    import torch
+    import squishrs_amd
+    from squishrs_amd import _lib
+    st = squishrs_amd.ChunkStore(device=0, dedup_capacity=1 << 10)
+    try:
+        c = corpus.text_like(1, 5000)
+        data = np.frombuffer(c, dtype=np.uint8)
+        d = torch.from_numpy(data.copy()).cuda()
+        offs = np.zeros(1, dtype=np.uint64)
+        lens = np.array([len(c)], dtype=np.uint32)
+        hashes_h = np.zeros(16, dtype=np.uint8)
+        new_d = torch.zeros(1, dtype=torch.uint8, device="cuda")
+        comp_d = torch.zeros(8192, dtype=torch.uint8, device="cuda")
+        coff = np.zeros(2, dtype=np.uint64)
+        rc = st._L.sq_pack_batch(st._h, d.data_ptr(), offs.ctypes.data, lens.ctypes.data, 1, hashes_h.ctypes.data,
+                                 new_d.data_ptr(), comp_d.data_ptr(), comp_d.numel(), coff.ctypes.data)
+        assert rc == _lib.SQ_E_INVAL and st.len() == 0
+        rc = st._L.sq_pack_batch(st._h, data.ctypes.data, offs.ctypes.data, lens.ctypes.data, 1, hashes_h.ctypes.data,
+                                 new_d.data_ptr(), comp_d.data_ptr(), comp_d.numel(), coff.ctypes.data)
+        assert rc == _lib.SQ_E_INVAL and st.len() == 0
+        # a chunk longer than the context's max_chunk is refused before anything is committed
+        st2 = squishrs_amd.ChunkStore(device=0, max_chunk=4096, dedup_capacity=1 << 10)
+        with pytest.raises(squishrs_amd.SquishError):
+            st2.insert_batch([c])
+        assert st2.len() == 0
+        st2.close()
+    finally:
+        st.close()

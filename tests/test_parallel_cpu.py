@@ -147,3 +147,72 @@ def test_two_rank_global_first_occurrence():
         off = r[4]
         for j, flag in enumerate(r[2]):
             assert (off[j + 1] - off[j] > 0) == bool(flag)
+
+
+# ---- end-to-end sharded pack: N ranks -> ONE archive, byte-identical to the `-j 1` archive -----------------------
+def _sharded_files():
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import corpus
+    big = corpus.mixed(11, 2 * 2097152 + 12345)              # 3 chunks: two full + a tail
+    files = [("a/big.bin", big), ("a/empty", b""), ("b/t1.txt", corpus.text_like(1, 70000)),
+             ("b/copy_of_big.bin", big),                       # cross-shard duplicates of every chunk of big.bin
+             ("c/r.bin", corpus.random_bytes(3, 1, 40000)), ("c/t1_again.txt", corpus.text_like(1, 70000)),
+             ("d/small", b"hello squish"), ("d/t2.txt", corpus.text_like(2, 150000)), ("e/z", bytes(300000))]
+    return files
+
+
+def _sharded_worker(rank, world, port, out_path, batch_chunks):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    sys.path.insert(0, ROOT)
+    from squishrs_amd.sharded_pack import pack_sharded
+    files = _sharded_files()
+    pack_sharded([(p, None) for p, _ in files], out_path, OracleStages(), device="cpu", timestamp=1234567,
+                 batch_chunks=batch_chunks, contents=[c for _, c in files])
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,batch_chunks", [(2, 4096), (4, 3)])
+def test_sharded_pack_archive_equals_single_writer_archive(tmp_path, world, batch_chunks):
+    """gloo ranks with CPU stand-ins for the device stages: the archive rank 0 writes must be the oracle's
+    `.squish` restatement byte for byte (same timestamp) -- records in global chunk-index order, duplicates that
+    live on other ranks (and in other super-batches) dropped, count patched, manifest complete."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    out = str(tmp_path / f"w{world}.squish")
+    ctx = mp.get_context("spawn")
+    procs = [ctx.Process(target=_sharded_worker, args=(r, world, port, out, batch_chunks)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(timeout=180)
+        assert p.exitcode == 0
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib
+    want = oracle_lib.load().pack_archive(_sharded_files(), timestamp=1234567)
+    got = open(out, "rb").read()
+    assert got == want
+
+
+def test_sharded_pack_single_process_and_walk_order(tmp_path):
+    """world size 1 (no process group): same bytes; and walk_files follows the driver's DFS (stack.pop, OS order)."""
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib
+    from squishrs_amd.sharded_pack import pack_sharded, walk_files
+    files = _sharded_files()
+    root = tmp_path / "tree"
+    for p, c in files:
+        (root / p).parent.mkdir(parents=True, exist_ok=True)
+        (root / p).write_bytes(c)
+    walked = walk_files(str(root) + "/")
+    assert sorted(r for r, _ in walked) == sorted(p for p, _ in files)
+    out = str(tmp_path / "one.squish")
+    size = pack_sharded(walked, out, OracleStages(), device="cpu", timestamp=99, batch_chunks=3)
+    body = {p: c for p, c in files}
+    want = oracle_lib.load().pack_archive([(r, body[r]) for r, _ in walked], timestamp=99)
+    assert open(out, "rb").read() == want and size == len(want)
