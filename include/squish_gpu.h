@@ -154,6 +154,11 @@ typedef struct sq_timings {
 } sq_timings;
 int sq_last_timings(sq_ctx* ctx, sq_timings* out);
 
+/* Test / measurement hook: indices (within the most recent compress launch of this ctx) of the chunks that its
+ * first stage (the incompressible-chunk kernel) left to the compressor proper, heavy ones first; at most cap
+ * entries, *n_out = entries written (0 when that stage did not run).  bench.py draws its oracle sample from it. */
+int sq_debug_stage2_list(sq_ctx* ctx, uint32_t* h_out, uint32_t cap, uint32_t* n_out);
+
 const char* sq_strerror(int err);
 uint32_t sq_abi_version(void);
 

@@ -161,6 +161,13 @@ class ChunkStore:
                                     comp.numel(), comp_off.ctypes.data))
         return comp_off
 
+    def stage2_list(self, cap: int = 1 << 20) -> np.ndarray:
+        """Indices of the chunks the last compress launch's first stage left to the compressor proper."""
+        out = np.zeros(cap, dtype=np.uint32)
+        k = ctypes.c_uint32(0)
+        check(self._L.sq_debug_stage2_list(self._h, out.ctypes.data, cap, ctypes.byref(k)))
+        return out[:k.value].copy()
+
     def read_bw_ms(self, buf) -> float:
         ms = ctypes.c_float(0)
         check(self._L.sq_calibrate_read_bw(self._h, buf.data_ptr(), buf.numel(), ctypes.byref(ms)))

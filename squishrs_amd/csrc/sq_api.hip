@@ -93,6 +93,7 @@ struct sq_ctx {
     u32* d_sched_tab = nullptr; // constant no-match schedule tables of the compressor (sched_tab_fill)
 
     sq_timings last = {0, 0, 0, 0, 0, 0};
+    u32 work_n = 0; // chunks of the launch whose stage-2 work lists b_work holds (0: none)
 };
 
 static bool is_device_ptr(const void* p) {
@@ -504,6 +505,7 @@ static int compress_async(sq_ctx* c, const u8* d_data, const u64* h_off, const u
     HIPCHK(hipEventElapsedTime(&c->last.compress_ms, c->ev[4], c->ev[5]));
     if (fast) HIPCHK(hipEventElapsedTime(&c->last.fast_ms, c->ev[8], c->ev[9]));
     c->last.fast_decided = fast ? h_err[1] : 0;
+    c->work_n = fast ? n : 0;
     if (!*h_err) { // both kernels ran to completion: their saved table states are good for the next launch
         c->ws_ptr_last = c->b_ws.p;
         c->ws_each_last = ws_each;
@@ -661,6 +663,25 @@ int sq_compress_batch_slots(sq_ctx* c, const uint8_t* d_data, const uint64_t* h_
     if ((r = upload_off_len(c, h_off, h_len, n))) return r;
     return compress_async(c, d_data, h_off, h_len, n, d_select, d_comp, comp_cap, h_comp_off, h_comp_len);
 #endif
+}
+
+int sq_debug_stage2_list(sq_ctx* c, uint32_t* h_out, uint32_t cap, uint32_t* n_out) {
+    if (!c || !n_out || (cap && !h_out)) return SQ_E_INVAL;
+    *n_out = 0;
+    if (!c->work_n) return SQ_OK;
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    u32 cnt[2] = {0, 0};
+    HIPCHK(hipMemcpy(cnt, c->b_work.p, 8, hipMemcpyDeviceToHost));
+    u32 k = 0;
+    for (int pass = 0; pass < 2; pass++) {
+        u32 const take = std::min(cnt[pass], cap - k);
+        if (take)
+            HIPCHK(hipMemcpy(h_out + k, (u32*)c->b_work.p + 2 + (pass ? c->work_n : 0u), (size_t)take * 4, hipMemcpyDeviceToHost));
+        k += take;
+    }
+    *n_out = k;
+    return SQ_OK;
 }
 
 uint64_t sq_slots_bound(const uint32_t* h_len, uint32_t n) {

@@ -83,3 +83,17 @@ def test_store_semantics(oracle):
     assert len(c1) < len(data) and oracle.decompress(c1, 2048) == data
     h3, c3 = st.insert(b"other chunk")
     assert c3 is not None and h3 != h1 and st.len() == 2
+
+
+def test_cross_shard_plan_for_config4():
+    """bench.py --gpus N (BASELINE configs[4] shape): 30 % of all chunks copy an original on another shard."""
+    import numpy as np
+    for world, n in ((2, 1000), (8, 500)):
+        plan = corpus.cross_shard_plan(world, n)
+        N = world * n
+        dup = plan != np.arange(N)
+        assert dup.sum() == int(0.3 * N)
+        assert (plan[plan[dup]] == plan[dup]).all()                  # sources are originals
+        assert ((plan[dup] // n) != (np.nonzero(dup)[0] // n)).all()  # ... on another shard
+        assert len(np.unique(plan)) == N - int(0.3 * N)
+    assert (corpus.cross_shard_plan(1, 10) == np.arange(10)).all()

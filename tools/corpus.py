@@ -248,6 +248,28 @@ def planted(seed: int, nbytes: int, variant: int = 0) -> bytes:
     return bytes(b)
 
 
+def cross_shard_plan(world: int, n: int, frac: float = 0.3, seed: int = 4):
+    """BASELINE configs[4]: `world` contiguous shards of n chunks; int(frac * world * n) of ALL chunks are exact
+    copies of an "original" (never itself a copy) that lives on ANOTHER shard.  Returns the content index of every
+    global chunk position (int64[world * n]; plan[g] == g for originals).  Distinct contents = world*n - copies."""
+    N = world * n
+    rng = np.random.default_rng(seed)
+    plan = np.arange(N, dtype=np.int64)
+    if world < 2:
+        return plan
+    is_dup = np.zeros(N, dtype=bool)
+    is_dup[rng.choice(N, size=int(frac * N), replace=False)] = True
+    orig = np.nonzero(~is_dup)[0]
+    dups = np.nonzero(is_dup)[0]
+    pick = orig[rng.integers(0, len(orig), size=len(dups))]
+    same = (pick // n) == (dups // n)
+    while same.any():                                            # same shard: draw again
+        pick[same] = orig[rng.integers(0, len(orig), size=int(same.sum()))]
+        same = (pick // n) == (dups // n)
+    plan[dups] = pick
+    return plan
+
+
 def make(kind: str, seed: int, nbytes: int) -> bytes:
     if kind.startswith("planted"):
         return planted(seed, nbytes, int(kind[7:] or 0))
