@@ -830,16 +830,129 @@ SQ_DEVFN u32 huf_writeCTable(u8* dst, u32 cap, u32 maxSym, u32 huffLog, FseCT* w
     for (u32 n = 0; n < maxSym; n += 2) op[(n / 2) + 1] = (u8)((huffWeight[n] << 4) + huffWeight[n + 1]);
     return ((maxSym + 1) / 2) + 1;
 }
+// ---------------------------------------------------------------- wave-parallel bit-stream emission
+// A zstd bit stream is written LSB first, front to back, by symbols taken from the END of their array towards its
+// start.  So the bit position of a symbol's code is the sum of the code lengths of everything behind it: one
+// exclusive prefix scan over the lanes of a tile (wv_excl_scan), after which every lane ORs its own bits into an
+// LDS window (ds_or) and the wave stores the window's complete 32-bit words with coalesced stores.  Only what is a
+// true recurrence stays serial (the three FSE states, see wv_encode_sequences).
+// The window lives in g_lds.grp (2 KiB, free during the entropy stage): word 0 holds the < 32 carried bits.
+#if SQ_ON_DEVICE
+#define SQZ_WIN_WORDS 192u
+struct WvBitOut {
+    u8* dst;
+    u32 cap, outBytes, carry, overflow;
+};
+SQ_DEV void wvb_init(WvBitOut& o, u8* dst, u32 cap) {
+    o.dst = dst;
+    o.cap = cap;
+    o.outBytes = 0;
+    o.carry = 0;
+    o.overflow = 0;
+    SQ_L u32* const win = (SQ_L u32*)g_lds.grp;
+    for (u32 i = wv_lane(); i < SQZ_WIN_WORDS; i += 64) win[i] = 0;
+    wv_fence();
+}
+// OR `len` bits (len <= 64; bits above len are zero) of this lane at window bit position `pos`
+SQ_DEV void wvb_or(u32 pos, u64 bits, u32 len) {
+    if (len == 0) return;
+    SQ_L u32* const win = (SQ_L u32*)g_lds.grp;
+    u32 const w = pos >> 5, sh = pos & 31;
+    u64 const lo = bits << sh;
+    u32 const hi = sh ? (u32)(bits >> (64 - sh)) : 0u;
+    if ((u32)lo) __hip_atomic_fetch_or(&win[w], (u32)lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    if ((u32)(lo >> 32)) __hip_atomic_fetch_or(&win[w + 1], (u32)(lo >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    if (hi) __hip_atomic_fetch_or(&win[w + 2], hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+// One tile: lane l contributes part A (lenA bits) directly followed by part B (lenB bits); lanes in lane order.
+// total bits of a tile <= (SQZ_WIN_WORDS - 4) * 32 - 32.
+SQ_DEV void wvb_tile(WvBitOut& o, u64 a, u32 lenA, u64 b, u32 lenB) {
+    u32 total;
+    u32 const excl = wv_excl_scan(lenA + lenB, &total);
+    u32 const pos = o.carry + excl;
+    wvb_or(pos, a, lenA);
+    wvb_or(pos + lenA, b, lenB);
+    wv_fence();
+    SQ_L u32* const win = (SQ_L u32*)g_lds.grp;
+    u32 const bitsNow = o.carry + total;
+    u32 const D = bitsNow >> 5; // complete words
+    if (o.outBytes + 4 * D > o.cap) o.overflow = 1;
+    if (!o.overflow)
+        for (u32 i = wv_lane(); i < D; i += 64) *(SQ_G sq_u32_ua*)(o.dst + o.outBytes + 4 * i) = win[i];
+    u32 const rem = win[D];
+    wv_fence();
+    for (u32 i = wv_lane(); i <= D + 3 && i < SQZ_WIN_WORDS; i += 64) win[i] = 0;
+    wv_fence();
+    if (wv_lane() == 0) win[0] = rem;
+    wv_fence();
+    o.outBytes += 4 * D;
+    o.carry = bitsNow & 31;
+}
+// the closing '1' bit and the last partial bytes; returns the stream size, 0 if it did not fit
+SQ_DEV u32 wvb_close(WvBitOut& o) {
+    SQ_L u32* const win = (SQ_L u32*)g_lds.grp;
+    u32 const v = win[0] | (1u << o.carry);
+    u32 const nb = (o.carry + 1 + 7) >> 3;
+    if (o.outBytes + nb > o.cap) o.overflow = 1;
+    if (!o.overflow && wv_lane() == 0)
+        for (u32 k = 0; k < nb; k++) sq_gwr8(o.dst + o.outBytes + k, (v >> (8 * k)) & 0xFF);
+    wv_fence();
+    return o.overflow ? 0u : o.outBytes + nb;
+}
+#endif
+
+// HUF_compress1X_usingCTable: symbols src[n-1] ... src[0], then the end mark.  Wave-level.  ct: table in LDS.
 SQ_DEVFN u32 huf_compress1X(u8* dst, u32 cap, const u8* src, u32 n, const HufCT* ct) {
-    BitW b;
     if (cap < 8) return 0;
+#if SQ_ON_DEVICE
+    WvBitOut o;
+    wvb_init(o, dst, cap);
+    const SQ_L u8* const nbT = (const SQ_L u8*)ct->nbBits;
+    const SQ_L u16* const valT = (const SQ_L u16*)ct->val;
+    u32 const lane = wv_lane();
+    // tiles of 256 symbols from the end; lane l owns the 4 symbols at hi-4l-4 .. hi-4l-1 (written last-first)
+    s32 a = (s32)n - 4 * (s32)(lane + 1);
+    u32 w = 0;
+    auto load4 = [&](s32 at) -> u32 {
+        if (at >= 0) return sq_grd32(src + at);
+        u32 r = 0;
+        for (int k = 0; k < 4; k++)
+            if (at + k >= 0) r |= sq_grd8(src + at + k) << (8 * k);
+        return r;
+    };
+    if (a > -4) w = load4(a);
+    for (u32 hi = n; hi > 0; hi = hi > 256 ? hi - 256 : 0) {
+        // prefetch the next tile's word before working on this one
+        s32 const an = a - 256;
+        u32 wn = 0;
+        if (hi > 256 && an > -4) wn = load4(an);
+        u64 acc = 0;
+        u32 len = 0;
+#pragma unroll
+        for (int k = 3; k >= 0; k--) {
+            if (a + k >= 0) {
+                u32 const sym = (w >> (8 * k)) & 0xFF;
+                u32 const nb = nbT[sym];
+                acc |= (u64)(valT[sym] & ((1u << nb) - 1)) << len;
+                len += nb;
+            }
+        }
+        wvb_tile(o, acc, len, 0, 0);
+        a = an;
+        w = wn;
+    }
+    return wvb_close(o);
+#else
+    BitW b;
     bw_init(b, dst, cap);
     for (u32 i = n; i > 0; i--) {
         u8 s = src[i - 1];
         bw_add(b, ct->val[s], ct->nbBits[s]);
     }
     return bw_close(b);
+#endif
 }
+// HUF_compress4X_usingCTable.  Wave-level.
 SQ_DEVFN u32 huf_compress4X(u8* dst, u32 cap, const u8* src, u32 n, const HufCT* ct) {
     u32 const segmentSize = (n + 3) / 4;
     const u8* ip = src;
@@ -852,8 +965,8 @@ SQ_DEVFN u32 huf_compress4X(u8* dst, u32 cap, const u8* src, u32 n, const HufCT*
     for (int k = 0; k < 3; k++) {
         u32 cSize = huf_compress1X(op, (u32)(oend - op), ip, segmentSize, ct);
         if (cSize == 0 || cSize > 65535) return 0;
-        dst[2 * k] = (u8)cSize;
-        dst[2 * k + 1] = (u8)(cSize >> 8);
+        gst8(dst + 2 * k, cSize & 0xFF);
+        gst8(dst + 2 * k + 1, cSize >> 8);
         op += cSize;
         ip += segmentSize;
     }
@@ -946,15 +1059,16 @@ SQ_DEVFN u32 compressLiterals(u8* dst, u32 dstCap, const u8* src, u32 srcSize, c
         wv_hist_bytes(g_lds.u.es.count, src, srcSize);
         wv_max_and_last(g_lds.u.es.count, 256, &largest, &maxSym);
     }
-    // --- table construction, header and stream emission: serial on lane 0
+    // --- table construction and header: serial on lane 0.  Leaves in g_lds.ret: [0] what to do next (0 = cLitSize
+    // decided, 1 = emit the streams with the previous table, 2 = with the new table), [1] cLitSize when decided,
+    // [2] bytes of table description in front of the streams, [3] the repeat mode so far.
+    u8* const ostart = dst + lhSize;
+    u8* const oend = ostart + (dstCap - lhSize);
     WV_SERIAL {
-        u8* const ostart = dst + lhSize;
         u32 const hcap = dstCap - lhSize;
-        u8* const oend = ostart + hcap;
         u8* op = ostart;
-        u32 cLitSize = 0;
+        u32 cLitSize = 0, todo = 0, hdrBytes = 0;
         u32 repeat = prev->huf_repeat;
-        u32 hType = SET_COMPRESSED;
         const u32* count = g_lds.u.es.count;
         do {
             if (early == 0) {
@@ -1002,7 +1116,7 @@ SQ_DEVFN u32 compressLiterals(u8* dst, u32 dstCap, const u8* src, u32 srcSize, c
                     }
                     u32 const oldSize = oldBits >> 3, newSize = newBits >> 3;
                     if (oldSize <= hSize + newSize || hSize + 12 >= srcSize) {
-                        cLitSize = huf_compressCTable(ostart, op, oend, src, srcSize, singleStream, &prev->huf);
+                        todo = 1; // streams with the previous table, no description
                         break;
                     }
                 }
@@ -1010,12 +1124,33 @@ SQ_DEVFN u32 compressLiterals(u8* dst, u32 dstCap, const u8* src, u32 srcSize, c
                     cLitSize = 0;
                     break;
                 }
-                op += hSize;
+                hdrBytes = hSize;
                 repeat = REP_NONE;
                 next->huf = g_lds.u.es.newHuf;
+                todo = 2;
             }
-            cLitSize = huf_compressCTable(ostart, op, oend, src, srcSize, singleStream, &g_lds.u.es.newHuf);
         } while (0);
+        g_lds.ret[0] = todo;
+        g_lds.ret[1] = cLitSize;
+        g_lds.ret[2] = hdrBytes;
+        g_lds.ret[3] = repeat;
+    }
+    wv_mem_sync();
+    // --- stream emission by the whole wave (huf_compress1X / 4X)
+    u32 cLit = g_lds.ret[1];
+    {
+        u32 const todo = g_lds.ret[0], hdrBytes = g_lds.ret[2];
+        wv_fence();
+        if (todo) {
+            const HufCT* const table = (todo == 1) ? &prev->huf : &g_lds.u.es.newHuf;
+            cLit = huf_compressCTable(ostart, ostart + hdrBytes, oend, src, srcSize, singleStream, table);
+            wv_mem_sync();
+        }
+    }
+    WV_SERIAL {
+        u32 const cLitSize = cLit;
+        u32 const repeat = g_lds.ret[3];
+        u32 hType = SET_COMPRESSED;
         if (repeat != REP_NONE) hType = SET_REPEAT;
         // ZSTD_compressLiterals post-processing
         u32 mode; // 0 raw, 1 rle, 2 compressed
@@ -1175,12 +1310,101 @@ SQ_DEVFN u32 buildCTable(u8* dst, u32 dstCap, FseCT* nextCTable, u32 FSELog, u32
     default: return SQZ_ERR;
     }
 }
+// ZSTD_encodeSequences.  Wave-level.  The three FSE states are true recurrences: lanes 0..2 run them (OF, ML, LL)
+// side by side over all sequences, last to first, and leave (nbBits << 12 | bits) per sequence and stream in
+// stBits (4 x u16 per sequence, workspace); then tiles of 64 sequences are packed in parallel: every lane builds
+// its sequence's bits (state bits of OF, ML, LL; extra bits of LL, ML, OF), a prefix scan places them (wvb_tile).
 SQ_DEVFN u32 encodeSequences(u8* dst, u32 dstCap, const FseCT* ctML, const u8* mlCodeTable, const FseCT* ctOF,
                              const u8* ofCodeTable, const FseCT* ctLL, const u8* llCodeTable,
-                             const SeqDef* sequences, u32 nbSeq) {
+                             const SeqDef* sequences, u32 nbSeq, u16* stBits) {
+    if (dstCap < 9) return SQZ_ERR;
+#if SQ_ON_DEVICE
+    u32 const lane = wv_lane();
+    u32 finalValue = 0, tableLog = 0;
+    if (lane < 3) {
+        const FseCT* const ctg = lane == 0 ? ctOF : lane == 1 ? ctML : ctLL;
+        const SQ_L FseCT* const ct = (const SQ_L FseCT*)ctg;
+        const u8* const codes = lane == 0 ? ofCodeTable : lane == 1 ? mlCodeTable : llCodeTable;
+        tableLog = ct->tableLog;
+        u32 value;
+        { // FSE_initCState2 with the last sequence's code
+            u32 const sym = sq_grd8(codes + nbSeq - 1);
+            u32 const dnb = ct->dnb[sym];
+            u32 const nbBitsOut = (dnb + (1u << 15)) >> 16;
+            value = (nbBitsOut << 16) - dnb;
+            value = ct->stateTable[(value >> nbBitsOut) + ct->dfs[sym]];
+        }
+        if (nbSeq >= 2) {
+            // sequences nbSeq-2 .. 0 in groups of 16 code bytes (one aligned 16-byte load per group, the next
+            // group's load in flight while this one is worked on)
+            s32 g = (s32)((nbSeq - 2) >> 4);
+            sq_v4u cur = *(const SQ_G sq_v4u*)(codes + 16 * g);
+            for (; g >= 0; g--) {
+                sq_v4u nxt = cur;
+                if (g > 0) nxt = *(const SQ_G sq_v4u*)(codes + 16 * (g - 1));
+#pragma unroll
+                for (int k = 15; k >= 0; k--) {
+                    u32 const n = 16u * (u32)g + (u32)k;
+                    if (n <= nbSeq - 2) {
+                        u32 const sym = (cur[k >> 2] >> (8 * (k & 3))) & 0xFF;
+                        u32 const nb = (value + ct->dnb[sym]) >> 16;
+                        *(SQ_G u16*)(stBits + 4 * n + lane) = (u16)((nb << 12) | (value & ((1u << nb) - 1)));
+                        value = ct->stateTable[(value >> nb) + ct->dfs[sym]];
+                    }
+                }
+                cur = nxt;
+            }
+        }
+        finalValue = value;
+    }
+    wv_mem_sync(); // the state bits have landed
+    WvBitOut o;
+    wvb_init(o, dst, dstCap);
+    for (s32 hi = (s32)nbSeq; hi > 0; hi -= 64) {
+        s32 const n = hi - 1 - (s32)lane;
+        u64 A = 0, B = 0;
+        u32 lenA = 0, lenB = 0;
+        if (n >= 0) {
+            sq_v2u const sd = *(const SQ_G sq_v2u*)(sequences + n); // offBase | litLength, mlBase
+            u32 const ll = sq_grd8(llCodeTable + n), of = sq_grd8(ofCodeTable + n), ml = sq_grd8(mlCodeTable + n);
+            if ((u32)n != nbSeq - 1) {
+                sq_v2u const sb = *(const SQ_G sq_v2u*)(stBits + 4 * n);
+                u32 const fOF = sb.x & 0xFFFF, fML = sb.x >> 16, fLL = sb.y & 0xFFFF;
+                A = fOF & 0xFFF;
+                lenA = fOF >> 12;
+                A |= (u64)(fML & 0xFFF) << lenA;
+                lenA += fML >> 12;
+                A |= (u64)(fLL & 0xFFF) << lenA;
+                lenA += fLL >> 12;
+            }
+            u32 const llb = LL_bits[ll], mlb = ML_bits[ml];
+            A |= (u64)((sd.y & 0xFFFF) & ((1u << llb) - 1)) << lenA;
+            lenA += llb;
+            A |= (u64)((sd.y >> 16) & ((1u << mlb) - 1)) << lenA;
+            lenA += mlb;
+            B = sd.x & (u32)((1ull << of) - 1);
+            lenB = of;
+        }
+        wvb_tile(o, A, lenA, B, lenB);
+    }
+    { // FSE_flushCState x 3: ML, OF, LL
+        u32 const vOF = wv_readlane(finalValue, 0), vML = wv_readlane(finalValue, 1), vLL = wv_readlane(finalValue, 2);
+        u32 const tOF = wv_readlane(tableLog, 0), tML = wv_readlane(tableLog, 1), tLL = wv_readlane(tableLog, 2);
+        u64 A = vML & ((1u << tML) - 1);
+        u32 len = tML;
+        A |= (u64)(vOF & ((1u << tOF) - 1)) << len;
+        len += tOF;
+        A |= (u64)(vLL & ((1u << tLL) - 1)) << len;
+        len += tLL;
+        wvb_tile(o, lane == 0 ? A : 0, lane == 0 ? len : 0, 0, 0);
+    }
+    u32 const streamSize = wvb_close(o);
+    wv_mem_sync();
+    return streamSize ? streamSize : SQZ_ERR;
+#else
+    (void)stBits;
     BitW b;
     FseState stML, stOF, stLL;
-    if (dstCap < 9) return SQZ_ERR;
     bw_init(b, dst, dstCap);
     fse_initCState2(stML, ctML, mlCodeTable[nbSeq - 1]);
     fse_initCState2(stOF, ctOF, ofCodeTable[nbSeq - 1]);
@@ -1205,6 +1429,7 @@ SQ_DEVFN u32 encodeSequences(u8* dst, u32 dstCap, const FseCT* ctML, const u8* m
         if (streamSize == 0) return SQZ_ERR;
         return streamSize;
     }
+#endif
 }
 
 // Sequence store of one block (arrays in the wave's global workspace)
@@ -1212,6 +1437,7 @@ struct SeqStore {
     SeqDef* seqs;
     u8* lits;
     u8 *llCode, *ofCode, *mlCode;
+    u16* stBits; // 4 x u16 per sequence: FSE state bits of the sequences bit stream (encodeSequences)
     u32 nseq, nlits;
     u32 longLengthType, longLengthPos;
 };
@@ -1293,6 +1519,7 @@ SQ_DEVFN u32 entropy_compress_seqstore(const SeqStore& ss, const Entropy* prev, 
         u8* op = dst + litSectionSize;
         u32 result = 0; // 0 => raw
         u32 lastCountSize = 0;
+        g_lds.ret[3] = 0;
         do {
             if ((oend - op) < 3 + 1) {
                 result = 0;
@@ -1376,20 +1603,11 @@ SQ_DEVFN u32 entropy_compress_seqstore(const SeqStore& ss, const Entropy* prev, 
                     break;
                 }
                 *seqHead = (u8)((LLtype << 6) + (Offtype << 4) + (MLtype << 2));
-                {
-                    u32 const bitstreamSize = encodeSequences(op, (u32)(oend - op), &next->ml, ss.mlCode, &next->of,
-                                                              ss.ofCode, &next->ll, ss.llCode, ss.seqs, nbSeq);
-                    if (is_err(bitstreamSize)) {
-                        result = (blockSize <= dstCap) ? 0 : SQZ_ERR;
-                        break;
-                    }
-                    op += bitstreamSize;
-                    if (lastCountSize && (lastCountSize + bitstreamSize) < 4) {
-                        result = 0;
-                        break;
-                    }
-                }
-                result = (u32)(op - ostart);
+                // the bit stream itself is written by the whole wave, below
+                g_lds.ret[3] = 1;
+                g_lds.ret[4] = (u32)(op - ostart);
+                g_lds.ret[5] = lastCountSize;
+                break;
             }
             {
                 u32 const maxCSize = blockSize - min_gain(blockSize, strategy);
@@ -1397,6 +1615,25 @@ SQ_DEVFN u32 entropy_compress_seqstore(const SeqStore& ss, const Entropy* prev, 
             }
         } while (0);
         g_lds.ret[2] = result;
+    }
+    wv_mem_sync();
+    if (nbSeq && g_lds.ret[3] == 1) {
+        u32 const opOff = g_lds.ret[4], lastCountSize = g_lds.ret[5];
+        wv_fence();
+        u32 result;
+        u32 const bitstreamSize = encodeSequences(dst + opOff, dstCap - opOff, &next->ml, ss.mlCode, &next->of, ss.ofCode,
+                                                  &next->ll, ss.llCode, ss.seqs, nbSeq, ss.stBits);
+        if (is_err(bitstreamSize)) {
+            result = (blockSize <= dstCap) ? 0 : SQZ_ERR;
+        } else if (lastCountSize && (lastCountSize + bitstreamSize) < 4) {
+            result = 0;
+        } else {
+            result = opOff + bitstreamSize;
+            u32 const maxCSize = blockSize - min_gain(blockSize, strategy);
+            if (result >= maxCSize) result = 0;
+        }
+        PROF_ADD(6, t_ent);
+        return result;
     }
     wv_mem_sync();
     PROF_ADD(6, t_ent);

@@ -25,7 +25,7 @@ struct Fingerprint {
 };
 
 struct WsLayout {
-    size_t hashTable, table2, hashTable3, seqs, lits, llCode, ofCode, mlCode, optState, fp, sched, liveList,
+    size_t hashTable, table2, hashTable3, seqs, lits, llCode, ofCode, mlCode, stBits, optState, fp, sched, liveList,
         skipList, blockTab, certTab, dummy, total;
 };
 
@@ -90,6 +90,8 @@ SQ_HD WsLayout ws_layout(u32 max_len) {
     o += ws_align(SQZ_MAX_NBSEQ);
     L.mlCode = o;
     o += ws_align(SQZ_MAX_NBSEQ);
+    L.stBits = o;
+    o += ws_align((size_t)SQZ_MAX_NBSEQ * 8);
     L.optState = o;
     o += ws_align(sizeof(opt::optstate));
     L.fp = o;
@@ -457,6 +459,7 @@ SQ_DEVFN u32 compress_frame_wave(const u8* src, u32 n, u8* dst, u32 cap, u8* ws,
     ss.llCode = ws + L.llCode;
     ss.ofCode = ws + L.ofCode;
     ss.mlCode = ws + L.mlCode;
+    ss.stBits = (u16*)(ws + L.stBits);
     ss.nseq = ss.nlits = 0;
     ss.longLengthType = ss.longLengthPos = 0;
     WV_SERIAL {
