@@ -62,13 +62,23 @@ struct EntropyScratch { // live only inside the entropy stage of a block
     u8 tableSymbol[512];
 };
 #define SQZ_BLOOM_WORDS 2048 // 65,536-bit Bloom filter of "live" hash buckets (match-finding phase)
+// candidate list of a row-hash search batch (sq_zstd_rowbatch.h): (owner lane, slot) descriptors, then the
+// candidates' positions and match lengths, balanced over the lanes
+#define SQZ_RB_PAIRS 256u
+struct RbLds {
+    u16 desc[SQZ_RB_PAIRS];
+    u32 cand[SQZ_RB_PAIRS];
+    u32 rowId[64], pbase[64]; // per owner lane: its row, the start of its pairs
+    u32 stop[64], best[64], flag[64]; // per owner lane: first pair that ends the scan; (len << 8 | 255 - order) maximum; "long candidate" flag
+};
 struct LdsState {
     Entropy ent[2];
     union {
         EntropyScratch es;
         u32 bloom[SQZ_BLOOM_WORDS];
+        RbLds rb; // row-hash search batches (match-finding phase of the lazy2 strategy)
     } u;
-    u8 grp[2048]; // wv_group scratch
+    alignas(16) u8 grp[2048]; // wv_group scratch; the 64 x 32 source bytes of a row-hash search batch
     u32 ret[8];   // results handed from a serial region to the whole wave
     u32* trace;   // 56 debug words in the wave's workspace (read by the host watchdog)
 #ifdef SQ_PROF

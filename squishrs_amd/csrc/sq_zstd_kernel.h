@@ -262,7 +262,7 @@ SQ_DEVFN u32 compressBlock_internal(MatchState& ms, SeqStore& ss, BlockState& bs
         u32 lastLLSize;
         SQ_TRACE(0, 6);
         if (ms.cp.strategy == STRAT_LAZY2) {
-            lastLLSize = compressBlock_lazy<1>(ms, ss, bs.rep[nx], src, srcSize);
+            lastLLSize = compressBlock_lazy_rowbatch(ms, ss, bs.rep[nx], src, srcSize);
         } else if (ms.cp.strategy == STRAT_BTLAZY2) {
             lastLLSize = compressBlock_lazy<0>(ms, ss, bs.rep[nx], src, srcSize);
         } else {

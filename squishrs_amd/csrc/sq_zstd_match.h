@@ -2379,4 +2379,6 @@ SQ_DEVFN u32 compressBlock_lazy(MatchState& ms, SeqStore& ss, u32* rep, const u8
 #endif
 }
 
+#include "sq_zstd_rowbatch.h"
+
 } // namespace sqz

@@ -40,6 +40,10 @@ def _sim_compress(lib, data):
 CASES = [(k, s, n) for k in ("random", "text", "mixed", "runs", "records", "skewed", "zeros")
          for s, n in ((0, 3000), (1, 16384), (0, 20000), (1, 70000), (0, 131073), (1, 262144))]
 CASES += [("mixed", 2, 600000), ("text", 3, 1048577), ("random", 4, 2097152), ("mixed", 5, 2097152)]
+# row-hash finder over speculative search batches (sq_zstd_rowbatch.h): every kind at the sizes of that strategy
+CASES += [(k, 20 + i, n) for i, (k, n) in enumerate([("records", 300000), ("runs", 400001), ("skewed", 270000), ("zeros", 262145),
+                                                     ("text", 262145), ("records", 1500000), ("runs", 2097152), ("skewed", 700000),
+                                                     ("mixed", 1000003), ("planted4", 300000)])]
 
 
 @pytest.mark.parametrize("kind,seed,n", CASES)
