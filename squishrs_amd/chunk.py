@@ -161,6 +161,20 @@ class ChunkStore:
                                     comp.numel(), comp_off.ctypes.data))
         return comp_off
 
+    def pack_submit(self, data, offs: np.ndarray, lens: np.ndarray, hashes, is_new, comp, reset: bool = False):
+        """sq_pack_submit: enqueue hash -> dedup -> compress (slots layout) of one device-resident batch and return;
+        at most two batches in flight, each with its own hashes / is_new / comp buffers."""
+        check(self._L.sq_pack_submit(self._h, data.data_ptr(), offs.ctypes.data, lens.ctypes.data, len(lens),
+                                     hashes.data_ptr(), is_new.data_ptr(), comp.data_ptr(), comp.numel(),
+                                     1 if reset else 0))
+
+    def pack_wait(self, n: int):
+        """sq_pack_wait: (slot offsets[n], frame lengths[n]) of the oldest batch in flight."""
+        comp_off = np.zeros(n, dtype=np.uint64)
+        comp_len = np.zeros(n, dtype=np.uint32)
+        check(self._L.sq_pack_wait(self._h, comp_off.ctypes.data, comp_len.ctypes.data))
+        return comp_off, comp_len
+
     def stage2_list(self, cap: int = 1 << 20) -> np.ndarray:
         """Indices of the chunks the last compress launch's first stage left to the compressor proper."""
         out = np.zeros(cap, dtype=np.uint32)

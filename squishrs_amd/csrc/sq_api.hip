@@ -63,12 +63,43 @@ struct DevBuf {
 
 } // namespace
 
+// Everything ONE batch in flight needs: a stream, events, the per-batch device buffers, the two table pools of the
+// compressor and the small pinned mirror.  A context has two of them ("lanes"): the synchronous entry points use
+// lane 0; sq_pack_submit alternates, so that the thin tail of one batch's compress stage runs under the next
+// batch's hash and stage-1 kernels (and, with host buffers, under its transfers).
+struct sq_lane {
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    hipEvent_t ev[10] = {};
+    hipEvent_t dedup_done = nullptr; // recorded after this lane's dedup kernels: the other lane's dedup waits for it
+    DevBuf b_off, b_len, b_slot_off, b_frame_len, b_out_off, b_isnew, b_hashes, b_stage_in,
+        b_stage_out, b_slots, b_ws, b_misc, b_cert, b_etab, b_work;
+    // shapes of the two table pools at the last launch that completed (persistent generation tags)
+    void* ws_ptr_last = nullptr;
+    size_t ws_each_last = 0;
+    u32 ws_waves_last = 0;
+    void* etab_ptr_last = nullptr;
+    size_t etab_bytes_last = 0;
+    u32 etab_waves_last = 0;
+    void* h_pinned = nullptr; // small pinned host mirror (error words etc.)
+    sq_timings last = {0, 0, 0, 0, 0, 0};
+    u32 work_n = 0; // chunks of the launch whose stage-2 work lists b_work holds (0: none)
+    // a batch enqueued by sq_pack_submit and not yet collected by sq_pack_wait
+    bool busy = false;
+    u32 job_n = 0;
+    std::vector<u64> job_slot_off;
+    void* h_len_pinned = nullptr; // pinned mirror of the frame lengths of the batch in flight
+    size_t h_len_cap = 0;
+    u32 job_max_len = 0;
+    u32 job_waves = 0, job_fwaves = 0;
+    size_t job_ws_each = 0, job_etab_bytes = 0;
+    bool job_fast = false;
+    u64 job_seen_before = 0;
+};
+
 struct sq_ctx {
     sq_config cfg;
     int device = 0;
-    hipStream_t stream = nullptr;
-    bool own_stream = false;
-    hipEvent_t ev[10];
     int num_cu = 256;
 
     // dedup state (persistent)
@@ -79,21 +110,10 @@ struct sq_ctx {
     u64 key_capacity = 0;
     u64 n_seen = 0; // global chunk index of the next chunk
 
-    // per-batch scratch
-    DevBuf b_off, b_len, b_slot_off, b_frame_len, b_out_off, b_isnew, b_hashes, b_stage_in,
-        b_stage_out, b_slots, b_ws, b_misc, b_cert, b_etab, b_work;
-    // shapes of the two table pools at the last launch that completed (persistent generation tags)
-    void* ws_ptr_last = nullptr;
-    size_t ws_each_last = 0;
-    u32 ws_waves_last = 0;
-    void* etab_ptr_last = nullptr;
-    size_t etab_bytes_last = 0;
-    u32 etab_waves_last = 0;
-    void* h_pinned = nullptr; // small pinned host mirror (total sizes etc.)
     u32* d_sched_tab = nullptr; // constant no-match schedule tables of the compressor (sched_tab_fill)
-
-    sq_timings last = {0, 0, 0, 0, 0, 0};
-    u32 work_n = 0; // chunks of the launch whose stage-2 work lists b_work holds (0: none)
+    sq_lane ln[2];
+    u32 last_lane = 0; // lane of the batch finished most recently (sq_debug_stage2_list)
+    u32 submitted = 0, collected = 0; // sq_pack_submit / sq_pack_wait tickets (submitted - collected <= 2)
 };
 
 static bool is_device_ptr(const void* p) {
@@ -156,16 +176,25 @@ int sq_ctx_create(const sq_config* cfg_in, sq_ctx** out) {
     c->cfg = cfg;
     c->device = cfg.device;
     c->num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
-        delete c;
-        return SQ_E_DEVICE;
-    }
-    c->own_stream = true;
-    for (auto& e : c->ev)
-        if (hipEventCreate(&e) != hipSuccess) {
-            delete c;
+    for (sq_lane& ln : c->ln) {
+        sq_lane* const L = &ln;
+        if (hipStreamCreateWithFlags(&L->stream, hipStreamNonBlocking) != hipSuccess) {
+            sq_ctx_destroy(c);
             return SQ_E_DEVICE;
         }
+        L->own_stream = true;
+        for (auto& e : L->ev)
+            if (hipEventCreate(&e) != hipSuccess) {
+                sq_ctx_destroy(c);
+                return SQ_E_DEVICE;
+            }
+        if (hipEventCreateWithFlags(&L->dedup_done, hipEventDisableTiming) != hipSuccess ||
+            hipHostMalloc(&L->h_pinned, 4096, hipHostMallocDefault) != hipSuccess) {
+            sq_ctx_destroy(c);
+            return SQ_E_NOMEM;
+        }
+    }
+    sq_lane* const L = &c->ln[0];
     // dedup set: table of 2x capacity (power of two), keys for `capacity` chunks
     u64 slots = 1024;
     while (slots < cfg.dedup_capacity * 2) slots <<= 1;
@@ -173,14 +202,13 @@ int sq_ctx_create(const sq_config* cfg_in, sq_ctx** out) {
     c->key_capacity = cfg.dedup_capacity;
     if (hipMalloc((void**)&c->d_table, slots * sizeof(u32)) != hipSuccess ||
         hipMalloc((void**)&c->d_keys, c->key_capacity * 16) != hipSuccess ||
-        hipMalloc((void**)&c->d_unique, 64) != hipSuccess ||
-        hipHostMalloc(&c->h_pinned, 4096, hipHostMallocDefault) != hipSuccess) {
+        hipMalloc((void**)&c->d_unique, 64) != hipSuccess) {
         sq_ctx_destroy(c);
         return SQ_E_NOMEM;
     }
-    if (hipMemsetAsync(c->d_table, 0, slots * sizeof(u32), c->stream) != hipSuccess ||
-        hipMemsetAsync(c->d_unique, 0, 64, c->stream) != hipSuccess ||
-        hipStreamSynchronize(c->stream) != hipSuccess) {
+    if (hipMemsetAsync(c->d_table, 0, slots * sizeof(u32), L->stream) != hipSuccess ||
+        hipMemsetAsync(c->d_unique, 0, 64, L->stream) != hipSuccess ||
+        hipStreamSynchronize(L->stream) != hipSuccess) {
         sq_ctx_destroy(c);
         return SQ_E_DEVICE;
     }
@@ -202,35 +230,42 @@ int sq_ctx_create(const sq_config* cfg_in, sq_ctx** out) {
 void sq_ctx_destroy(sq_ctx* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
-    if (c->stream) (void)hipStreamSynchronize(c->stream);
-    for (DevBuf* b : {&c->b_off, &c->b_len, &c->b_slot_off, &c->b_frame_len, &c->b_out_off, &c->b_isnew,
-                      &c->b_hashes, &c->b_stage_in, &c->b_stage_out, &c->b_slots, &c->b_ws, &c->b_misc, &c->b_cert, &c->b_etab, &c->b_work})
-        b->release();
+    for (sq_lane& ln : c->ln) {
+        sq_lane* const L = &ln;
+        if (L->stream) (void)hipStreamSynchronize(L->stream);
+        for (DevBuf* b : {&L->b_off, &L->b_len, &L->b_slot_off, &L->b_frame_len, &L->b_out_off, &L->b_isnew,
+                          &L->b_hashes, &L->b_stage_in, &L->b_stage_out, &L->b_slots, &L->b_ws, &L->b_misc, &L->b_cert, &L->b_etab, &L->b_work})
+            b->release();
+        if (L->h_pinned) (void)hipHostFree(L->h_pinned);
+        if (L->h_len_pinned) (void)hipHostFree(L->h_len_pinned);
+        for (auto& e : L->ev)
+            if (e) (void)hipEventDestroy(e);
+        if (L->dedup_done) (void)hipEventDestroy(L->dedup_done);
+        if (L->own_stream && L->stream) (void)hipStreamDestroy(L->stream);
+    }
     if (c->d_table) (void)hipFree(c->d_table);
     if (c->d_keys) (void)hipFree(c->d_keys);
     if (c->d_unique) (void)hipFree(c->d_unique);
-    if (c->h_pinned) (void)hipHostFree(c->h_pinned);
     if (c->d_sched_tab) (void)hipFree(c->d_sched_tab);
-    for (auto& e : c->ev)
-        if (e) (void)hipEventDestroy(e);
-    if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
 
 int sq_ctx_set_stream(sq_ctx* c, void* s) {
     if (!c) return SQ_E_INVAL;
+    if (c->submitted != c->collected) return SQ_E_INVAL; // batches of sq_pack_submit are in flight: collect them first
+    sq_lane* const L = &c->ln[0];
     HIPCHK(hipSetDevice(c->device));
-    HIPCHK(hipStreamSynchronize(c->stream));
-    if (c->own_stream) (void)hipStreamDestroy(c->stream);
-    c->stream = (hipStream_t)s;
-    c->own_stream = false;
+    HIPCHK(hipStreamSynchronize(L->stream));
+    if (L->own_stream) (void)hipStreamDestroy(L->stream);
+    L->stream = (hipStream_t)s;
+    L->own_stream = false;
     return SQ_OK;
 }
 
 int sq_ctx_synchronize(sq_ctx* c) {
     if (!c) return SQ_E_INVAL;
     HIPCHK(hipSetDevice(c->device));
-    HIPCHK(hipStreamSynchronize(c->stream));
+    for (sq_lane& ln : c->ln) HIPCHK(hipStreamSynchronize(ln.stream));
     return SQ_OK;
 }
 
@@ -238,88 +273,94 @@ uint64_t sq_unique_count(const sq_ctx* c) {
     if (!c) return 0;
     unsigned long long v = 0;
     (void)hipSetDevice(c->device);
-    if (hipStreamSynchronize(c->stream) != hipSuccess) return 0;
+    for (const sq_lane& ln : c->ln)
+        if (hipStreamSynchronize(ln.stream) != hipSuccess) return 0;
     if (hipMemcpy(&v, c->d_unique, sizeof(v), hipMemcpyDeviceToHost) != hipSuccess) return 0;
     return (uint64_t)v;
 }
 
 int sq_dedup_reset(sq_ctx* c) {
     if (!c) return SQ_E_INVAL;
+    if (c->submitted != c->collected) return SQ_E_INVAL; // batches of sq_pack_submit are in flight: collect them first
+    sq_lane* const L = &c->ln[0];
     HIPCHK(hipSetDevice(c->device));
-    HIPCHK(hipMemsetAsync(c->d_table, 0, (c->table_mask + 1) * sizeof(u32), c->stream));
-    HIPCHK(hipMemsetAsync(c->d_unique, 0, 64, c->stream));
+    HIPCHK(hipMemsetAsync(c->d_table, 0, (c->table_mask + 1) * sizeof(u32), L->stream));
+    HIPCHK(hipMemsetAsync(c->d_unique, 0, 64, L->stream));
     c->n_seen = 0;
     return SQ_OK;
 }
 
 int sq_last_timings(sq_ctx* c, sq_timings* out) {
     if (!c || !out) return SQ_E_INVAL;
-    *out = c->last;
+    sq_lane* const L = &c->ln[0];
+    *out = L->last;
     return SQ_OK;
 }
 
 // ---- helpers --------------------------------------------------------------------------------
-static int upload_off_len(sq_ctx* c, const u64* h_off, const u32* h_len, u32 n) {
+static int upload_off_len(sq_ctx* c, sq_lane* L, const u64* h_off, const u32* h_len, u32 n) {
     int r;
-    if ((r = c->b_off.ensure((size_t)n * 8))) return r;
-    if ((r = c->b_len.ensure((size_t)n * 4))) return r;
-    HIPCHK(hipMemcpyAsync(c->b_off.p, h_off, (size_t)n * 8, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(hipMemcpyAsync(c->b_len.p, h_len, (size_t)n * 4, hipMemcpyHostToDevice, c->stream));
+    if ((r = L->b_off.ensure((size_t)n * 8))) return r;
+    if ((r = L->b_len.ensure((size_t)n * 4))) return r;
+    HIPCHK(hipMemcpyAsync(L->b_off.p, h_off, (size_t)n * 8, hipMemcpyHostToDevice, L->stream));
+    HIPCHK(hipMemcpyAsync(L->b_len.p, h_len, (size_t)n * 4, hipMemcpyHostToDevice, L->stream));
     return SQ_OK;
 }
 
-static int launch_hash(sq_ctx* c, const u8* d_data, u32 n, u8* d_hashes) {
+static int launch_hash(sq_ctx* c, sq_lane* L, const u8* d_data, u32 n, u8* d_hashes) {
     if (n == 0) return SQ_OK;
     const u32 wpb = 4;
-    HIPCHK(hipEventRecord(c->ev[0], c->stream));
+    HIPCHK(hipEventRecord(L->ev[0], L->stream));
     if (getenv("SQ_HASH_WAVE_PER_CHUNK")) { // the first mapping: one wave per chunk
         dim3 grid((n + wpb - 1) / wpb), block(64 * wpb);
-        hipLaunchKernelGGL(sqx::k_xxh3_128_batch, grid, block, 0, c->stream, d_data, (const u64*)c->b_off.p,
-                           (const u32*)c->b_len.p, n, d_hashes);
+        hipLaunchKernelGGL(sqx::k_xxh3_128_batch, grid, block, 0, L->stream, d_data, (const u64*)L->b_off.p,
+                           (const u32*)L->b_len.p, n, d_hashes);
     } else { // 16 lanes per chunk, four chunks per wave
         dim3 grid((n + 4 * wpb - 1) / (4 * wpb)), block(64 * wpb);
-        hipLaunchKernelGGL(sqx::k_xxh3_128_rows, grid, block, 0, c->stream, d_data, (const u64*)c->b_off.p,
-                           (const u32*)c->b_len.p, n, d_hashes);
+        hipLaunchKernelGGL(sqx::k_xxh3_128_rows, grid, block, 0, L->stream, d_data, (const u64*)L->b_off.p,
+                           (const u32*)L->b_len.p, n, d_hashes);
     }
     HIPCHK(hipGetLastError());
-    HIPCHK(hipEventRecord(c->ev[1], c->stream));
+    HIPCHK(hipEventRecord(L->ev[1], L->stream));
     return SQ_OK;
 }
 
 int sq_hash_batch(sq_ctx* c, const uint8_t* d_data, const uint64_t* h_off, const uint32_t* h_len,
                   uint32_t n, uint8_t* d_hashes) {
     if (!c || (n && (!d_data || !h_off || !h_len || !d_hashes))) return SQ_E_INVAL;
+    if (c->submitted != c->collected) return SQ_E_INVAL; // batches of sq_pack_submit are in flight: collect them first
+    sq_lane* const L = &c->ln[0];
     HIPCHK(hipSetDevice(c->device));
     int r;
-    if ((r = upload_off_len(c, h_off, h_len, n))) return r;
-    if ((r = launch_hash(c, d_data, n, d_hashes))) return r;
-    HIPCHK(hipStreamSynchronize(c->stream));
-    if (n) HIPCHK(hipEventElapsedTime(&c->last.hash_ms, c->ev[0], c->ev[1]));
+    if ((r = upload_off_len(c, L, h_off, h_len, n))) return r;
+    if ((r = launch_hash(c, L, d_data, n, d_hashes))) return r;
+    HIPCHK(hipStreamSynchronize(L->stream));
+    if (n) HIPCHK(hipEventElapsedTime(&L->last.hash_ms, L->ev[0], L->ev[1]));
     return SQ_OK;
 }
 
-static int dedup_async(sq_ctx* c, const u8* d_all_hashes, u64 n_total, u64 my_first, u32 my_n,
+static int dedup_async(sq_ctx* c, sq_lane* L, const u8* d_all_hashes, u64 n_total, u64 my_first, u32 my_n,
                        u8* d_is_new) {
     if (c->n_seen + n_total > c->key_capacity) return SQ_E_CAP;
     if (c->n_seen + n_total >= 0xFFFFFFFFull) return SQ_E_CAP;
     if (n_total == 0) return SQ_OK;
     const u64 g0 = c->n_seen;
-    HIPCHK(hipEventRecord(c->ev[2], c->stream));
+    HIPCHK(hipEventRecord(L->ev[2], L->stream));
     HIPCHK(hipMemcpyAsync(c->d_keys + 2 * g0, d_all_hashes, n_total * 16, hipMemcpyDeviceToDevice,
-                          c->stream));
+                          L->stream));
     {
         dim3 block(256), grid((unsigned)((n_total + 255) / 256));
-        hipLaunchKernelGGL(sqd::k_dedup_insert, grid, block, 0, c->stream, (const u64*)c->d_keys, g0,
+        hipLaunchKernelGGL(sqd::k_dedup_insert, grid, block, 0, L->stream, (const u64*)c->d_keys, g0,
                            n_total, c->d_table, c->table_mask, c->d_unique);
         HIPCHK(hipGetLastError());
     }
     if (my_n) {
         dim3 block(256), grid((my_n + 255) / 256);
-        hipLaunchKernelGGL(sqd::k_dedup_resolve, grid, block, 0, c->stream, (const u64*)c->d_keys,
+        hipLaunchKernelGGL(sqd::k_dedup_resolve, grid, block, 0, L->stream, (const u64*)c->d_keys,
                            g0 + my_first, my_n, (const u32*)c->d_table, c->table_mask, d_is_new);
         HIPCHK(hipGetLastError());
     }
-    HIPCHK(hipEventRecord(c->ev[3], c->stream));
+    HIPCHK(hipEventRecord(L->ev[3], L->stream));
     c->n_seen += n_total;
     return SQ_OK;
 }
@@ -328,27 +369,30 @@ int sq_dedup_global(sq_ctx* c, const uint8_t* d_all_hashes, uint64_t n_total, ui
                     uint32_t my_n, uint8_t* d_is_new) {
     if (!c || (n_total && !d_all_hashes) || (my_n && !d_is_new) || my_first + my_n > n_total)
         return SQ_E_INVAL;
+    if (c->submitted != c->collected) return SQ_E_INVAL; // batches of sq_pack_submit are in flight: collect them first
+    sq_lane* const L = &c->ln[0];
     HIPCHK(hipSetDevice(c->device));
-    int r = dedup_async(c, d_all_hashes, n_total, my_first, my_n, d_is_new);
+    int r = dedup_async(c, L, d_all_hashes, n_total, my_first, my_n, d_is_new);
     if (r) return r;
-    HIPCHK(hipStreamSynchronize(c->stream));
-    if (n_total) HIPCHK(hipEventElapsedTime(&c->last.dedup_ms, c->ev[2], c->ev[3]));
+    HIPCHK(hipStreamSynchronize(L->stream));
+    if (n_total) HIPCHK(hipEventElapsedTime(&L->last.dedup_ms, L->ev[2], L->ev[3]));
     return SQ_OK;
 }
 
 int sq_calibrate_read_bw(sq_ctx* c, const uint8_t* d_buf, uint64_t nbytes, float* ms) {
     if (!c || !d_buf || !ms || ((uintptr_t)d_buf & 15)) return SQ_E_INVAL;
+    sq_lane* const L = &c->ln[0];
     HIPCHK(hipSetDevice(c->device));
-    int r = c->b_misc.ensure(256);
+    int r = L->b_misc.ensure(256);
     if (r) return r;
     dim3 block(256), grid((unsigned)(c->num_cu * 8));
-    HIPCHK(hipEventRecord(c->ev[6], c->stream));
-    hipLaunchKernelGGL(sqd::k_read_bw, grid, block, 0, c->stream, (const uint4*)d_buf, nbytes / 16,
-                       (u32*)c->b_misc.p);
+    HIPCHK(hipEventRecord(L->ev[6], L->stream));
+    hipLaunchKernelGGL(sqd::k_read_bw, grid, block, 0, L->stream, (const uint4*)d_buf, nbytes / 16,
+                       (u32*)L->b_misc.p);
     HIPCHK(hipGetLastError());
-    HIPCHK(hipEventRecord(c->ev[7], c->stream));
-    HIPCHK(hipStreamSynchronize(c->stream));
-    HIPCHK(hipEventElapsedTime(ms, c->ev[6], c->ev[7]));
+    HIPCHK(hipEventRecord(L->ev[7], L->stream));
+    HIPCHK(hipStreamSynchronize(L->stream));
+    HIPCHK(hipEventElapsedTime(ms, L->ev[6], L->ev[7]));
     return SQ_OK;
 }
 
@@ -357,17 +401,16 @@ int sq_calibrate_read_bw(sq_ctx* c, const uint8_t* d_buf, uint64_t nbytes, float
 // nullptr: the slots are a scratch buffer and the frames are then packed back to back into d_comp
 // (h_comp_off: n + 1 offsets).  Otherwise the slots ARE d_comp and the frames stay where they were
 // produced (h_comp_off: n slot offsets, h_comp_len: n frame lengths): no packing pass.
-static int compress_async(sq_ctx* c, const u8* d_data, const u64* h_off, const u32* h_len, u32 n,
-                          const u8* d_select, u8* d_comp, u64 comp_cap, u64* h_comp_off, u32* h_comp_len) {
-    (void)h_off;
+// Two halves: compress_enqueue puts every kernel and the small result copies on the lane's stream and returns;
+// compress_finish waits for them, hands out offsets / lengths and (packed layout) runs the packing pass.
+static int compress_enqueue(sq_ctx* c, sq_lane* L, const u8* d_data, const u32* h_len, u32 n, const u8* d_select,
+                            u8* d_comp, u64 comp_cap, bool in_place) {
     int r;
-    const bool in_place = h_comp_len != nullptr;
-    if (n == 0) {
-        if (!in_place) h_comp_off[0] = 0;
-        return SQ_OK;
-    }
+    L->job_n = n;
+    if (n == 0) return SQ_OK;
     // slot offsets on the host (prefix sum of bounds)
-    std::vector<u64> slot_off((size_t)n + 1);
+    std::vector<u64>& slot_off = L->job_slot_off;
+    slot_off.resize((size_t)n + 1);
     u64 acc = 0;
     u32 max_len = 0;
     for (u32 i = 0; i < n; i++) {
@@ -377,17 +420,17 @@ static int compress_async(sq_ctx* c, const u8* d_data, const u64* h_off, const u
     }
     slot_off[n] = acc;
     if (max_len > c->cfg.max_chunk) return SQ_E_INVAL;
-    if ((r = c->b_slot_off.ensure(((size_t)n + 1) * 8))) return r;
-    if ((r = c->b_frame_len.ensure((size_t)n * 4))) return r;
-    if ((r = c->b_out_off.ensure(((size_t)n + 1) * 8))) return r;
+    if ((r = L->b_slot_off.ensure(((size_t)n + 1) * 8))) return r;
+    if ((r = L->b_frame_len.ensure((size_t)n * 4))) return r;
+    if ((r = L->b_out_off.ensure(((size_t)n + 1) * 8))) return r;
     if (in_place) {
         if (acc > comp_cap) return SQ_E_CAP;
-    } else if ((r = c->b_slots.ensure(acc)))
+    } else if ((r = L->b_slots.ensure(acc)))
         return r;
-    u8* const d_slots = in_place ? d_comp : (u8*)c->b_slots.p;
-    HIPCHK(hipMemcpyAsync(c->b_slot_off.p, slot_off.data(), ((size_t)n + 1) * 8, hipMemcpyHostToDevice,
-                          c->stream));
-    HIPCHK(hipMemsetAsync(c->b_frame_len.p, 0, (size_t)n * 4, c->stream));
+    u8* const d_slots = in_place ? d_comp : (u8*)L->b_slots.p;
+    HIPCHK(hipMemcpyAsync(L->b_slot_off.p, slot_off.data(), ((size_t)n + 1) * 8, hipMemcpyHostToDevice,
+                          L->stream));
+    HIPCHK(hipMemsetAsync(L->b_frame_len.p, 0, (size_t)n * 4, L->stream));
 
     // persistent compressor waves, one private workspace each
     u32 waves = c->cfg.compress_waves ? c->cfg.compress_waves : (u32)c->num_cu * 8;
@@ -407,19 +450,19 @@ static int compress_async(sq_ctx* c, const u8* d_data, const u64* h_off, const u
         if (occ < 1) occ = 4;
         fwaves = c->cfg.compress_waves ? c->cfg.compress_waves * 2 : (u32)c->num_cu * (u32)occ;
         fwaves = std::min(fwaves, n);
-        if ((r = c->b_cert.ensure((size_t)n * 8))) return r;
-        if ((r = c->b_work.ensure(((size_t)2 * n + 2) * 4))) return r;
-        HIPCHK(hipMemsetAsync(c->b_work.p, 0, 8, c->stream));
+        if ((r = L->b_cert.ensure((size_t)n * 8))) return r;
+        if ((r = L->b_work.ensure(((size_t)2 * n + 2) * 4))) return r;
+        HIPCHK(hipMemsetAsync(L->b_work.p, 0, 8, L->stream));
     }
-    if ((r = c->b_ws.ensure((size_t)waves * ws_each + 256))) return r;
-    if (fast && (r = c->b_etab.ensure((size_t)fwaves * (etab_bytes + 256)))) return r;
+    if ((r = L->b_ws.ensure((size_t)waves * ws_each + 256))) return r;
+    if (fast && (r = L->b_etab.ensure((size_t)fwaves * (etab_bytes + 256)))) return r;
     // the pools keep their generation tags from launch to launch as long as nothing about them changes
-    const u32 ws_persist = (c->b_ws.p == c->ws_ptr_last && ws_each == c->ws_each_last && waves == c->ws_waves_last && fast) ? 1u : 0u;
-    const u32 etab_persist = (fast && c->b_etab.p == c->etab_ptr_last && etab_bytes == c->etab_bytes_last && fwaves == c->etab_waves_last) ? 1u : 0u;
-    c->ws_ptr_last = nullptr; // becomes valid again when this launch has completed
-    c->etab_ptr_last = nullptr;
-    if ((r = c->b_misc.ensure(256))) return r;
-    HIPCHK(hipMemsetAsync(c->b_misc.p, 0, 256, c->stream));
+    const u32 ws_persist = (L->b_ws.p == L->ws_ptr_last && ws_each == L->ws_each_last && waves == L->ws_waves_last && fast) ? 1u : 0u;
+    const u32 etab_persist = (fast && L->b_etab.p == L->etab_ptr_last && etab_bytes == L->etab_bytes_last && fwaves == L->etab_waves_last) ? 1u : 0u;
+    L->ws_ptr_last = nullptr; // becomes valid again when this launch has completed
+    L->etab_ptr_last = nullptr;
+    if ((r = L->b_misc.ensure(256))) return r;
+    HIPCHK(hipMemsetAsync(L->b_misc.p, 0, 256, L->stream));
 
     if (getenv("SQ_DEBUG")) {
         int nb = 0;
@@ -433,50 +476,50 @@ static int compress_async(sq_ctx* c, const u8* d_data, const u64* h_off, const u
         fprintf(stderr, "[squish_gpu] incompressible-chunk kernel: occupancy %d blocks/CU, regs %d, lds %zu, scratch %zu; waves %u, table %zu\n",
                 nb, fa.numRegs, fa.sharedSizeBytes, fa.localSizeBytes, fwaves, etab_bytes);
     }
-    c->last.fast_ms = 0;
+    L->last.fast_ms = 0;
     if (fast) {
-        HIPCHK(hipEventRecord(c->ev[8], c->stream));
-        hipLaunchKernelGGL(sqz::k_incompressible_batch, dim3(fwaves), dim3(64), 0, c->stream, d_data,
-                           (const u64*)c->b_off.p, (const u32*)c->b_len.p, d_select, n, d_slots,
-                           (const u64*)c->b_slot_off.p, (u32*)c->b_frame_len.p, (u32*)c->b_cert.p, (u8*)c->b_etab.p,
-                           (u64)etab_bytes, (u32*)c->b_misc.p + 32 /*queue*/, (const u32*)c->d_sched_tab,
-                           (u32)(getenv("SQ_FAST_DBG") ? atoi(getenv("SQ_FAST_DBG")) : 0), etab_persist, (u32*)c->b_work.p);
+        HIPCHK(hipEventRecord(L->ev[8], L->stream));
+        hipLaunchKernelGGL(sqz::k_incompressible_batch, dim3(fwaves), dim3(64), 0, L->stream, d_data,
+                           (const u64*)L->b_off.p, (const u32*)L->b_len.p, d_select, n, d_slots,
+                           (const u64*)L->b_slot_off.p, (u32*)L->b_frame_len.p, (u32*)L->b_cert.p, (u8*)L->b_etab.p,
+                           (u64)etab_bytes, (u32*)L->b_misc.p + 32 /*queue*/, (const u32*)c->d_sched_tab,
+                           (u32)(getenv("SQ_FAST_DBG") ? atoi(getenv("SQ_FAST_DBG")) : 0), etab_persist, (u32*)L->b_work.p);
         HIPCHK(hipGetLastError());
-        HIPCHK(hipEventRecord(c->ev[9], c->stream));
+        HIPCHK(hipEventRecord(L->ev[9], L->stream));
     }
     // Stage 2, the compressor proper, for everything stage 1 left undecided
-    HIPCHK(hipEventRecord(c->ev[4], c->stream));
+    HIPCHK(hipEventRecord(L->ev[4], L->stream));
     {
         dim3 block(64), grid(waves);
-        hipLaunchKernelGGL(sqz::k_compress_batch, grid, block, 0, c->stream, d_data, (const u64*)c->b_off.p,
-                           (const u32*)c->b_len.p, d_select, n, d_slots,
-                           (const u64*)c->b_slot_off.p, (u32*)c->b_frame_len.p, (u8*)c->b_ws.p,
-                           (u64)ws_each, (u32*)c->b_misc.p /*queue*/, (u32*)c->b_misc.p + 16 /*err*/,
-                           (const u32*)c->d_sched_tab, fast ? (const u32*)c->b_cert.p : (const u32*)nullptr, ws_persist,
-                           fast ? (const u32*)c->b_work.p : (const u32*)nullptr);
+        hipLaunchKernelGGL(sqz::k_compress_batch, grid, block, 0, L->stream, d_data, (const u64*)L->b_off.p,
+                           (const u32*)L->b_len.p, d_select, n, d_slots,
+                           (const u64*)L->b_slot_off.p, (u32*)L->b_frame_len.p, (u8*)L->b_ws.p,
+                           (u64)ws_each, (u32*)L->b_misc.p /*queue*/, (u32*)L->b_misc.p + 16 /*err*/,
+                           (const u32*)c->d_sched_tab, fast ? (const u32*)L->b_cert.p : (const u32*)nullptr, ws_persist,
+                           fast ? (const u32*)L->b_work.p : (const u32*)nullptr);
         HIPCHK(hipGetLastError());
     }
-    HIPCHK(hipEventRecord(c->ev[5], c->stream));
+    HIPCHK(hipEventRecord(L->ev[5], L->stream));
 #ifdef SQ_PROF
     if (const char* wd = getenv("SQ_WATCHDOG_MS")) {
         // bring-up aid of the PROFILING build only (libsquish_gpu_prof.so; the release library never terminates
         // its host process): if the compressor does not finish in time, dump wave 0..3 progress markers
         const long limit_ms = atol(wd);
         long waited = 0;
-        while (hipStreamQuery(c->stream) == hipErrorNotReady && waited < limit_ms) {
+        while (hipStreamQuery(L->stream) == hipErrorNotReady && waited < limit_ms) {
             struct timespec ts = {0, 5 * 1000 * 1000};
             nanosleep(&ts, nullptr);
             waited += 5;
         }
-        if (hipStreamQuery(c->stream) == hipErrorNotReady) {
+        if (hipStreamQuery(L->stream) == hipErrorNotReady) {
             hipStream_t s2;
             (void)hipStreamCreateWithFlags(&s2, hipStreamNonBlocking);
-            const sqz::WsLayout L = sqz::ws_layout(max_len);
+            const sqz::WsLayout WL = sqz::ws_layout(max_len);
             for (u32 w = 0; w < std::min(waves, 4u); w++) {
                 u32 tr[64];
                 // per-chunk layouts differ from the pool layout: dump the dummy area of every
                 // distinct layout used in this batch (bring-up batches are uniform)
-                (void)hipMemcpyAsync(tr, (u8*)c->b_ws.p + (size_t)w * ws_each + L.dummy, sizeof(tr),
+                (void)hipMemcpyAsync(tr, (u8*)L->b_ws.p + (size_t)w * ws_each + WL.dummy, sizeof(tr),
                                      hipMemcpyDeviceToHost, s2);
                 (void)hipStreamSynchronize(s2);
                 fprintf(stderr, "[squish_gpu watchdog] wave %u trace:", w);
@@ -489,42 +532,76 @@ static int compress_async(sq_ctx* c, const u8* d_data, const u64* h_off, const u
     }
 #endif
     if (in_place) {
-        HIPCHK(hipMemcpyAsync(h_comp_len, c->b_frame_len.p, (size_t)n * 4, hipMemcpyDeviceToHost, c->stream));
-        for (u32 i = 0; i < n; i++) h_comp_off[i] = slot_off[i];
+        if (L->h_len_cap < (size_t)n * 4) {
+            if (L->h_len_pinned) (void)hipHostFree(L->h_len_pinned);
+            L->h_len_pinned = nullptr;
+            L->h_len_cap = 0;
+            size_t const want = (size_t)n * 4 + ((size_t)n >> 1) + 4096;
+            if (hipHostMalloc(&L->h_len_pinned, want, hipHostMallocDefault) != hipSuccess) return SQ_E_NOMEM;
+            L->h_len_cap = want;
+        }
+        HIPCHK(hipMemcpyAsync(L->h_len_pinned, L->b_frame_len.p, (size_t)n * 4, hipMemcpyDeviceToHost, L->stream));
     } else {
-        hipLaunchKernelGGL(sqd::k_scan_lengths, dim3(1), dim3(1024), 0, c->stream, (const u32*)c->b_frame_len.p,
-                           n, (u64*)c->b_out_off.p);
+        if ((r = L->b_out_off.ensure(((size_t)n + 1) * 8))) return r;
+        hipLaunchKernelGGL(sqd::k_scan_lengths, dim3(1), dim3(1024), 0, L->stream, (const u32*)L->b_frame_len.p,
+                           n, (u64*)L->b_out_off.p);
         HIPCHK(hipGetLastError());
-        HIPCHK(hipMemcpyAsync(h_comp_off, c->b_out_off.p, ((size_t)n + 1) * 8, hipMemcpyDeviceToHost,
-                              c->stream));
     }
-    u32* h_err = (u32*)c->h_pinned;
-    HIPCHK(hipMemcpyAsync(h_err, (u32*)c->b_misc.p + 16, 4, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(hipMemcpyAsync(h_err + 1, (u32*)c->b_misc.p + 33, 4, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(hipStreamSynchronize(c->stream));
-    HIPCHK(hipEventElapsedTime(&c->last.compress_ms, c->ev[4], c->ev[5]));
-    if (fast) HIPCHK(hipEventElapsedTime(&c->last.fast_ms, c->ev[8], c->ev[9]));
-    c->last.fast_decided = fast ? h_err[1] : 0;
-    c->work_n = fast ? n : 0;
+    u32* h_err = (u32*)L->h_pinned;
+    HIPCHK(hipMemcpyAsync(h_err, (u32*)L->b_misc.p + 16, 4, hipMemcpyDeviceToHost, L->stream));
+    HIPCHK(hipMemcpyAsync(h_err + 1, (u32*)L->b_misc.p + 33, 4, hipMemcpyDeviceToHost, L->stream));
+    L->job_max_len = max_len;
+    L->job_waves = waves;
+    L->job_fwaves = fwaves;
+    L->job_ws_each = ws_each;
+    L->job_etab_bytes = etab_bytes;
+    L->job_fast = fast;
+    return SQ_OK;
+}
+
+static int compress_finish(sq_ctx* c, sq_lane* L, u8* d_comp, u64 comp_cap, u64* h_comp_off, u32* h_comp_len, bool in_place) {
+    (void)c;
+    u32 const n = L->job_n;
+    if (n == 0) {
+        if (!in_place) h_comp_off[0] = 0;
+        return SQ_OK;
+    }
+    u32 const max_len = L->job_max_len, waves = L->job_waves, fwaves = L->job_fwaves;
+    size_t const ws_each = L->job_ws_each, etab_bytes = L->job_etab_bytes;
+    bool const fast = L->job_fast;
+    std::vector<u64> const& slot_off = L->job_slot_off;
+    u32* h_err = (u32*)L->h_pinned;
+    (void)max_len;
+    if (!in_place)
+        HIPCHK(hipMemcpyAsync(h_comp_off, L->b_out_off.p, ((size_t)n + 1) * 8, hipMemcpyDeviceToHost, L->stream));
+    HIPCHK(hipStreamSynchronize(L->stream));
+    if (in_place) {
+        memcpy(h_comp_len, L->h_len_pinned, (size_t)n * 4);
+        for (u32 i = 0; i < n; i++) h_comp_off[i] = slot_off[i];
+    }
+    HIPCHK(hipEventElapsedTime(&L->last.compress_ms, L->ev[4], L->ev[5]));
+    if (fast) HIPCHK(hipEventElapsedTime(&L->last.fast_ms, L->ev[8], L->ev[9]));
+    L->last.fast_decided = fast ? h_err[1] : 0;
+    L->work_n = fast ? n : 0;
     if (!*h_err) { // both kernels ran to completion: their saved table states are good for the next launch
-        c->ws_ptr_last = c->b_ws.p;
-        c->ws_each_last = ws_each;
-        c->ws_waves_last = waves;
+        L->ws_ptr_last = L->b_ws.p;
+        L->ws_each_last = ws_each;
+        L->ws_waves_last = waves;
         if (fast) {
-            c->etab_ptr_last = c->b_etab.p;
-            c->etab_bytes_last = etab_bytes;
-            c->etab_waves_last = fwaves;
+            L->etab_ptr_last = L->b_etab.p;
+            L->etab_bytes_last = etab_bytes;
+            L->etab_waves_last = fwaves;
         }
     }
 #ifdef SQ_PROF
     if (fast) { // stage 1 phase timers (one 256-byte slice per wave: its saved state, then 8 tick sums)
         std::vector<unsigned long long> tot(8, 0), one(8);
         for (u32 w = 0; w < fwaves; w++) {
-            (void)hipMemcpy(one.data(), (u8*)c->b_etab.p + (size_t)w * (etab_bytes + 256) + etab_bytes + 32, 64, hipMemcpyDeviceToHost);
+            (void)hipMemcpy(one.data(), (u8*)L->b_etab.p + (size_t)w * (etab_bytes + 256) + etab_bytes + 32, 64, hipMemcpyDeviceToHost);
             for (int k = 0; k < 8; k++) tot[k] += one[k];
         }
         static const char* nm1[6] = {"build", "scan_loop", "lookups(in scan)", "hit_resolution", "precheck+frame", "chunk_total"};
-        fprintf(stderr, "[squish_gpu prof] stage 1: waves=%u kernel=%.2f ms; per-wave mean ms:", fwaves, c->last.fast_ms);
+        fprintf(stderr, "[squish_gpu prof] stage 1: waves=%u kernel=%.2f ms; per-wave mean ms:", fwaves, L->last.fast_ms);
         for (int k = 0; k < 6; k++) fprintf(stderr, " %s=%.3f", nm1[k], (double)tot[k] / fwaves / 1e5);
         fprintf(stderr, "\n");
     }
@@ -533,7 +610,7 @@ static int compress_async(sq_ctx* c, const u8* d_data, const u64* h_off, const u
         std::vector<std::pair<unsigned long long, unsigned long long>> longest; // (ticks, pass<<32 | chunk) per wave
         std::vector<unsigned long long> fin;                                    // when each wave finished its last chunk
         for (u32 w = 0; w < waves; w++) {
-            (void)hipMemcpy(one.data(), (u8*)c->b_ws.p + (size_t)(w + 1) * ws_each - 1024, 71 * 8, hipMemcpyDeviceToHost);
+            (void)hipMemcpy(one.data(), (u8*)L->b_ws.p + (size_t)(w + 1) * ws_each - 1024, 71 * 8, hipMemcpyDeviceToHost);
             for (int k = 0; k < 33; k++)
                 if (k < 29 || k > 31) tot[k] += one[k];
             if (one[29] > worst[29]) worst = one;
@@ -549,7 +626,7 @@ static int compress_async(sq_ctx* c, const u8* d_data, const u64* h_off, const u
             fprintf(stderr, " %.3f(%u:%u", (double)e.first / 1e5, (unsigned)(e.second >> 32), (unsigned)e.second);
             if (fast) { // where stage 1's certificates ended (positions; 2 = chunk start, 131074 = block 1)
                 u32 ce[2] = {0, 0};
-                (void)hipMemcpy(ce, (u32*)c->b_cert.p + 2 * (size_t)(u32)e.second, 8, hipMemcpyDeviceToHost);
+                (void)hipMemcpy(ce, (u32*)L->b_cert.p + 2 * (size_t)(u32)e.second, 8, hipMemcpyDeviceToHost);
                 fprintf(stderr, " cert %u/%u", ce[0], ce[1] & 0x7FFFFFFFu);
             }
             fprintf(stderr, ")");
@@ -574,7 +651,7 @@ static int compress_async(sq_ctx* c, const u8* d_data, const u64* h_off, const u
             for (int k = 0; k < 29; k++) fprintf(stderr, " %s=%.3f", nmL[k], (k >= 16 && k < 24) ? (double)wv[42 + k] : (double)wv[42 + k] / 1e5);
             fprintf(stderr, "\n");
         }
-        fprintf(stderr, "[squish_gpu prof] waves=%u kernel=%.2f ms; per-wave mean ms:", waves, c->last.compress_ms);
+        fprintf(stderr, "[squish_gpu prof] waves=%u kernel=%.2f ms; per-wave mean ms:", waves, L->last.compress_ms);
         for (int k = 0; k < 33; k++)
             if (nm[k][0] != '-') fprintf(stderr, " %s=%.3f", nm[k], (k >= 16 && k < 24) || k == 32 ? (double)tot[k] / waves : (double)tot[k] / waves / 1e5);
         fprintf(stderr, "\n");
@@ -582,27 +659,27 @@ static int compress_async(sq_ctx* c, const u8* d_data, const u64* h_off, const u
 #endif
     if (getenv("SQ_DEBUG_STATS") && fast) { // certificate ends of the first chunks, as stage 1 left them
         std::vector<u32> ce(2 * (size_t)std::min(n, 24u));
-        (void)hipMemcpy(ce.data(), c->b_cert.p, ce.size() * 4, hipMemcpyDeviceToHost);
+        (void)hipMemcpy(ce.data(), L->b_cert.p, ce.size() * 4, hipMemcpyDeviceToHost);
         fprintf(stderr, "[squish_gpu stats] cert ends:");
         for (size_t i = 0; i < ce.size(); i += 2) fprintf(stderr, " %u/%u", ce[i], ce[i + 1] & 0x7FFFFFFFu);
         fprintf(stderr, "\n");
     }
     if (getenv("SQ_DEBUG_STATS")) { // per-wave statistics words of the last chunk each wave compressed
-        const sqz::WsLayout L = sqz::ws_layout(max_len);
+        const sqz::WsLayout WL = sqz::ws_layout(max_len);
         for (u32 w = 0; w < waves && w < 6; w++) {
             u32 tr[64];
-            (void)hipMemcpy(tr, (u8*)c->b_ws.p + (size_t)w * ws_each + L.dummy, sizeof(tr), hipMemcpyDeviceToHost);
+            (void)hipMemcpy(tr, (u8*)L->b_ws.p + (size_t)w * ws_each + WL.dummy, sizeof(tr), hipMemcpyDeviceToHost);
             fprintf(stderr, "[squish_gpu stats] wave %u: n=%u eager=%u repairs=%u live=%u skips=%u epochs=%u specfail=%u replays=%u certified=%u dbg=%u,%u,%u,%u\n",
                     w, tr[8 + 1], tr[8 + 30], tr[8 + 31], tr[8 + 32], tr[8 + 33], tr[8 + 34], tr[8 + 35], tr[8 + 36], tr[8 + 37],
                     tr[8 + 40], tr[8 + 41], tr[8 + 42], tr[8 + 43]);
         }
     }
     if (*h_err && getenv("SQ_DEBUG")) {
-        const sqz::WsLayout L = sqz::ws_layout(max_len);
+        const sqz::WsLayout WL = sqz::ws_layout(max_len);
         int shown = 0;
         for (u32 w = 0; w < waves && shown < 8; w++) {
             u32 tr[64];
-            (void)hipMemcpy(tr, (u8*)c->b_ws.p + (size_t)w * ws_each + L.dummy, sizeof(tr), hipMemcpyDeviceToHost);
+            (void)hipMemcpy(tr, (u8*)L->b_ws.p + (size_t)w * ws_each + WL.dummy, sizeof(tr), hipMemcpyDeviceToHost);
             if (tr[8 + 16]) {
                 fprintf(stderr, "[squish_gpu fault] wave %u:", w);
                 for (int k = 8; k < 8 + 24; k++) fprintf(stderr, " %u", tr[k]);
@@ -613,23 +690,33 @@ static int compress_async(sq_ctx* c, const u8* d_data, const u64* h_off, const u
     }
     if (*h_err) return SQ_E_COMPRESS;
     if (in_place) {
-        c->last.compact_ms = 0;
+        L->last.compact_ms = 0;
         return SQ_OK;
     }
     if (h_comp_off[n] > comp_cap) return SQ_E_CAP;
-    HIPCHK(hipEventRecord(c->ev[6], c->stream));
+    HIPCHK(hipEventRecord(L->ev[6], L->stream));
     {
         const u32 wpb = 4;
         dim3 grid((n + wpb - 1) / wpb), block(64 * wpb);
-        hipLaunchKernelGGL(sqd::k_compact_frames, grid, block, 0, c->stream, (const u8*)c->b_slots.p,
-                           (const u64*)c->b_slot_off.p, (const u32*)c->b_frame_len.p,
-                           (const u64*)c->b_out_off.p, n, d_comp);
+        hipLaunchKernelGGL(sqd::k_compact_frames, grid, block, 0, L->stream, (const u8*)L->b_slots.p,
+                           (const u64*)L->b_slot_off.p, (const u32*)L->b_frame_len.p,
+                           (const u64*)L->b_out_off.p, n, d_comp);
         HIPCHK(hipGetLastError());
     }
-    HIPCHK(hipEventRecord(c->ev[7], c->stream));
-    HIPCHK(hipStreamSynchronize(c->stream));
-    HIPCHK(hipEventElapsedTime(&c->last.compact_ms, c->ev[6], c->ev[7]));
+    HIPCHK(hipEventRecord(L->ev[7], L->stream));
+    HIPCHK(hipStreamSynchronize(L->stream));
+    HIPCHK(hipEventElapsedTime(&L->last.compact_ms, L->ev[6], L->ev[7]));
     return SQ_OK;
+}
+
+static int compress_async(sq_ctx* c, sq_lane* L, const u8* d_data, const u64* h_off, const u32* h_len, u32 n,
+                          const u8* d_select, u8* d_comp, u64 comp_cap, u64* h_comp_off, u32* h_comp_len) {
+    (void)h_off;
+    c->last_lane = 0;
+    bool const in_place = h_comp_len != nullptr;
+    int const r = compress_enqueue(c, L, d_data, h_len, n, d_select, d_comp, comp_cap, in_place);
+    if (r) return r;
+    return compress_finish(c, L, d_comp, comp_cap, h_comp_off, h_comp_len, in_place);
 }
 #endif
 
@@ -642,10 +729,12 @@ int sq_compress_batch(sq_ctx* c, const uint8_t* d_data, const uint64_t* h_off, c
     return SQ_E_COMPRESS;
 #else
     if (!c || !h_comp_off || (n && (!d_data || !h_off || !h_len || !d_comp))) return SQ_E_INVAL;
+    if (c->submitted != c->collected) return SQ_E_INVAL; // batches of sq_pack_submit are in flight: collect them first
+    sq_lane* const L = &c->ln[0];
     HIPCHK(hipSetDevice(c->device));
     int r;
-    if ((r = upload_off_len(c, h_off, h_len, n))) return r;
-    return compress_async(c, d_data, h_off, h_len, n, d_select, d_comp, comp_cap, h_comp_off, nullptr);
+    if ((r = upload_off_len(c, L, h_off, h_len, n))) return r;
+    return compress_async(c, L, d_data, h_off, h_len, n, d_select, d_comp, comp_cap, h_comp_off, nullptr);
 #endif
 }
 
@@ -658,26 +747,29 @@ int sq_compress_batch_slots(sq_ctx* c, const uint8_t* d_data, const uint64_t* h_
     return SQ_E_COMPRESS;
 #else
     if (!c || (n && (!d_data || !h_off || !h_len || !d_comp || !h_comp_off || !h_comp_len))) return SQ_E_INVAL;
+    if (c->submitted != c->collected) return SQ_E_INVAL; // batches of sq_pack_submit are in flight: collect them first
+    sq_lane* const L = &c->ln[0];
     HIPCHK(hipSetDevice(c->device));
     int r;
-    if ((r = upload_off_len(c, h_off, h_len, n))) return r;
-    return compress_async(c, d_data, h_off, h_len, n, d_select, d_comp, comp_cap, h_comp_off, h_comp_len);
+    if ((r = upload_off_len(c, L, h_off, h_len, n))) return r;
+    return compress_async(c, L, d_data, h_off, h_len, n, d_select, d_comp, comp_cap, h_comp_off, h_comp_len);
 #endif
 }
 
 int sq_debug_stage2_list(sq_ctx* c, uint32_t* h_out, uint32_t cap, uint32_t* n_out) {
     if (!c || !n_out || (cap && !h_out)) return SQ_E_INVAL;
+    sq_lane* const L = &c->ln[c->last_lane & 1];
     *n_out = 0;
-    if (!c->work_n) return SQ_OK;
+    if (!L->work_n) return SQ_OK;
     HIPCHK(hipSetDevice(c->device));
-    HIPCHK(hipStreamSynchronize(c->stream));
+    HIPCHK(hipStreamSynchronize(L->stream));
     u32 cnt[2] = {0, 0};
-    HIPCHK(hipMemcpy(cnt, c->b_work.p, 8, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(cnt, L->b_work.p, 8, hipMemcpyDeviceToHost));
     u32 k = 0;
     for (int pass = 0; pass < 2; pass++) {
         u32 const take = std::min(cnt[pass], cap - k);
         if (take)
-            HIPCHK(hipMemcpy(h_out + k, (u32*)c->b_work.p + 2 + (pass ? c->work_n : 0u), (size_t)take * 4, hipMemcpyDeviceToHost));
+            HIPCHK(hipMemcpy(h_out + k, (u32*)L->b_work.p + 2 + (pass ? L->work_n : 0u), (size_t)take * 4, hipMemcpyDeviceToHost));
         k += take;
     }
     *n_out = k;
@@ -699,6 +791,8 @@ int sq_pack_batch(sq_ctx* c, const uint8_t* data, const uint64_t* off, const uin
     return SQ_E_COMPRESS;
 #else
     if (!c || !comp_off || (n && (!data || !off || !len || !hashes || !is_new || !comp))) return SQ_E_INVAL;
+    if (c->submitted != c->collected) return SQ_E_INVAL; // batches of sq_pack_submit are in flight: collect them first
+    sq_lane* const L = &c->ln[0];
     HIPCHK(hipSetDevice(c->device));
     if (n == 0) {
         comp_off[0] = 0;
@@ -723,50 +817,111 @@ int sq_pack_batch(sq_ctx* c, const uint8_t* data, const uint64_t* off, const uin
             off2[i] = acc;
             acc += ((u64)len[i] + 255) & ~(u64)255;
         }
-        if ((r = c->b_stage_in.ensure(acc + 256))) return r;
-        if ((r = c->b_hashes.ensure((size_t)n * 16))) return r;
-        if ((r = c->b_isnew.ensure(n))) return r;
-        if ((r = c->b_stage_out.ensure(comp_cap ? comp_cap : 16))) return r;
+        if ((r = L->b_stage_in.ensure(acc + 256))) return r;
+        if ((r = L->b_hashes.ensure((size_t)n * 16))) return r;
+        if ((r = L->b_isnew.ensure(n))) return r;
+        if ((r = L->b_stage_out.ensure(comp_cap ? comp_cap : 16))) return r;
         bool span = true; // the host batch already has the staging layout: one transfer
         for (u32 i = 0; i < n && span; i++) span = (off[i] - off[0]) == off2[i];
         if (span)
-            HIPCHK(hipMemcpyAsync(c->b_stage_in.p, data + off[0], off2[n - 1] + len[n - 1], hipMemcpyHostToDevice, c->stream));
+            HIPCHK(hipMemcpyAsync(L->b_stage_in.p, data + off[0], off2[n - 1] + len[n - 1], hipMemcpyHostToDevice, L->stream));
         else
             for (u32 i = 0; i < n; i++)
-                HIPCHK(hipMemcpyAsync((u8*)c->b_stage_in.p + off2[i], data + off[i], len[i],
-                                      hipMemcpyHostToDevice, c->stream));
-        d_data = (const u8*)c->b_stage_in.p;
-        d_hashes = (u8*)c->b_hashes.p;
-        d_isnew = (u8*)c->b_isnew.p;
-        d_comp = (u8*)c->b_stage_out.p;
+                HIPCHK(hipMemcpyAsync((u8*)L->b_stage_in.p + off2[i], data + off[i], len[i],
+                                      hipMemcpyHostToDevice, L->stream));
+        d_data = (const u8*)L->b_stage_in.p;
+        d_hashes = (u8*)L->b_hashes.p;
+        d_isnew = (u8*)L->b_isnew.p;
+        d_comp = (u8*)L->b_stage_out.p;
         use_off = off2.data();
     }
-    if ((r = upload_off_len(c, use_off, len, n))) return r;
-    if ((r = launch_hash(c, d_data, n, d_hashes))) return r;
+    if ((r = upload_off_len(c, L, use_off, len, n))) return r;
+    if ((r = launch_hash(c, L, d_data, n, d_hashes))) return r;
     // The dedup commit is provisional until the frames are out: if the compress stage fails (SQ_E_CAP: the
     // frames do not fit comp_cap; SQ_E_COMPRESS; an allocation), the set, its unique count and the global
     // chunk index are put back, so the caller can retry the same batch (squish_gpu.h: "nothing is committed").
     const u64 seen_before = c->n_seen;
-    HIPCHK(hipMemcpyAsync(c->d_unique + 1, c->d_unique, sizeof(unsigned long long), hipMemcpyDeviceToDevice, c->stream));
-    if ((r = dedup_async(c, d_hashes, n, 0, n, d_isnew))) return r; // (fails before touching the set)
-    r = compress_async(c, d_data, use_off, len, n, d_isnew, d_comp, comp_cap, comp_off, nullptr);
+    HIPCHK(hipMemcpyAsync(c->d_unique + 1, c->d_unique, sizeof(unsigned long long), hipMemcpyDeviceToDevice, L->stream));
+    if ((r = dedup_async(c, L, d_hashes, n, 0, n, d_isnew))) return r; // (fails before touching the set)
+    r = compress_async(c, L, d_data, use_off, len, n, d_isnew, d_comp, comp_cap, comp_off, nullptr);
     if (r) {
         const u64 nslots = c->table_mask + 1;
         hipLaunchKernelGGL(sqd::k_dedup_rollback, dim3((unsigned)std::min<u64>((nslots + 255) / 256, 4096)), dim3(256), 0,
-                           c->stream, c->d_table, nslots, seen_before);
-        (void)hipMemcpyAsync(c->d_unique, c->d_unique + 1, sizeof(unsigned long long), hipMemcpyDeviceToDevice, c->stream);
-        (void)hipStreamSynchronize(c->stream);
+                           L->stream, c->d_table, nslots, seen_before);
+        (void)hipMemcpyAsync(c->d_unique, c->d_unique + 1, sizeof(unsigned long long), hipMemcpyDeviceToDevice, L->stream);
+        (void)hipStreamSynchronize(L->stream);
         c->n_seen = seen_before;
         return r;
     }
-    HIPCHK(hipEventElapsedTime(&c->last.hash_ms, c->ev[0], c->ev[1]));
-    HIPCHK(hipEventElapsedTime(&c->last.dedup_ms, c->ev[2], c->ev[3]));
+    HIPCHK(hipEventElapsedTime(&L->last.hash_ms, L->ev[0], L->ev[1]));
+    HIPCHK(hipEventElapsedTime(&L->last.dedup_ms, L->ev[2], L->ev[3]));
     if (!dev) {
-        HIPCHK(hipMemcpyAsync(hashes, d_hashes, (size_t)n * 16, hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(hipMemcpyAsync(is_new, d_isnew, n, hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(hipMemcpyAsync(comp, d_comp, comp_off[n], hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(hipStreamSynchronize(c->stream));
+        HIPCHK(hipMemcpyAsync(hashes, d_hashes, (size_t)n * 16, hipMemcpyDeviceToHost, L->stream));
+        HIPCHK(hipMemcpyAsync(is_new, d_isnew, n, hipMemcpyDeviceToHost, L->stream));
+        HIPCHK(hipMemcpyAsync(comp, d_comp, comp_off[n], hipMemcpyDeviceToHost, L->stream));
+        HIPCHK(hipStreamSynchronize(L->stream));
     }
+    return SQ_OK;
+#endif
+}
+
+// ---- pipelined form: two batches in flight on the context's two lanes -------------------------------------------
+int sq_pack_submit(sq_ctx* c, const uint8_t* d_data, const uint64_t* h_off, const uint32_t* h_len, uint32_t n,
+                   uint8_t* d_hashes, uint8_t* d_is_new, uint8_t* d_comp, uint64_t comp_cap, uint32_t flags) {
+#ifdef SQ_NO_COMPRESS
+    (void)c; (void)d_data; (void)h_off; (void)h_len; (void)n; (void)d_hashes; (void)d_is_new; (void)d_comp; (void)comp_cap; (void)flags;
+    return SQ_E_COMPRESS;
+#else
+    if (!c || (n && (!d_data || !h_off || !h_len || !d_hashes || !d_is_new || !d_comp))) return SQ_E_INVAL;
+    if (c->submitted - c->collected >= 2) return SQ_E_INVAL; // both lanes busy: collect one with sq_pack_wait first
+    HIPCHK(hipSetDevice(c->device));
+    for (u32 i = 0; i < n; i++)
+        if (h_len[i] > c->cfg.max_chunk) return SQ_E_INVAL;
+    if (sq_slots_bound(h_len, n) > comp_cap) return SQ_E_CAP;
+    sq_lane* const L = &c->ln[c->submitted & 1];
+    sq_lane* const other = &c->ln[(c->submitted & 1) ^ 1];
+    int r;
+    if ((r = upload_off_len(c, L, h_off, h_len, n))) return r;
+    if ((r = launch_hash(c, L, d_data, n, d_hashes))) return r; // (does not depend on the batch before)
+    // the dedup set is shared: this batch's reset / insert must follow the previous batch's dedup kernels
+    if (other->busy) HIPCHK(hipStreamWaitEvent(L->stream, other->dedup_done, 0));
+    if (flags & 1u) {
+        HIPCHK(hipMemsetAsync(c->d_table, 0, (c->table_mask + 1) * sizeof(u32), L->stream));
+        HIPCHK(hipMemsetAsync(c->d_unique, 0, 64, L->stream));
+        c->n_seen = 0;
+    }
+    L->job_seen_before = c->n_seen;
+    if ((r = dedup_async(c, L, d_hashes, n, 0, n, d_is_new))) return r; // (fails before touching the set)
+    HIPCHK(hipEventRecord(L->dedup_done, L->stream));
+    if ((r = compress_enqueue(c, L, d_data, h_len, n, d_is_new, d_comp, comp_cap, true))) {
+        (void)hipStreamSynchronize(L->stream);
+        return r;
+    }
+    L->busy = true;
+    c->submitted++;
+    return SQ_OK;
+#endif
+}
+
+int sq_pack_wait(sq_ctx* c, uint64_t* h_comp_off, uint32_t* h_comp_len) {
+#ifdef SQ_NO_COMPRESS
+    (void)c; (void)h_comp_off; (void)h_comp_len;
+    return SQ_E_COMPRESS;
+#else
+    if (!c || c->submitted == c->collected) return SQ_E_INVAL;
+    sq_lane* const L = &c->ln[c->collected & 1];
+    if (L->job_n && (!h_comp_off || !h_comp_len)) return SQ_E_INVAL;
+    HIPCHK(hipSetDevice(c->device));
+    int const r = compress_finish(c, L, nullptr, 0, h_comp_off, h_comp_len, true);
+    L->busy = false;
+    c->collected++;
+    if (r) return r;
+    if (L->job_n) {
+        HIPCHK(hipEventElapsedTime(&L->last.hash_ms, L->ev[0], L->ev[1]));
+        HIPCHK(hipEventElapsedTime(&L->last.dedup_ms, L->ev[2], L->ev[3]));
+    }
+    c->last_lane = (u32)(L - c->ln);
+    c->ln[0].last = L->last; // sq_last_timings reports the batch collected last
     return SQ_OK;
 #endif
 }
@@ -809,14 +964,15 @@ int sq_hash_chunk(const uint8_t* chunk, size_t len, uint8_t out[SQ_HASH_BYTES]) 
     sq_ctx* c;
     int r = default_ctx(&c);
     if (r) return r;
+    sq_lane* const L = &c->ln[0];
     HIPCHK(hipSetDevice(c->device));
-    if ((r = c->b_stage_in.ensure(len + 256))) return r;
-    if ((r = c->b_hashes.ensure(16))) return r;
-    if (len) HIPCHK(hipMemcpyAsync(c->b_stage_in.p, chunk, len, hipMemcpyHostToDevice, c->stream));
+    if ((r = L->b_stage_in.ensure(len + 256))) return r;
+    if ((r = L->b_hashes.ensure(16))) return r;
+    if (len) HIPCHK(hipMemcpyAsync(L->b_stage_in.p, chunk, len, hipMemcpyHostToDevice, L->stream));
     u64 off = 0;
     u32 l32 = (u32)len;
-    if ((r = sq_hash_batch(c, (const u8*)c->b_stage_in.p, &off, &l32, 1, (u8*)c->b_hashes.p))) return r;
-    HIPCHK(hipMemcpy(out, c->b_hashes.p, 16, hipMemcpyDeviceToHost));
+    if ((r = sq_hash_batch(c, (const u8*)L->b_stage_in.p, &off, &l32, 1, (u8*)L->b_hashes.p))) return r;
+    HIPCHK(hipMemcpy(out, L->b_hashes.p, 16, hipMemcpyDeviceToHost));
     return SQ_OK;
 }
 
@@ -830,18 +986,19 @@ int sq_compress_chunk(const uint8_t* chunk, size_t len, uint8_t* dst, size_t cap
     sq_ctx* c;
     int r = default_ctx(&c);
     if (r) return r;
+    sq_lane* const L = &c->ln[0];
     HIPCHK(hipSetDevice(c->device));
     const size_t bound = sq_compress_bound(len) + 64;
-    if ((r = c->b_stage_in.ensure(len + 256))) return r;
-    if ((r = c->b_stage_out.ensure(bound))) return r;
-    if (len) HIPCHK(hipMemcpyAsync(c->b_stage_in.p, chunk, len, hipMemcpyHostToDevice, c->stream));
+    if ((r = L->b_stage_in.ensure(len + 256))) return r;
+    if ((r = L->b_stage_out.ensure(bound))) return r;
+    if (len) HIPCHK(hipMemcpyAsync(L->b_stage_in.p, chunk, len, hipMemcpyHostToDevice, L->stream));
     u64 off = 0, coff[2] = {0, 0};
     u32 l32 = (u32)len;
-    if ((r = sq_compress_batch(c, (const u8*)c->b_stage_in.p, &off, &l32, 1, nullptr,
-                               (u8*)c->b_stage_out.p, bound, coff)))
+    if ((r = sq_compress_batch(c, (const u8*)L->b_stage_in.p, &off, &l32, 1, nullptr,
+                               (u8*)L->b_stage_out.p, bound, coff)))
         return r;
     if (coff[1] > cap) return SQ_E_CAP;
-    HIPCHK(hipMemcpy(dst, c->b_stage_out.p, coff[1], hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(dst, L->b_stage_out.p, coff[1], hipMemcpyDeviceToHost));
     *out_len = (size_t)coff[1];
     return SQ_OK;
 #endif

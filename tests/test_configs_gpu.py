@@ -268,3 +268,62 @@ def test_pack_batch_rejects_mixed_pointer_sides():
         st2.close()
     finally:
         st.close()
+
+
+def test_pack_submit_wait_two_batches_in_flight(oracle):
+    """sq_pack_submit / sq_pack_wait: two batches in flight on one context's two lanes.  Four batches of mixed
+    content with duplicates inside and ACROSS batches (the dedup set is shared and stays in batch order), submitted
+    back to back with at most two in flight: flags, unique count and every frame equal the synchronous path's and the
+    oracle's; a third submit without a wait is refused; the synchronous calls are refused while batches are in flight."""
+    import torch
+    import squishrs_amd
+    from squishrs_amd import _lib
+    L = 262144
+    base = [corpus.random_bytes(81, i, L) for i in range(40)] + [corpus.planted(7, L, 0), corpus.text_like(9, L), corpus.planted(8, L, 9)]
+    plans = [list(range(0, 20)) + [3, 40, 41], [5, 20, 21, 22, 41, 23, 42], list(range(24, 40)) + [0, 42, 24], [41, 1, 2]]
+    st = squishrs_amd.ChunkStore(device=0, max_chunk=L, dedup_capacity=1 << 12)
+    try:
+        bufs = []
+        for plan in plans:
+            n = len(plan)
+            data = torch.frombuffer(bytearray(b"".join(base[i] for i in plan)), dtype=torch.uint8).cuda()
+            offs = np.arange(n, dtype=np.uint64) * np.uint64(L)
+            lens = np.full(n, L, dtype=np.uint32)
+            bufs.append((data, offs, lens, torch.zeros(n * 16, dtype=torch.uint8, device="cuda"),
+                         torch.zeros(n, dtype=torch.uint8, device="cuda"),
+                         torch.empty(st.slots_bound(lens), dtype=torch.uint8, device="cuda")))
+        results = []
+        st.pack_submit(*bufs[0], reset=True)
+        st.pack_submit(*bufs[1])
+        with pytest.raises(squishrs_amd.SquishError):       # both lanes busy
+            st.pack_submit(*bufs[2])
+        with pytest.raises(squishrs_amd.SquishError):       # synchronous calls wait their turn
+            st.reset()
+        results.append(st.pack_wait(len(plans[0])))
+        st.pack_submit(*bufs[2])
+        results.append(st.pack_wait(len(plans[1])))
+        st.pack_submit(*bufs[3])
+        results.append(st.pack_wait(len(plans[2])))
+        results.append(st.pack_wait(len(plans[3])))
+        seen = set()
+        for plan, (data, offs, lens, hashes, is_new, comp), (coff, clen) in zip(plans, bufs, results):
+            nn = is_new.cpu().numpy()
+            hh = hashes.cpu().numpy().reshape(-1, 16)
+            for j, i in enumerate(plan):
+                assert hh[j].tobytes() == oracle.hash_chunk(base[i])
+                new = i not in seen
+                seen.add(i)
+                assert bool(nn[j]) == new, (plan, j)
+                if new:
+                    f = comp[int(coff[j]):int(coff[j]) + int(clen[j])].cpu().numpy().tobytes()
+                    assert f == oracle.compress_chunk(base[i]), (plan, j)
+                else:
+                    assert clen[j] == 0
+        assert st.len() == len(seen)
+        # and the synchronous path still works on the same context afterwards
+        st.reset()
+        r = st.insert_batch([base[41], base[0], base[41]])
+        assert [x.compressed_data is not None for x in r] == [True, True, False]
+        assert r[0].compressed_data == oracle.compress_chunk(base[41])
+    finally:
+        st.close()
