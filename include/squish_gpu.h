@@ -131,8 +131,7 @@ int sq_compress_batch_slots(sq_ctx* ctx, const uint8_t* d_data, const uint64_t* 
                             uint32_t* h_comp_len);
 uint64_t sq_slots_bound(const uint32_t* h_len, uint32_t n);
 
-/* ---- pipelined form (device pointers): hash -> dedup -> compress (slots layout) of one batch is ENQUEUED and the
- * call returns; up to two batches may be in flight on one context (its two internal "lanes": own stream, events,
+/* ---- pipelined form: hash -> dedup -> compress of one batch is ENQUEUED and the call returns; up to two batches may be in flight on one context (its two internal "lanes": own stream, events,
  * per-batch buffers and compressor table pools; the dedup set is shared and its updates stay in batch order).  The
  * thin tail of one batch's compress stage -- a few long chunks -- then runs under the next batch's hash and first
  * compress stage.  This is the shape of the reference's own overlap: Rayon workers keep hashing / compressing the
@@ -140,14 +139,19 @@ uint64_t sq_slots_bound(const uint32_t* h_len, uint32_t n);
  *   sq_pack_submit: == sq_pack_batch's semantics for the batch (n x ChunkStore::insert in index order), with the
  *     frames left in their slots of d_comp (see sq_compress_batch_slots; SQ_E_CAP unless comp_cap >=
  *     sq_slots_bound(h_len, n)).  flags bit 0: empty the dedup set first (== sq_dedup_reset, ordered correctly
- *     behind the batch before).  Every in-flight batch needs its OWN d_hashes / d_is_new / d_comp buffers.
+ *     behind the batch before).  Every in-flight batch needs its OWN hashes / is_new / comp buffers.
  *     SQ_E_INVAL when two batches are already in flight.
- *   sq_pack_wait: waits for the OLDEST batch in flight and returns its slot offsets and frame lengths (n entries
- *     each; length 0 = duplicate).  If it fails (SQ_E_COMPRESS / SQ_E_DEVICE) the context's dedup set holds that
+ *     data / hashes / is_new / comp may also be HOST pointers (all four on the same side): the batch is then staged
+ *     through the lane's device buffers -- one H2D copy on the lane's stream, which overlaps the other lane's
+ *     kernels -- the frames are packed back to back on the device and sq_pack_wait copies hashes, flags and
+ *     exactly the frames' bytes back (comp_cap bytes must be available at comp; SQ_E_CAP from sq_pack_wait
+ *     otherwise).  Page-locked buffers (sq_host_alloc) make the copies asynchronous.
+ *   sq_pack_wait: waits for the OLDEST batch in flight and returns its frames' offsets in comp and their lengths (n
+ *     entries each; length 0 = duplicate).  If it fails (SQ_E_COMPRESS / SQ_E_DEVICE) the context's dedup set holds that
  *     batch's hashes: call sq_dedup_reset before reusing the context.
  * The synchronous entry points above return SQ_E_INVAL while batches are in flight. */
-int sq_pack_submit(sq_ctx* ctx, const uint8_t* d_data, const uint64_t* h_off, const uint32_t* h_len, uint32_t n,
-                   uint8_t* d_hashes, uint8_t* d_is_new, uint8_t* d_comp, uint64_t comp_cap, uint32_t flags);
+int sq_pack_submit(sq_ctx* ctx, const uint8_t* data, const uint64_t* h_off, const uint32_t* h_len, uint32_t n,
+                   uint8_t* hashes, uint8_t* is_new, uint8_t* comp, uint64_t comp_cap, uint32_t flags);
 int sq_pack_wait(sq_ctx* ctx, uint64_t* h_comp_off, uint32_t* h_comp_len);
 
 /* Page-locked host buffers for the batch forms (hipHostMalloc).  The reference's packer reads every

@@ -95,6 +95,11 @@ struct sq_lane {
     size_t job_ws_each = 0, job_etab_bytes = 0;
     bool job_fast = false;
     u64 job_seen_before = 0;
+    // host-pointer batch of sq_pack_submit: where the results go at sq_pack_wait
+    bool job_host = false;
+    u8 *job_h_hashes = nullptr, *job_h_isnew = nullptr, *job_h_comp = nullptr;
+    u64 job_comp_cap = 0;
+    std::vector<u64> job_out_off;
 };
 
 struct sq_ctx {
@@ -694,6 +699,10 @@ static int compress_finish(sq_ctx* c, sq_lane* L, u8* d_comp, u64 comp_cap, u64*
         return SQ_OK;
     }
     if (h_comp_off[n] > comp_cap) return SQ_E_CAP;
+    if (L->job_host) { // the packing pass was enqueued with the kernels (sq_pack_submit, host buffers)
+        HIPCHK(hipEventElapsedTime(&L->last.compact_ms, L->ev[6], L->ev[7]));
+        return SQ_OK;
+    }
     HIPCHK(hipEventRecord(L->ev[6], L->stream));
     {
         const u32 wpb = 4;
@@ -713,6 +722,7 @@ static int compress_async(sq_ctx* c, sq_lane* L, const u8* d_data, const u64* h_
                           const u8* d_select, u8* d_comp, u64 comp_cap, u64* h_comp_off, u32* h_comp_len) {
     (void)h_off;
     c->last_lane = 0;
+    L->job_host = false;
     bool const in_place = h_comp_len != nullptr;
     int const r = compress_enqueue(c, L, d_data, h_len, n, d_select, d_comp, comp_cap, in_place);
     if (r) return r;
@@ -866,22 +876,61 @@ int sq_pack_batch(sq_ctx* c, const uint8_t* data, const uint64_t* off, const uin
 }
 
 // ---- pipelined form: two batches in flight on the context's two lanes -------------------------------------------
-int sq_pack_submit(sq_ctx* c, const uint8_t* d_data, const uint64_t* h_off, const uint32_t* h_len, uint32_t n,
-                   uint8_t* d_hashes, uint8_t* d_is_new, uint8_t* d_comp, uint64_t comp_cap, uint32_t flags) {
+int sq_pack_submit(sq_ctx* c, const uint8_t* data, const uint64_t* h_off, const uint32_t* h_len, uint32_t n,
+                   uint8_t* hashes, uint8_t* is_new, uint8_t* comp, uint64_t comp_cap, uint32_t flags) {
 #ifdef SQ_NO_COMPRESS
-    (void)c; (void)d_data; (void)h_off; (void)h_len; (void)n; (void)d_hashes; (void)d_is_new; (void)d_comp; (void)comp_cap; (void)flags;
+    (void)c; (void)data; (void)h_off; (void)h_len; (void)n; (void)hashes; (void)is_new; (void)comp; (void)comp_cap; (void)flags;
     return SQ_E_COMPRESS;
 #else
-    if (!c || (n && (!d_data || !h_off || !h_len || !d_hashes || !d_is_new || !d_comp))) return SQ_E_INVAL;
+    if (!c || (n && (!data || !h_off || !h_len || !hashes || !is_new || !comp))) return SQ_E_INVAL;
     if (c->submitted - c->collected >= 2) return SQ_E_INVAL; // both lanes busy: collect one with sq_pack_wait first
     HIPCHK(hipSetDevice(c->device));
     for (u32 i = 0; i < n; i++)
         if (h_len[i] > c->cfg.max_chunk) return SQ_E_INVAL;
-    if (sq_slots_bound(h_len, n) > comp_cap) return SQ_E_CAP;
+    bool const dev = n ? is_device_ptr(data) : true;
+    if (n && (is_device_ptr(hashes) != dev || is_device_ptr(is_new) != dev || is_device_ptr(comp) != dev)) return SQ_E_INVAL;
+    if (dev && sq_slots_bound(h_len, n) > comp_cap) return SQ_E_CAP;
     sq_lane* const L = &c->ln[c->submitted & 1];
     sq_lane* const other = &c->ln[(c->submitted & 1) ^ 1];
     int r;
-    if ((r = upload_off_len(c, L, h_off, h_len, n))) return r;
+    const u8* d_data = data;
+    u8 *d_hashes = hashes, *d_isnew = is_new, *d_comp = comp;
+    std::vector<u64> off2;
+    const u64* use_off = h_off;
+    L->job_host = !dev;
+    if (!dev) {
+        // host buffers: one H2D into the lane's staging buffer (chunks at 256-byte aligned starts), frames produced
+        // into the lane's slots and packed back to back on the device; sq_pack_wait brings the results back.  On
+        // the lane's own stream all of this overlaps the other lane's kernels.
+        off2.resize(n);
+        u64 acc = 0, bound = 0;
+        for (u32 i = 0; i < n; i++) {
+            off2[i] = acc;
+            acc += ((u64)h_len[i] + 255) & ~(u64)255;
+            bound += sq_compress_bound(h_len[i]) + 16;
+        }
+        if ((r = L->b_stage_in.ensure(acc + 256))) return r;
+        if ((r = L->b_hashes.ensure((size_t)n * 16 + 16))) return r;
+        if ((r = L->b_isnew.ensure((size_t)n + 16))) return r;
+        if ((r = L->b_stage_out.ensure(bound + 64))) return r;
+        bool span = true;
+        for (u32 i = 0; i < n && span; i++) span = (h_off[i] - h_off[0]) == off2[i];
+        if (span && n)
+            HIPCHK(hipMemcpyAsync(L->b_stage_in.p, data + h_off[0], off2[n - 1] + h_len[n - 1], hipMemcpyHostToDevice, L->stream));
+        else
+            for (u32 i = 0; i < n; i++)
+                HIPCHK(hipMemcpyAsync((u8*)L->b_stage_in.p + off2[i], data + h_off[i], h_len[i], hipMemcpyHostToDevice, L->stream));
+        d_data = (const u8*)L->b_stage_in.p;
+        d_hashes = (u8*)L->b_hashes.p;
+        d_isnew = (u8*)L->b_isnew.p;
+        d_comp = (u8*)L->b_stage_out.p;
+        use_off = off2.data();
+        L->job_h_hashes = hashes;
+        L->job_h_isnew = is_new;
+        L->job_h_comp = comp;
+        L->job_comp_cap = comp_cap;
+    }
+    if ((r = upload_off_len(c, L, use_off, h_len, n))) return r;
     if ((r = launch_hash(c, L, d_data, n, d_hashes))) return r; // (does not depend on the batch before)
     // the dedup set is shared: this batch's reset / insert must follow the previous batch's dedup kernels
     if (other->busy) HIPCHK(hipStreamWaitEvent(L->stream, other->dedup_done, 0));
@@ -891,11 +940,19 @@ int sq_pack_submit(sq_ctx* c, const uint8_t* d_data, const uint64_t* h_off, cons
         c->n_seen = 0;
     }
     L->job_seen_before = c->n_seen;
-    if ((r = dedup_async(c, L, d_hashes, n, 0, n, d_is_new))) return r; // (fails before touching the set)
+    if ((r = dedup_async(c, L, d_hashes, n, 0, n, d_isnew))) return r; // (fails before touching the set)
     HIPCHK(hipEventRecord(L->dedup_done, L->stream));
-    if ((r = compress_enqueue(c, L, d_data, h_len, n, d_is_new, d_comp, comp_cap, true))) {
+    if ((r = compress_enqueue(c, L, d_data, h_len, n, d_isnew, d_comp, dev ? comp_cap : ~0ull, dev))) {
         (void)hipStreamSynchronize(L->stream);
         return r;
+    }
+    if (!dev && n) { // the packing pass, on the device: slots -> staging buffer, offsets from the scan
+        HIPCHK(hipEventRecord(L->ev[6], L->stream));
+        const u32 wpb = 4;
+        hipLaunchKernelGGL(sqd::k_compact_frames, dim3((n + wpb - 1) / wpb), dim3(64 * wpb), 0, L->stream, (const u8*)L->b_slots.p,
+                           (const u64*)L->b_slot_off.p, (const u32*)L->b_frame_len.p, (const u64*)L->b_out_off.p, n, d_comp);
+        HIPCHK(hipGetLastError());
+        HIPCHK(hipEventRecord(L->ev[7], L->stream));
     }
     L->busy = true;
     c->submitted++;
@@ -910,13 +967,34 @@ int sq_pack_wait(sq_ctx* c, uint64_t* h_comp_off, uint32_t* h_comp_len) {
 #else
     if (!c || c->submitted == c->collected) return SQ_E_INVAL;
     sq_lane* const L = &c->ln[c->collected & 1];
-    if (L->job_n && (!h_comp_off || !h_comp_len)) return SQ_E_INVAL;
+    u32 const n = L->job_n;
+    if (n && (!h_comp_off || !h_comp_len)) return SQ_E_INVAL;
     HIPCHK(hipSetDevice(c->device));
-    int const r = compress_finish(c, L, nullptr, 0, h_comp_off, h_comp_len, true);
+    int r;
+    if (!L->job_host) {
+        r = compress_finish(c, L, nullptr, 0, h_comp_off, h_comp_len, true);
+    } else {
+        L->job_out_off.resize((size_t)n + 1);
+        r = compress_finish(c, L, (u8*)L->b_stage_out.p, L->job_comp_cap, L->job_out_off.data(), nullptr, false);
+        if (!r && n) {
+            u64 const total = L->job_out_off[n];
+            r = [&]() -> int {
+                HIPCHK(hipMemcpyAsync(L->job_h_hashes, L->b_hashes.p, (size_t)n * 16, hipMemcpyDeviceToHost, L->stream));
+                HIPCHK(hipMemcpyAsync(L->job_h_isnew, L->b_isnew.p, n, hipMemcpyDeviceToHost, L->stream));
+                if (total) HIPCHK(hipMemcpyAsync(L->job_h_comp, L->b_stage_out.p, total, hipMemcpyDeviceToHost, L->stream));
+                HIPCHK(hipStreamSynchronize(L->stream));
+                return SQ_OK;
+            }();
+            for (u32 i = 0; i < n; i++) {
+                h_comp_off[i] = L->job_out_off[i];
+                h_comp_len[i] = (u32)(L->job_out_off[i + 1] - L->job_out_off[i]);
+            }
+        }
+    }
     L->busy = false;
     c->collected++;
     if (r) return r;
-    if (L->job_n) {
+    if (n) {
         HIPCHK(hipEventElapsedTime(&L->last.hash_ms, L->ev[0], L->ev[1]));
         HIPCHK(hipEventElapsedTime(&L->last.dedup_ms, L->ev[2], L->ev[3]));
     }

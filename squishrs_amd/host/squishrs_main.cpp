@@ -209,11 +209,12 @@ static uint64_t pack(const std::string& input, const std::string& output, int de
     };
     uint64_t total_bytes = 0;
     for (uint64_t z : sizes) total_bytes += z;
-    // batch size: the configured one, but no larger than a third of the input (small inputs should not pay
+    // batch size: the configured one, but no larger than an eighth of the input (four batches rotate through the
+    // stages, two of them in flight on the GPU: enough batches for the stages to overlap) (small inputs should not pay
     // for page-locking gigabytes they never fill)
-    uint64_t const eff_batch = std::max<uint64_t>(std::min<uint64_t>(batch_bytes, total_bytes / 3 + SQ_CHUNK_SIZE), 8u << 20);
-    int const NB = 3;
-    Batch bt[3];
+uint64_t const eff_batch = std::max<uint64_t>(std::min<uint64_t>(batch_bytes, total_bytes / 8 + SQ_CHUNK_SIZE), 8u << 20);
+    int const NB = 4; // reader: 1, gpu: 2 in flight (sq_pack_submit / sq_pack_wait), writer: 1
+    Batch bt[4];
     {   // Page-locking costs ~0.2 s per GiB here and only pays when the GPU stage (two PCIe crossings) is the
         // slowest of the three, i.e. on large inputs; SQUISH_PINNED=0/1 overrides.
         bool pin = total_bytes >= (16ull << 30);
@@ -313,27 +314,49 @@ static uint64_t pack(const std::string& input, const std::string& output, int de
         }
     });
 
-    try { // the gpu stage
+    try { // the gpu stage: two batches in flight on the context's two lanes -- batch k+1's H2D copy and kernels
+          // run while batch k's frames travel back (the read-ahead of writer.rs:233-246 + Rayon, on PCIe)
+        std::vector<int> inflight;
+        std::vector<uint64_t> woff;
+        std::vector<uint32_t> wlen;
+        auto collect = [&]() {
+            Batch& p = bt[inflight.front()];
+            inflight.erase(inflight.begin());
+            uint32_t const n = (uint32_t)p.len.size();
+            woff.resize((size_t)n + 1);
+            wlen.resize((size_t)n + 1);
+            double const tg0 = now_s();
+            check(sq_pack_wait(ctx, woff.data(), wlen.data()), "sq_pack_wait");
+            t_gpu += now_s() - tg0;
+            p.coff.resize((size_t)n + 1);
+            for (uint32_t i = 0; i < n; i++) p.coff[i] = woff[i];
+            p.coff[n] = n ? woff[n - 1] + wlen[n - 1] : 0;
+            set_state(p, 2);
+        };
+        auto ready = [&](Batch& x) {
+            std::lock_guard<std::mutex> lk(mu);
+            return x.state == 1 || !err.empty();
+        };
         for (int k = 0;; k = (k + 1) % NB) {
             Batch& b = bt[k];
+            // hand finished batches to the writer while the reader is still filling the next one
+            while (!inflight.empty() && (inflight.size() == 2 || !ready(b))) collect();
             if (!wait_state(b, 1)) break;
             uint32_t const n = (uint32_t)b.len.size();
-            if (n) {
-                b.hashes.resize((size_t)n * 16);
-                b.is_new.resize(n);
-                uint64_t cap = 0;
-                for (uint32_t i = 0; i < n; i++) cap += sq_compress_bound(b.len[i]) + 64;
-                b.comp.ensure((size_t)cap);
-                b.coff.resize((size_t)n + 1);
-                double const tg0 = now_s();
-                check(sq_pack_batch(ctx, b.data.p, b.off.data(), b.len.data(), n, b.hashes.data(), b.is_new.data(), b.comp.p,
-                                    cap, b.coff.data()),
-                      "sq_pack_batch");
-                t_gpu += now_s() - tg0;
+            b.hashes.resize((size_t)n * 16 + 16);
+            b.is_new.resize((size_t)n + 16);
+            uint64_t cap = 64;
+            for (uint32_t i = 0; i < n; i++) cap += sq_compress_bound(b.len[i]) + 64;
+            b.comp.ensure((size_t)cap);
+            double const tg0 = now_s();
+            check(sq_pack_submit(ctx, b.data.p, b.off.data(), b.len.data(), n, b.hashes.data(), b.is_new.data(), b.comp.p, cap, 0),
+                  "sq_pack_submit");
+            t_gpu += now_s() - tg0;
+            inflight.push_back(k);
+            if (b.last) {
+                while (!inflight.empty()) collect();
+                break;
             }
-            bool const last = b.last;
-            set_state(b, 2);
-            if (last) break;
         }
     } catch (const AppError& e) {
         fail(e.msg);
@@ -353,7 +376,7 @@ static uint64_t pack(const std::string& input, const std::string& output, int de
     {
         double t_alloc = 0;
         for (auto& b : bt) t_alloc += b.data.alloc_s + b.comp.alloc_s;
-        fprintf(stderr, "[squishrs timing] ctx_create %.3f s; overlapped stages: file reads %.3f s, sq_pack_batch %.3f s, record writes %.3f s; page-locked allocations %.3f s (inside the stages)\n", t_ctx, t_read, t_gpu, t_write, t_alloc);
+        fprintf(stderr, "[squishrs timing] ctx_create %.3f s; overlapped stages: file reads %.3f s, sq_pack_submit/wait %.3f s, record writes %.3f s; page-locked allocations %.3f s (inside the stages)\n", t_ctx, t_read, t_gpu, t_write, t_alloc);
     }
     {
         uint64_t count = sq_unique_count(ctx); // writer.rs:177-184

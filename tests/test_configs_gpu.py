@@ -327,3 +327,56 @@ def test_pack_submit_wait_two_batches_in_flight(oracle):
         assert r[0].compressed_data == oracle.compress_chunk(base[41])
     finally:
         st.close()
+
+
+def test_pack_submit_wait_host_buffers(oracle):
+    """The pipelined form with HOST buffers (what the C++ driver's GPU stage does): three ragged batches, two in
+    flight, results copied back by sq_pack_wait: hashes, flags, frames (packed back to back) against the oracle."""
+    import squishrs_amd
+    kinds = ["text", "random", "mixed", "records", "planted3", "runs", "zeros", "skewed"]
+    batches = []
+    for b in range(3):
+        chunks = [corpus.make(kinds[(3 * b + i) % len(kinds)], 300 + 10 * b + i, [70000, 262144, 5000, 400000, 131072][(b + i) % 5])
+                  for i in range(6)]
+        chunks.append(chunks[1])                      # a duplicate inside the batch
+        if b:
+            chunks.append(batches[0][0][2])           # ... and one of an earlier batch
+        lens = np.array([len(c) for c in chunks], dtype=np.uint32)
+        offs = np.zeros(len(chunks), dtype=np.uint64)
+        pos = 0
+        for i, c in enumerate(chunks):
+            offs[i] = pos
+            pos += (len(c) + 255) & ~255
+        data = np.zeros(pos + 256, dtype=np.uint8)
+        for i, c in enumerate(chunks):
+            data[int(offs[i]):int(offs[i]) + len(c)] = np.frombuffer(c, dtype=np.uint8)
+        cap = int(sum(squishrs_amd.compress_bound(len(c)) + 64 for c in chunks))
+        batches.append((chunks, data, offs, lens, np.zeros(len(chunks) * 16, dtype=np.uint8), np.zeros(len(chunks), dtype=np.uint8),
+                        np.zeros(cap, dtype=np.uint8)))
+    st = squishrs_amd.ChunkStore(device=0, dedup_capacity=1 << 12)
+    L = st._L
+    try:
+        def submit(b, reset):
+            chunks, data, offs, lens, hashes, is_new, comp = b
+            squishrs_amd.chunk.check(L.sq_pack_submit(st._h, data.ctypes.data, offs.ctypes.data, lens.ctypes.data, len(chunks),
+                                                      hashes.ctypes.data, is_new.ctypes.data, comp.ctypes.data, comp.size, 1 if reset else 0))
+        submit(batches[0], True)
+        submit(batches[1], False)
+        r0 = st.pack_wait(len(batches[0][0]))
+        submit(batches[2], False)
+        r1 = st.pack_wait(len(batches[1][0]))
+        r2 = st.pack_wait(len(batches[2][0]))
+        seen = set()
+        for (chunks, data, offs, lens, hashes, is_new, comp), (coff, clen) in zip(batches, (r0, r1, r2)):
+            for j, c in enumerate(chunks):
+                assert hashes[16 * j:16 * j + 16].tobytes() == oracle.hash_chunk(c)
+                new = c not in seen
+                seen.add(c)
+                assert bool(is_new[j]) == new
+                if new:
+                    assert comp[int(coff[j]):int(coff[j]) + int(clen[j])].tobytes() == oracle.compress_chunk(c), (j, len(c))
+                else:
+                    assert clen[j] == 0
+        assert st.len() == len(seen)
+    finally:
+        st.close()
