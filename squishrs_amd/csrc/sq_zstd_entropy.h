@@ -70,6 +70,8 @@ struct RbLds {
     u32 cand[SQZ_RB_PAIRS];
     u32 rowId[64], pbase[64]; // per owner lane: its row, the start of its pairs
     u32 stop[64], best[64], flag[64]; // per owner lane: first pair that ends the scan; (len << 8 | 255 - order) maximum; "long candidate" flag
+    u32 prev[128];                    // per owner lane: the 8 bytes in front of its position
+    u8 be[SQZ_RB_PAIRS];              // per pair: equal bytes in front of position and candidate (0..8)
 };
 struct LdsState {
     Entropy ent[2];

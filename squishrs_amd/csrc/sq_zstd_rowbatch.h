@@ -54,6 +54,27 @@ struct RowBatch {
 #define RB_GET(bt, f, i) ((bt).f[(i)])
 #endif
 
+// bit j: the search at lane j is known to find nothing (evaluated, not delegated, no match) / its repcode length is >= 4
+#if SQ_ON_DEVICE
+SQ_DEV u64 rb_nomatch_mask(const RowBatch& bt) {
+    return wv_ballot(wv_lane() < bt.n && (bt.flags & SQZ_RB_DONE) && !(bt.flags & SQZ_RB_EXACT) && bt.ml <= 3);
+}
+SQ_DEV u64 rb_rep_mask(const RowBatch& bt) { return wv_ballot(wv_lane() < bt.n && bt.rl >= 4); }
+#else
+SQ_DEV u64 rb_nomatch_mask(const RowBatch& bt) {
+    u64 m = 0;
+    for (u32 j = 0; j < bt.n; j++)
+        if ((bt.flags[j] & SQZ_RB_DONE) && !(bt.flags[j] & SQZ_RB_EXACT) && bt.ml[j] <= 3) m |= 1ull << j;
+    return m;
+}
+SQ_DEV u64 rb_rep_mask(const RowBatch& bt) {
+    u64 m = 0;
+    for (u32 j = 0; j < bt.n; j++)
+        if (bt.rl[j] >= 4) m |= 1ull << j;
+    return m;
+}
+#endif
+
 // recency order of a row's 63 usable slots (slot 0 holds the head byte): rank 0 = the head's slot
 SQ_DEV u32 rb_slot_of(u32 head, u32 rank) {
     u32 const j0 = (64u - head) & 63u; // where slot 0 sits in the scan order (head + j) & 63
@@ -230,6 +251,10 @@ SQ_DEVFN void rb_eval(MatchState& ms, RowBatch& bt, u32 i0, u32 iendPos) {
     SQ_L u32* const Lbest = (SQ_L u32*)g_lds.u.rb.best;
     SQ_L u32* const Lflag = (SQ_L u32*)g_lds.u.rb.flag;
     SQ_L u32* const Lown = (SQ_L u32*)g_lds.grp; // the 32 bytes at every lane's position
+    SQ_L u32* const Lprev = (SQ_L u32*)g_lds.u.rb.prev;
+    SQ_L u8* const Lbe = (SQ_L u8*)g_lds.u.rb.be;
+    Lprev[2 * lane] = (u32)bt.ownPrev;
+    Lprev[2 * lane + 1] = (u32)(bt.ownPrev >> 32);
     Lrow[lane] = bt.rowId;
     Lpb[lane] = pbase;
     Lstop[lane] = 0xFFFFFFFFu;
@@ -272,6 +297,7 @@ SQ_DEVFN void rb_eval(MatchState& ms, RowBatch& bt, u32 i0, u32 iendPos) {
             if (has[k] && !(d & 64u)) c[k] = sq_tld32(ms.hashTable + ((size_t)Lrow[own[k]] << 6) + (d & 63u));
         }
         sq_v4u b0[4], b1[4];
+        u64 bp[4];
         bool bad = false;
 #pragma unroll
         for (int k = 0; k < 4; k++) {
@@ -285,6 +311,7 @@ SQ_DEVFN void rb_eval(MatchState& ms, RowBatch& bt, u32 i0, u32 iendPos) {
             u32 const cc = ok ? c[k] : SQZ_WINDOW_START;
             b0[k] = sq_grd128(base + cc);
             b1[k] = sq_grd128(base + cc + 16);
+            bp[k] = sq_grd64(base + (cc >= 8 + SQZ_WINDOW_START ? cc - 8 : SQZ_WINDOW_START)); // the 8 bytes in front of the candidate
         }
         if (wv_ballot(bad)) ms.fault = 1;
 #pragma unroll
@@ -300,6 +327,10 @@ SQ_DEVFN void rb_eval(MatchState& ms, RowBatch& bt, u32 i0, u32 iendPos) {
                 else if (l > lim) l = lim;
                 len[k] = l;
                 Lcand[p] = c[k];
+                // backward extension (catch-up) of this pair: equal bytes in front of both, at most 8; only
+                // meaningful (and only used) when both positions have 8 bytes in front of them
+                u64 const x = (((u64)Lprev[2 * own[k] + 1] << 32) | Lprev[2 * own[k]]) ^ bp[k];
+                Lbe[p] = (u8)((c[k] >= 8 + SQZ_WINDOW_START) ? (x ? ((u32)__builtin_clzll(x) >> 3) : SQZ_RB_BECAP) : 0u);
             }
         }
         wv_fence(); // (the stoppers are in before anybody reads them: LDS operations of a wave execute in order)
@@ -312,7 +343,7 @@ SQ_DEVFN void rb_eval(MatchState& ms, RowBatch& bt, u32 i0, u32 iendPos) {
         }
     }
     wv_fence();
-    u32 ml = 3, bestC = 0;
+    u32 ml = 3, bestC = 0, be = 0;
     if (cnt) {
         // (a long candidate anywhere in front of the first stopper sends the position to the exact finder, even where
         // libzstd's scan would have ended before reaching it: asking the exact finder is always right)
@@ -320,19 +351,11 @@ SQ_DEVFN void rb_eval(MatchState& ms, RowBatch& bt, u32 i0, u32 iendPos) {
         else {
             u32 const b = Lbest[lane];
             if ((b >> 8) > 3) {
+                u32 const t = 255u - (b & 255u);
                 ml = b >> 8;
-                bestC = Lcand[pbase + (255u - (b & 255u))];
+                bestC = Lcand[pbase + t];
+                be = (q >= 8 + SQZ_WINDOW_START) ? (u32)Lbe[pbase + t] : 0u;
             }
-        }
-    }
-    // ---- backward extension of the best candidate: equal bytes in front of both, at most 8
-    u32 be = 0;
-    if (wv_ballot(sel && ml > 3 && !(flags & SQZ_RB_EXACT))) {
-        bool const want = sel && ml > 3 && !(flags & SQZ_RB_EXACT) && bestC >= 8 + SQZ_WINDOW_START && q >= 8 + SQZ_WINDOW_START;
-        u64 const cp = sq_grd64(base + (want ? bestC - 8 : SQZ_WINDOW_START));
-        if (want) {
-            u64 const x = bt.ownPrev ^ cp;
-            be = x ? ((u32)__builtin_clzll(x) >> 3) : SQZ_RB_BECAP;
         }
     }
     if (sel) {
@@ -616,6 +639,26 @@ SQ_DEV u32 compressBlock_lazy_rb_impl(MatchState& ms, SeqStore& ss, u32* rep, co
             u32 const step = ((ip - anchor) >> 8) + 1;
             ip += step;
             ms.lazySkipping = step > 8;
+            // Fast-forward over positions that are known to give nothing: while the step is 1 the parser would visit
+            // ip, ip+1, ... one by one, each time finding no match (the batch says so) and no repcode match at the
+            // position after it; jump to the first position where one of these is not known to hold.
+            if (step == 1 && bt.valid && ip > bt.B0 && ip < bt.B0 + bt.n && (offset_1 == 0 || bt.off1 == offset_1)) {
+                u64 const nom = rb_nomatch_mask(bt);
+                u64 const rep = offset_1 ? rb_rep_mask(bt) : 0ull;
+                // lane j is skippable: no match at j, no repcode match at j+1 (which must be a lane of the batch)
+                u64 skippable = nom & ~(rep >> 1);
+                skippable &= (bt.n >= 64) ? (~0ull >> 1) : ((1ull << (bt.n - 1)) - 1);
+                u32 const i = ip - bt.B0;
+                u64 const stop = ~skippable & (~0ull << i); // first lane >= i that must be visited
+                u32 j = stop ? (u32)__builtin_ctzll(stop) : 64u;
+                u32 lim = anchor + 256 - bt.B0; // the step is 1 only while ip - anchor < 256
+                if (ilimitPos - bt.B0 < lim) lim = ilimitPos - bt.B0;
+                if (j > lim) j = lim;
+                if (j > i) {
+                    ip = bt.B0 + j;
+                    ms.nextToUpdate = ip; // every position in between counts as searched (and inserted)
+                }
+            }
             continue;
         }
         while (ip < ilimitPos) {

@@ -1,39 +1,59 @@
-"""Fold the rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes written by tools/profile_r1.sh into
-profiles/<tag>_pmc.json (per kernel, as reported) and refresh profiles/pmc_traffic.json, the
-per-launch HBM traffic of k_compress_batch that bench.py quotes in roofline.traffic.
-usage: python tools/pmc_summary.py <tag> <chunks> <chunk_bytes> <launches in the profiled run>"""
-import collections
+"""Fold the rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes written by tools/profile_r2.sh into profiles/<tag>_pmc.json
+(per kernel, as reported) and refresh profiles/pmc_traffic.json, the per-launch HBM traffic bench.py quotes in
+roofline.traffic.  For every kernel the LAST launch of the profiled run is taken (steady state: the run does one
+warm-up launch first).  Also copies the kernel-stats CSVs of the two trace passes into profiles/.
+usage: python tools/pmc_summary.py <tag> <chunks> <chunk_bytes>"""
 import csv
 import glob
 import json
 import os
+import shutil
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-tag, n, L, launches = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4])
+tag, n, L = sys.argv[1], int(sys.argv[2]), int(sys.argv[3])
+O = os.path.join(ROOT, "gpurun_out", f"prof_{tag}")
+for name in ("bench_pmc_fetch", "bench_pmc_write"):
+    p = os.path.join(O, name + ".json")
+    assert os.path.exists(p) and os.path.getsize(p) > 0, f"{p} is missing or empty: that counter pass failed"
 out = {"note": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes over "
-               f"`python3 bench.py --chunks {n} --chunk-bytes {L} --steps {launches} --warmup 0 --no-cpu-baseline`; "
-               "counter values are KB as reported, summed over the run's launches.  gfx950: FETCH_SIZE counts a "
-               "wide coalesced streaming read at half its bytes (MI355X_MICROARCH.md, HBM section); the raw "
-               "values are kept here and the correction is applied where a kernel is a pure streaming read.",
-       "kernels": collections.defaultdict(dict)}
+               f"`python3 bench.py --chunks {n} --chunk-bytes {L} --steps 1 --warmup 1 --no-pipeline --no-other-configs "
+               "--no-cpu-baseline`; per kernel the LAST launch (steady state); counter values are KB as reported.  "
+               "gfx950: FETCH_SIZE counts a wide coalesced streaming read at half its bytes (MI355X_MICROARCH.md, HBM "
+               "section); raw values here, the correction is applied in profiles/pmc_traffic.json / bench.py.",
+       "kernels": {}}
 for kind, cname in (("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE")):
-    files = glob.glob(os.path.join(ROOT, "gpurun_out", f"prof_{tag}", f"pmc_{kind}", "**", "*counter_collection.csv"),
-                      recursive=True)
+    files = glob.glob(os.path.join(O, f"pmc_{kind}", "**", "*counter_collection.csv"), recursive=True)
+    assert files, f"no counter CSV for {kind}"
+    last = {}
     for f in files:
         for r in csv.DictReader(open(f)):
             k = r["Kernel_Name"].split("(")[0]
             if k.startswith("sq") and r["Counter_Name"] == cname:
-                out["kernels"][k][cname] = out["kernels"][k].get(cname, 0.0) + float(r["Counter_Value"])
+                d = int(r["Dispatch_Id"])
+                if k not in last or d >= last[k][0]:
+                    last[k] = (d, float(r["Counter_Value"]))
+    for k, (_, v) in last.items():
+        out["kernels"].setdefault(k, {})[cname] = v
 json.dump(out, open(os.path.join(ROOT, "profiles", f"{tag}_pmc.json"), "w"), indent=1)
-p = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+# streaming-read bytes per chunk (one 16 B/lane pass over the chunk), the part FETCH_SIZE tallies at half:
+STREAM = {"sqz::k_incompressible_batch": L, "sqx::k_xxh3_128_rows": L}
 t = {}
 for k, ck in out["kernels"].items():
-    if "FETCH_SIZE" in ck and "WRITE_SIZE" in ck and k.startswith("sqz::"):
-        t[f"{k}@{L}"] = {"fetch_bytes_per_chunk": ck["FETCH_SIZE"] * 1024 / launches / n,
-                         "write_bytes_per_chunk": ck["WRITE_SIZE"] * 1024 / launches / n,
+    if "FETCH_SIZE" in ck and "WRITE_SIZE" in ck:
+        t[f"{k}@{L}"] = {"fetch_bytes_per_chunk": ck["FETCH_SIZE"] * 1024 / n,
+                         "write_bytes_per_chunk": ck["WRITE_SIZE"] * 1024 / n,
+                         "stream_read_bytes_per_chunk": STREAM.get(k, 0),
                          "measured_on_chunks": n, "source": f"profiles/{tag}_pmc.json",
-                         "note": "FETCH_SIZE uncorrected (streaming reads are counted at half on gfx950; these "
-                                 "kernels mix them with 4-8 byte gathers and 8-byte atomics)"}
+                         "note": "per chunk of the BATCH (stage 2 handles ~7 % of them); corrected traffic = fetch + "
+                                 "stream_read/2 + write (FETCH_SIZE tallies a coalesced streaming read at half on gfx950)"}
         print(k, json.dumps(t[f"{k}@{L}"]))
-json.dump(t, open(p, "w"), indent=1)
+json.dump(t, open(os.path.join(ROOT, "profiles", "pmc_traffic.json"), "w"), indent=1)
+for sub, suffix in (("trace", "bench_kernel_stats.csv"), ("trace_solo", "bench_solo_kernel_stats.csv")):
+    fs = glob.glob(os.path.join(O, sub, "**", "*kernel_stats.csv"), recursive=True)
+    if fs:
+        shutil.copy(fs[0], os.path.join(ROOT, "profiles", f"{tag}_{suffix}"))
+for name in ("bench_under_trace", "bench_under_trace_solo"):
+    p = os.path.join(O, name + ".json")
+    if os.path.exists(p):
+        shutil.copy(p, os.path.join(ROOT, "profiles", f"{tag}_{name}_line.json"))
