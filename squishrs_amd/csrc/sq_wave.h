@@ -4,8 +4,9 @@
 // wave-uniform: every lane executes the same "scalar" program on the same values (uniform loads
 // broadcast one address; single-lane stores publish), and the 64 lanes are used as a vector unit
 // by the primitives in this file: match-length extension, 64-entry tag-row compare, batched hash
-// insertion with in-wave conflict ranking, LDS histograms, coalesced copies/fills, bit-stream
-// packing with wavefront prefix scans.
+// insertion with in-wave conflict ranking, LDS histograms, coalesced copies/fills; the prefix scan
+// (wv_excl_scan) that places every lane's bits in a zstd bit stream (sq_zstd_entropy.h, wvb_tile)
+// and the candidate pairs of a row-hash search batch (sq_zstd_rowbatch.h).
 //
 // The same source also builds with -DSQ_SIM for the host: every primitive then has a plain
 // scalar body with identical semantics.  That build exists ONLY for tests/ (a CPU-side simulator

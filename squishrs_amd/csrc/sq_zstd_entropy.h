@@ -7,7 +7,8 @@
 //   * byte / code histograms: 64 lanes, LDS atomics (wv_hist_bytes)
 //   * table construction (Huffman tree, FSE normalisation, NCount, encoding-type cost model):
 //     a few hundred scalar steps on <= 256 symbols -> serial region on lane 0, tables in LDS
-//   * bit-stream emission: serial on lane 0 in this revision (see DESIGN.md "next")
+//   * bit-stream emission: wave-parallel -- code lengths -> prefix scan over the lanes -> every lane ORs its bits
+//     into an LDS window (wvb_tile); only the three FSE state recurrences are serial (lanes 0..2)
 // All tables live in LDS (g_lds); the previous block's tables stay resident for the
 // repeat / treeless modes.  Comments name the libzstd routine each function corresponds to.
 #pragma once

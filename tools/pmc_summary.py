@@ -2,7 +2,7 @@
 (per kernel, as reported) and refresh profiles/pmc_traffic.json, the per-launch HBM traffic bench.py quotes in
 roofline.traffic.  For every kernel the LAST launch of the profiled run is taken (steady state: the run does one
 warm-up launch first).  Also copies the kernel-stats CSVs of the two trace passes into profiles/.
-usage: python tools/pmc_summary.py <tag> <chunks> <chunk_bytes>"""
+usage: python tools/pmc_summary.py <tag> <chunks> <chunk_bytes> [name under profiles/, default = tag]"""
 import csv
 import glob
 import json
@@ -12,6 +12,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag, n, L = sys.argv[1], int(sys.argv[2]), int(sys.argv[3])
+name_out = sys.argv[4] if len(sys.argv) > 4 else tag
 O = os.path.join(ROOT, "gpurun_out", f"prof_{tag}")
 for name in ("bench_pmc_fetch", "bench_pmc_write"):
     p = os.path.join(O, name + ".json")
@@ -35,7 +36,7 @@ for kind, cname in (("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE")):
                     last[k] = (d, float(r["Counter_Value"]))
     for k, (_, v) in last.items():
         out["kernels"].setdefault(k, {})[cname] = v
-json.dump(out, open(os.path.join(ROOT, "profiles", f"{tag}_pmc.json"), "w"), indent=1)
+json.dump(out, open(os.path.join(ROOT, "profiles", f"{name_out}_pmc.json"), "w"), indent=1)
 # streaming-read bytes per chunk (one 16 B/lane pass over the chunk), the part FETCH_SIZE tallies at half:
 STREAM = {"sqz::k_incompressible_batch": L, "sqx::k_xxh3_128_rows": L}
 t = {}
@@ -52,8 +53,8 @@ json.dump(t, open(os.path.join(ROOT, "profiles", "pmc_traffic.json"), "w"), inde
 for sub, suffix in (("trace", "bench_kernel_stats.csv"), ("trace_solo", "bench_solo_kernel_stats.csv")):
     fs = glob.glob(os.path.join(O, sub, "**", "*kernel_stats.csv"), recursive=True)
     if fs:
-        shutil.copy(fs[0], os.path.join(ROOT, "profiles", f"{tag}_{suffix}"))
+        shutil.copy(fs[0], os.path.join(ROOT, "profiles", f"{name_out}_{suffix}"))
 for name in ("bench_under_trace", "bench_under_trace_solo"):
     p = os.path.join(O, name + ".json")
     if os.path.exists(p):
-        shutil.copy(p, os.path.join(ROOT, "profiles", f"{tag}_{name}_line.json"))
+        shutil.copy(p, os.path.join(ROOT, "profiles", f"{name_out}_{name}_line.json"))
