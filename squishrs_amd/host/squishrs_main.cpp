@@ -478,21 +478,46 @@ static void list_cmd(const std::string& squish, bool simple) {
         for (auto& f : s.files) printf("%10" PRIu64 "  %s\n", f.second, f.first.c_str());
         return;
     }
-    // cmd/mod.rs:60-158 (same labels and values; plain two-column layout)
-    printf("\nSquash breakdown:\n Squash Summary\n");
-    printf(" %-20s %s\n", "Creation Date (UTC)", date_of(s.timestamp).c_str());
-    printf(" %-20s %s\n", "Squish Version", s.version.c_str());
-    printf(" %-20s %s\n", "Compressed size", format_bytes(s.archive_size).c_str());
-    printf(" %-20s %s\n", "Original size", format_bytes(s.total_orig).c_str());
-    printf(" %-20s %.1f%%\n", "Compression Ratio", ratio);
-    printf(" %-20s %s\n", "Number of files", with_commas(s.files.size()).c_str());
-    printf(" %-20s %s\n", "Number of chunks", with_commas(s.unique_chunks).c_str());
+    // cmd/mod.rs:60-158: two prettytable tables, FORMAT_NO_LINESEP_WITH_TITLE (borders, a separator line under the
+    // title row only, cells padded with one space)
+    auto table = [](const std::vector<std::string>& title, bool span, const std::vector<std::pair<std::string, std::string>>& rows) {
+        size_t w0 = span ? 0 : title[0].size(), w1 = span ? 0 : title[1].size();
+        for (auto& r : rows) {
+            w0 = std::max(w0, r.first.size());
+            w1 = std::max(w1, r.second.size());
+        }
+        if (span && title[0].size() > w0 + w1 + 3) w1 = title[0].size() - w0 - 3; // the spanning title widens the last column
+        std::string const line = "+" + std::string(w0 + 2, '-') + "+" + std::string(w1 + 2, '-') + "+\n";
+        std::string o = line;
+        if (span)
+            o += "| " + title[0] + std::string(w0 + w1 + 3 - title[0].size(), ' ') + " |\n";
+        else
+            o += "| " + title[0] + std::string(w0 - title[0].size(), ' ') + " | " + title[1] + std::string(w1 - title[1].size(), ' ') + " |\n";
+        o += line;
+        for (auto& r : rows)
+            o += "| " + r.first + std::string(w0 - r.first.size(), ' ') + " | " + r.second + std::string(w1 - r.second.size(), ' ') + " |\n";
+        o += line;
+        return o;
+    };
+    char pct[32];
+    snprintf(pct, sizeof pct, "%.1f%%", ratio);
+    printf("\nSquash breakdown:\n%s",
+           table({"Squash Summary"}, true,
+                 {{"Creation Date (UTC)", date_of(s.timestamp)},
+                  {"Squish Version", s.version},
+                  {"Compressed size", format_bytes(s.archive_size)},
+                  {"Original size", format_bytes(s.total_orig)},
+                  {"Compression Ratio", pct},
+                  {"Number of files", with_commas(s.files.size())},
+                  {"Number of chunks", with_commas(s.unique_chunks)}})
+               .c_str());
     std::map<std::string, size_t> dirs;
     for (auto& f : s.files) dirs[f.first.substr(0, f.first.find('/'))]++;
     std::vector<std::pair<std::string, size_t>> v(dirs.begin(), dirs.end());
     std::stable_sort(v.begin(), v.end(), [](auto& a, auto& b) { return a.second > b.second; });
-    printf("\nTop-level directory breakdown:\n %-30s %s\n", "Directory", "File Count");
-    for (auto& d : v) printf(" %-30s %s\n", d.first.c_str(), with_commas(d.second).c_str());
+    std::vector<std::pair<std::string, std::string>> rows;
+    for (auto& d : v) rows.push_back({d.first, with_commas(d.second)});
+    printf("\n\nTop-level directory breakdown:\n%s\n", table({"Directory", "File Count"}, false, rows).c_str());
 }
 
 // ---- unpack (archive/reader.rs:232-413; lib.rs:86-106) ------------------------------------------
@@ -593,13 +618,35 @@ static void unpack_cmd(const std::string& squish, const std::string& outdir, lon
     fclose(f);
 }
 
-static int usage() {
-    fprintf(stderr,
-            "Compact, compress, and deduplicate files into a single archive\n\n"
-            "Usage: squishrs [OPTIONS] <COMMAND>\n\nCommands:\n"
-            "  pack    Pack a directory\n  list    List files in an archive\n  unpack  Extract archive contents\n\n"
-            "Options:\n  -j, --max-threads <MAX_THREADS>  [default: 25]\n"
-            "      --device <ORDINAL>           GPU ordinal [default: 0]\n");
+// clap's behaviour for `squishrs` (cmd/mod.rs:11-58): -h/--help prints the help on stdout and exits 0; an unknown
+// flag, a missing value or a missing positional is an error on stderr with exit code 2; -j/--max-threads is global.
+static const char* kHelp =
+    "Compact, compress, and deduplicate files into a single archive\n\n"
+    "Usage: squishrs [OPTIONS] <COMMAND>\n\nCommands:\n"
+    "  pack    Pack a directory\n  list    List files in an archive\n  unpack  Extract archive contents\n"
+    "  help    Print this message or the help of the given subcommand(s)\n\n"
+    "Options:\n  -j, --max-threads <MAX_THREADS>  Maximum number of threads to use [default: 25]\n"
+    "      --device <ORDINAL>           GPU ordinal (this implementation) [default: 0]\n"
+    "  -h, --help                       Print help\n";
+static int help_for(const std::string& cmd) {
+    if (cmd == "pack")
+        printf("Compress and deduplicate a directory into a .squish archive file\n\nUsage: squishrs pack [OPTIONS] <INPUT>\n\n"
+               "Arguments:\n  <INPUT>  \n\nOptions:\n  -o, --output <OUTPUT>            \n"
+               "  -j, --max-threads <MAX_THREADS>  Maximum number of threads to use [default: 25]\n  -h, --help                       Print help\n");
+    else if (cmd == "list")
+        printf("Display the contents of a .squish archive\n\nUsage: squishrs list [OPTIONS] <SQUISH>\n\n"
+               "Arguments:\n  <SQUISH>  \n\nOptions:\n      --simple                     \n"
+               "  -j, --max-threads <MAX_THREADS>  Maximum number of threads to use [default: 25]\n  -h, --help                       Print help\n");
+    else if (cmd == "unpack")
+        printf("Unpacks all files from a .squish archive into a target directory\n\nUsage: squishrs unpack [OPTIONS] <SQUISH>\n\n"
+               "Arguments:\n  <SQUISH>  \n\nOptions:\n  -o, --output <OUTPUT>            \n"
+               "  -j, --max-threads <MAX_THREADS>  Maximum number of threads to use [default: 25]\n  -h, --help                       Print help\n");
+    else
+        fputs(kHelp, stdout);
+    return 0;
+}
+static int cli_error(const std::string& what, const std::string& usage_line) {
+    fprintf(stderr, "error: %s\n\nUsage: %s\n\nFor more information, try '--help'.\n", what.c_str(), usage_line.c_str());
     return 2;
 }
 
@@ -607,29 +654,63 @@ int main(int argc, char** argv) {
     g_tty = isatty(1);
     std::vector<std::string> pos;
     std::string output;
-    bool simple = false, have_output = false;
+    bool simple = false, have_output = false, want_help = false;
     int device = 0;
     long max_threads = 25; // cmd/mod.rs:16 (host worker count; the GPU path does not use Rayon)
+    auto usage_of = [&]() -> std::string {
+        if (pos.empty()) return "squishrs [OPTIONS] <COMMAND>";
+        if (pos[0] == "pack") return "squishrs pack [OPTIONS] <INPUT>";
+        if (pos[0] == "list") return "squishrs list [OPTIONS] <SQUISH>";
+        if (pos[0] == "unpack") return "squishrs unpack [OPTIONS] <SQUISH>";
+        return "squishrs [OPTIONS] <COMMAND>";
+    };
+    bool only_positionals = false; // after "--"
     for (int i = 1; i < argc; i++) {
         std::string a = argv[i];
-        if ((a == "-j" || a == "--max-threads") && i + 1 < argc)
-            max_threads = atol(argv[++i]);
+        auto value = [&](const char* name) -> const char* {
+            if (i + 1 < argc) return argv[++i];
+            exit(cli_error(std::string("a value is required for '") + name + "' but none was supplied", usage_of()));
+        };
+        if (only_positionals || a.empty() || a[0] != '-' || a == "-")
+            pos.push_back(a);
+        else if (a == "--")
+            only_positionals = true;
+        else if (a == "-j" || a == "--max-threads")
+            max_threads = atol(value("--max-threads <MAX_THREADS>"));
         else if (a.rfind("--max-threads=", 0) == 0)
             max_threads = atol(a.c_str() + 14);
-        else if ((a == "-o" || a == "--output") && i + 1 < argc) {
-            output = argv[++i];
+        else if (a.rfind("-j", 0) == 0 && a.size() > 2)
+            max_threads = atol(a.c_str() + 2);
+        else if ((a == "-o" || a == "--output") && !pos.empty() && pos[0] != "list") {
+            output = value("--output <OUTPUT>");
             have_output = true;
-        } else if (a == "--simple")
+        } else if (a.rfind("--output=", 0) == 0 && !pos.empty() && pos[0] != "list") {
+            output = a.substr(9);
+            have_output = true;
+        } else if (a == "--simple" && !pos.empty() && pos[0] == "list")
             simple = true;
-        else if (a == "--device" && i + 1 < argc)
-            device = atoi(argv[++i]);
+        else if (a == "--device")
+            device = atoi(value("--device <ORDINAL>"));
         else if (a == "-h" || a == "--help")
-            return usage();
-        else
-            pos.push_back(a);
+            want_help = true;
+        else if ((a == "-V" || a == "--version") && !pos.empty()) {
+            printf("squishrs-%s %s\n", pos[0].c_str(), kVersion);
+            return 0;
+        } else
+            return cli_error("unexpected argument '" + a + "' found", usage_of());
     }
+    if (want_help) return help_for(pos.empty() ? "" : pos[0]);
+    if (pos.empty()) { // clap: a missing subcommand prints the help on stderr, exit code 2
+        fputs(kHelp, stderr);
+        return 2;
+    }
+    if (pos[0] == "help") return help_for(pos.size() > 1 ? pos[1] : "");
+    if (pos[0] != "pack" && pos[0] != "list" && pos[0] != "unpack")
+        return cli_error("unrecognized subcommand '" + pos[0] + "'", "squishrs [OPTIONS] <COMMAND>");
+    if (pos.size() < 2)
+        return cli_error(std::string("the following required arguments were not provided:\n  <") + (pos[0] == "pack" ? "INPUT" : "SQUISH") + ">", usage_of());
+    if (pos.size() > 2) return cli_error("unexpected argument '" + pos[2] + "' found", usage_of());
     try {
-        if (pos.size() < 2) return usage();
         if (pos[0] == "pack") {
             std::string input = pos[1];
             if (!have_output) output = input + ".squish"; // lib.rs:31 (untrimmed input)
@@ -651,8 +732,7 @@ int main(int argc, char** argv) {
             }
             unpack_cmd(squish, output, max_threads);
             printf("%s\n%s was unsquished into /%s\n", green("Unpacking complete!").c_str(), squish.c_str(), output.c_str());
-        } else
-            return usage();
+        }
     } catch (const AppError& e) {
         fprintf(stderr, "%s: %s\n", red("Error").c_str(), e.msg.c_str()); // main.rs:6-9
         return 1;

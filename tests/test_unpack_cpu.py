@@ -182,3 +182,41 @@ def test_unpack_errors(tmp_path, oracle):
     a.write_bytes(_archive([(h0, 2 << 20, fr)], [("y.txt", 550, [h0])])[:-5])
     r = _run("unpack", str(a), "-o", str(tmp_path / "o3"))
     assert r.returncode != 0 and "Error" in r.stderr
+
+
+def test_cli_clap_behaviour_and_list_tables(tmp_path, oracle):
+    """f3: what clap does for /root/reference/src/cmd/mod.rs:11-58 -- --help on stdout with exit code 0, an unknown
+    flag / a missing argument / an unknown subcommand on stderr with exit code 2, -j global -- and the two
+    prettytable tables of the non-simple listing (cmd/mod.rs:97-165: labels of src/cmd/tests.rs:38-58)."""
+    r = _run("--help")
+    assert r.returncode == 0 and "Usage: squishrs [OPTIONS] <COMMAND>" in r.stdout and "pack" in r.stdout and r.stderr == ""
+    r = _run("pack", "--help")
+    assert r.returncode == 0 and "Usage: squishrs pack [OPTIONS] <INPUT>" in r.stdout
+    r = _run("pack", "--bogus", "x")
+    assert r.returncode == 2 and "error: unexpected argument '--bogus' found" in r.stderr and r.stdout == ""
+    r = _run("list")
+    assert r.returncode == 2 and "required arguments were not provided" in r.stderr and "<SQUISH>" in r.stderr
+    r = _run("frobnicate", "x")
+    assert r.returncode == 2 and "unrecognized subcommand 'frobnicate'" in r.stderr
+    r = _run()
+    assert r.returncode == 2 and "Usage: squishrs [OPTIONS] <COMMAND>" in r.stderr
+    r = _run("list", "x.squish", "-o", "y")                 # -o belongs to pack / unpack only
+    assert r.returncode == 2 and "unexpected argument '-o'" in r.stderr
+    # listing of an archive of the oracle: 1,234 files in two top-level directories
+    files = [(f"big/f{i:04d}.txt", b"x" * (i % 7)) for i in range(1200)] + [(f"small/g{i}.bin", corpus.text_like(i, 3000)) for i in range(34)]
+    arch = tmp_path / "a.squish"
+    arch.write_bytes(oracle.pack_archive(files, timestamp=1_700_000_000))
+    r = _run("-j", "3", "list", str(arch))                  # the global -j in front of the subcommand
+    assert r.returncode == 0, r.stderr
+    out = r.stdout
+    for label in ("Squash breakdown:", "Squash Summary", "Creation Date (UTC)", "Squish Version", "Compressed size", "Original size",
+                  "Compression Ratio", "Number of files", "Number of chunks", "Top-level directory breakdown:", "Directory", "File Count"):
+        assert label in out, label
+    assert "| Number of files     | 1,234" in out and "14/11/2023 |" in out and "| 1.2.0" in out
+    lines = out.splitlines()
+    i = lines.index("Top-level directory breakdown:")
+    assert lines[i + 1].startswith("+-") and lines[i + 2].startswith("| Directory") and lines[i + 3].startswith("+-")
+    assert lines[i + 4].startswith("| big ") and lines[i + 4].rstrip().endswith("| 1,200 |")      # sorted by count, descending
+    assert lines[i + 5].startswith("| small ") and lines[i + 6].startswith("+-")
+    r = _run("list", str(arch), "--simple")
+    assert r.returncode == 0 and "number_of_files: 1234" in r.stdout
