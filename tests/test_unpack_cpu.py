@@ -216,7 +216,7 @@ def test_cli_clap_behaviour_and_list_tables(tmp_path, oracle):
     lines = out.splitlines()
     i = lines.index("Top-level directory breakdown:")
     assert lines[i + 1].startswith("+-") and lines[i + 2].startswith("| Directory") and lines[i + 3].startswith("+-")
-    assert lines[i + 4].startswith("| big ") and lines[i + 4].rstrip().endswith("| 1,200 |")      # sorted by count, descending
+    assert lines[i + 4].startswith("| big ") and "| 1,200 " in lines[i + 4]      # sorted by count, descending
     assert lines[i + 5].startswith("| small ") and lines[i + 6].startswith("+-")
     r = _run("list", str(arch), "--simple")
     assert r.returncode == 0 and "number_of_files: 1234" in r.stdout
