@@ -415,12 +415,16 @@ SQ_DEV WvGroup wv_group(u32 key, bool active, u8* scratch /*LDS 2048 B*/) {
 // exclusive prefix sum over lanes of a u32 (device only); returns (exclusive, total)
 #if SQ_ON_DEVICE
 SQ_DEV u32 wv_excl_scan(u32 v, u32* total) {
+    // Hillis-Steele inside every row of 16 lanes with DPP row shifts (zero fill), then the two row broadcasts of
+    // GCN / CDNA: lane 15 of a row into the next row (rows 1 and 3), lane 31 into rows 2 and 3.  Six v_add_u32 with
+    // a DPP operand instead of six trips through the LDS crossbar (ds_bpermute).
     u32 x = v;
-    const u32 lane = wv_lane();
-    for (int d = 1; d < 64; d <<= 1) {
-        u32 y = (u32)__shfl_up((int)x, d, 64);
-        if (lane >= (u32)d) x += y;
-    }
+    x += (u32)__builtin_amdgcn_update_dpp(0, (int)x, 0x111 /* row_shr:1 */, 0xF, 0xF, true);
+    x += (u32)__builtin_amdgcn_update_dpp(0, (int)x, 0x112 /* row_shr:2 */, 0xF, 0xF, true);
+    x += (u32)__builtin_amdgcn_update_dpp(0, (int)x, 0x114 /* row_shr:4 */, 0xF, 0xF, true);
+    x += (u32)__builtin_amdgcn_update_dpp(0, (int)x, 0x118 /* row_shr:8 */, 0xF, 0xF, true);
+    x += (u32)__builtin_amdgcn_update_dpp(0, (int)x, 0x142 /* row_bcast:15 */, 0xA, 0xF, false);
+    x += (u32)__builtin_amdgcn_update_dpp(0, (int)x, 0x143 /* row_bcast:31 */, 0xC, 0xF, false);
     *total = wv_readlane(x, 63);
     return x - v;
 }

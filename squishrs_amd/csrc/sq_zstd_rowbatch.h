@@ -47,6 +47,7 @@ struct RowBatch {
     u32 ml[64], off[64], rl[64], be[64], flags[64];
 #endif
     u32 B0, n, valid, off1; // wave-uniform
+    u32 ldsOk;              // wave-uniform: the lanes' source bytes are in LDS (g_lds.grp; clobbered by an insertion sweep)
 };
 #if SQ_ON_DEVICE
 #define RB_GET(bt, f, i) wv_readlane((bt).f, (i))
@@ -220,6 +221,21 @@ SQ_DEVFN void rb_prepare(MatchState& ms, RowBatch& bt, u32 B0, u32 n, u32 off1, 
     bt.off = 0;
     bt.be = 0;
     bt.flags = flags;
+    { // what rb_eval reads of OTHER lanes goes to LDS once per batch
+        SQ_L u32* const Lrow = (SQ_L u32*)g_lds.u.rb.rowId;
+        SQ_L u32* const Lprev = (SQ_L u32*)g_lds.u.rb.prev;
+        SQ_L u32* const Lown = (SQ_L u32*)g_lds.grp;
+        Lrow[lane] = rowId;
+        Lprev[2 * lane] = (u32)bt.ownPrev;
+        Lprev[2 * lane + 1] = (u32)(bt.ownPrev >> 32);
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            Lown[8 * lane + k] = own0[k];
+            Lown[8 * lane + 4 + k] = own1[k];
+        }
+        bt.ldsOk = 1;
+        wv_fence();
+    }
     PROF_ADD(4, t_rb);
     PROF_CNT(16, 1);
 }
@@ -253,17 +269,17 @@ SQ_DEVFN void rb_eval(MatchState& ms, RowBatch& bt, u32 i0, u32 iendPos) {
     SQ_L u32* const Lown = (SQ_L u32*)g_lds.grp; // the 32 bytes at every lane's position
     SQ_L u32* const Lprev = (SQ_L u32*)g_lds.u.rb.prev;
     SQ_L u8* const Lbe = (SQ_L u8*)g_lds.u.rb.be;
-    Lprev[2 * lane] = (u32)bt.ownPrev;
-    Lprev[2 * lane + 1] = (u32)(bt.ownPrev >> 32);
-    Lrow[lane] = bt.rowId;
     Lpb[lane] = pbase;
     Lstop[lane] = 0xFFFFFFFFu;
     Lbest[lane] = 0;
     Lflag[lane] = 0;
+    if (!bt.ldsOk) { // an insertion sweep (exact finder) has used the scratch in between
 #pragma unroll
-    for (int k = 0; k < 4; k++) {
-        Lown[8 * lane + k] = bt.own0[k];
-        Lown[8 * lane + 4 + k] = bt.own1[k];
+        for (int k = 0; k < 4; k++) {
+            Lown[8 * lane + k] = bt.own0[k];
+            Lown[8 * lane + 4 + k] = bt.own1[k];
+        }
+        bt.ldsOk = 1;
     }
     u32 P = 0;
     {
@@ -551,7 +567,7 @@ SQ_DEV u32 compressBlock_lazy_rb_impl(MatchState& ms, SeqStore& ss, u32* rep, co
     ms.lazySkipping = 0;
     RowBatch bt;
     bt.valid = 0;
-    bt.B0 = bt.n = bt.off1 = 0;
+    bt.B0 = bt.n = bt.off1 = bt.ldsOk = 0;
     u32 physNext = ms.nextToUpdate; // positions below it are in the tables (as far as libzstd inserts them)
 
     // everything the finder logically holds (positions < ms.nextToUpdate) goes into the tables
@@ -587,6 +603,7 @@ SQ_DEV u32 compressBlock_lazy_rb_impl(MatchState& ms, SeqStore& ss, u32* rep, co
         if (!(RB_GET(bt, flags, i) & (SQZ_RB_EXACT | SQZ_RB_DONE))) rb_eval(ms, bt, i, iendPos);
         if (RB_GET(bt, flags, i) & SQZ_RB_EXACT) {
             PROF_CNT(17, 1);
+            bt.ldsOk = 0; // (row_insert_range ranks equal rows in the same LDS scratch)
             if (physNext < q) row_insert_range(ms, physNext, q);
             ms.nextToUpdate = q;
             u32 const r = row_find(ms, base + q, base + iendPos, offOut);
