@@ -453,6 +453,10 @@ static int compress_enqueue(sq_ctx* c, sq_lane* L, const u8* d_data, const u32* 
         int occ = 0; // resident waves per CU (LDS-bound)
         (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, sqz::k_incompressible_batch, 64, 0);
         if (occ < 1) occ = 4;
+        if (const char* e = getenv("SQ_STAGE1_WAVES_PER_CU")) { // experiment: leave room for another lane's kernels
+            int const w = atoi(e);
+            if (w >= 1 && w < occ) occ = w;
+        }
         fwaves = c->cfg.compress_waves ? c->cfg.compress_waves * 2 : (u32)c->num_cu * (u32)occ;
         fwaves = std::min(fwaves, n);
         if ((r = L->b_cert.ensure((size_t)n * 8))) return r;

@@ -20,7 +20,9 @@
 #include "zstd_frame_decoder.hpp"
 
 #include <dirent.h>
+#include <fcntl.h>
 #include <sys/stat.h>
+#include <sys/uio.h>
 #include <unistd.h>
 
 #include <cerrno>
@@ -130,7 +132,7 @@ static std::string strip_prefix(const std::string& path, const std::string& pref
     return path.substr(i);
 }
 
-static uint64_t pack(const std::string& input, const std::string& output, int device, uint64_t batch_bytes) {
+static uint64_t pack(const std::string& input, const std::string& output, int device, uint64_t batch_bytes, long max_threads) {
     std::string trimmed = input;
     while (!trimmed.empty() && (trimmed.back() == '/' || trimmed.back() == '\\')) trimmed.pop_back();
     std::vector<std::string> files = walk_dir(trimmed); // lib.rs:36
@@ -238,50 +240,100 @@ uint64_t const eff_batch = std::max<uint64_t>(std::min<uint64_t>(batch_bytes, to
         cv.notify_all();
     };
 
+    // The reader: the reference reads every file on its Rayon workers (writer.rs:153-165, process_file's read
+    // loop 233-246).  Here the chunk plan -- file, offset, length, batch, position in the batch buffer -- follows
+    // from the file sizes alone (files in slice order, 2 MiB chunks, the batch layout of sq_pack_submit: starts padded
+    // to 256 bytes), so up to `-j` reader threads (cmd/mod.rs:16) fill a batch's chunks in parallel with pread();
+    // the archive's bytes do not depend on how many there are.
+    struct PlanChunk {
+        size_t file;
+        uint64_t foff;
+        uint32_t len;
+        size_t pos;
+    };
+    std::vector<std::vector<PlanChunk>> plan(1);
+    {
+        size_t used = 0;
+        for (size_t f = 0; f < files.size(); f++)
+            for (uint64_t o = 0; o < sizes[f]; o += SQ_CHUNK_SIZE) { // an empty file has no chunk (writer.rs:241-245)
+                uint32_t const len = (uint32_t)std::min<uint64_t>(SQ_CHUNK_SIZE, sizes[f] - o);
+                size_t const pos = (used + 255) & ~(size_t)255;
+                plan.back().push_back({f, o, len, pos});
+                used = pos + len;
+                if (used >= eff_batch || plan.back().size() >= 4096) {
+                    plan.emplace_back();
+                    used = 0;
+                }
+            }
+    }
+    unsigned const hw = std::max(1u, std::thread::hardware_concurrency());
+    size_t const n_readers = (size_t)std::max<long>(1, std::min<long>(max_threads, (long)hw));
     std::thread reader([&] {
         try {
-            int k = 0;
-            if (!wait_state(bt[k], 0)) return;
-            bt[k].data.ensure((size_t)eff_batch + 2 * (size_t)SQ_CHUNK_SIZE + 4096);
-            auto hand_over = [&](bool last) -> bool {
-                bt[k].last = last;
-                set_state(bt[k], 1);
-                if (last) return true;
-                k = (k + 1) % NB;
-                if (!wait_state(bt[k], 0)) return false;
-                bt[k].data.ensure((size_t)eff_batch + 2 * (size_t)SQ_CHUNK_SIZE + 4096);
-                return true;
-            };
-            for (size_t f = 0; f < files.size(); f++) { // writer.rs:229-271, files in slice order
-                FILE* in = fopen(files[f].c_str(), "rb");
-                if (!in) throw AppError{std::string("I/O error: ") + strerror(errno)};
-                for (;;) {
-                    Batch& b = bt[k];
-                    size_t const pos = (b.used + 255) & ~(size_t)255;
-                    double const tr0 = now_s();
-                    size_t got = fread(b.data.p + pos, 1, SQ_CHUNK_SIZE, in);
-                    t_read += now_s() - tr0;
-                    if (got == 0) break; // writer.rs:241-245
-                    b.used = pos + got;
-                    b.off.push_back(pos);
-                    b.len.push_back((uint32_t)got);
-                    b.owner.push_back(f);
-                    if (b.used >= eff_batch || b.len.size() >= 4096) {
-                        if (!hand_over(false)) {
-                            fclose(in);
-                            return;
+            for (size_t bi = 0; bi < plan.size(); bi++) {
+                Batch& b = bt[bi % NB];
+                if (!wait_state(b, 0)) return;
+                std::vector<PlanChunk> const& pc = plan[bi];
+                b.data.ensure((size_t)eff_batch + 2 * (size_t)SQ_CHUNK_SIZE + 4096);
+                double const tr0 = now_s();
+                std::atomic<size_t> next{0};
+                std::string rerr;
+                std::mutex rmu;
+                auto work = [&]() {
+                    int fd = -1;
+                    size_t cur = (size_t)-1;
+                    for (;;) {
+                        size_t const i = next.fetch_add(1);
+                        if (i >= pc.size()) break;
+                        PlanChunk const& c = pc[i];
+                        if (c.file != cur) {
+                            if (fd >= 0) close(fd);
+                            fd = open(files[c.file].c_str(), O_RDONLY);
+                            cur = c.file;
+                        }
+                        ssize_t got = 0;
+                        if (fd >= 0)
+                            for (size_t done = 0; done < c.len; done += (size_t)got) {
+                                got = pread(fd, b.data.p + c.pos + done, c.len - done, (off_t)(c.foff + done));
+                                if (got <= 0) break;
+                            }
+                        if (fd < 0 || got <= 0) {
+                            std::lock_guard<std::mutex> lk(rmu);
+                            if (rerr.empty()) rerr = std::string("I/O error: ") + (fd < 0 || got < 0 ? strerror(errno) : "file changed while packing");
+                            break;
                         }
                     }
-                    if (got < SQ_CHUNK_SIZE) break;
+                    if (fd >= 0) close(fd);
+                };
+                size_t const nt = std::min(n_readers, std::max<size_t>(1, pc.size()));
+                std::vector<std::thread> pool;
+                for (size_t t = 1; t < nt; t++) pool.emplace_back(work);
+                work();
+                for (auto& t : pool) t.join();
+                if (!rerr.empty()) throw AppError{rerr};
+                for (auto const& c : pc) {
+                    b.off.push_back(c.pos);
+                    b.len.push_back(c.len);
+                    b.owner.push_back(c.file);
                 }
-                fclose(in);
+                b.used = pc.empty() ? 0 : pc.back().pos + pc.back().len;
+                t_read += now_s() - tr0;
+                b.last = bi + 1 == plan.size();
+                set_state(b, 1);
             }
-            hand_over(true);
         } catch (const AppError& e) {
             fail(e.msg);
         }
     });
 
+    // The writer (fsutil/writer.rs:17-39): ONE stage emits the chunk records in canonical order.  Every record's
+    // place in the file follows from the frame lengths of the records before it, so the stage lays a batch's
+    // records out with a prefix sum and lets up to 8 threads pwritev() them (hash || original_size ||
+    // compressed_size || frame per record); the bytes are those of the reference's single writer thread.
+    fflush(out);
+    int const out_fd = fileno(out);
+    uint64_t file_pos = 27; // behind the preamble
+    size_t const n_writers = (size_t)std::max<long>(1, std::min<long>(std::min<long>(max_threads, 8), (long)hw));
     std::thread writer([&] {
         try {
             for (int k = 0;; k = (k + 1) % NB) {
@@ -289,16 +341,62 @@ uint64_t const eff_batch = std::max<uint64_t>(std::min<uint64_t>(batch_bytes, to
                 if (!wait_state(b, 2)) return;
                 double const tw0 = now_s();
                 uint32_t const n = (uint32_t)b.len.size();
+                std::vector<uint64_t> at((size_t)n, 0); // file offset of record i (new chunks only)
+                std::vector<uint32_t> recs;
                 for (uint32_t i = 0; i < n; i++) {
                     metas[b.owner[i]].hashes.emplace_back((const char*)&b.hashes[(size_t)16 * i], 16); // writer.rs:267
                     if (b.is_new[i]) { // fsutil/writer.rs:21-36
-                        uint64_t osz = SQ_CHUNK_SIZE /* chunk_buf.len(), writer.rs:255 */, csz = b.coff[i + 1] - b.coff[i];
-                        fwrite(&b.hashes[(size_t)16 * i], 1, 16, out);
-                        fwrite(&osz, 8, 1, out);
-                        fwrite(&csz, 8, 1, out);
-                        fwrite(b.comp.p + b.coff[i], 1, csz, out);
+                        at[i] = file_pos;
+                        file_pos += 32 + (b.coff[i + 1] - b.coff[i]);
+                        recs.push_back(i);
                     }
                 }
+                std::atomic<size_t> next{0};
+                std::string werr;
+                std::mutex wmu;
+                auto work = [&]() {
+                    for (;;) {
+                        size_t const r = next.fetch_add(1);
+                        if (r >= recs.size()) return;
+                        uint32_t const i = recs[r];
+                        uint64_t const osz = SQ_CHUNK_SIZE /* chunk_buf.len(), writer.rs:255 */, csz = b.coff[i + 1] - b.coff[i];
+                        uint8_t hdr[32];
+                        memcpy(hdr, &b.hashes[(size_t)16 * i], 16);
+                        memcpy(hdr + 16, &osz, 8);
+                        memcpy(hdr + 24, &csz, 8);
+                        struct iovec iov[2] = {{hdr, 32}, {b.comp.p + b.coff[i], (size_t)csz}};
+                        uint64_t off = at[i];
+                        size_t left = 32 + (size_t)csz;
+                        int cnt = 2;
+                        struct iovec* v = iov;
+                        while (left) {
+                            ssize_t const w = pwritev(out_fd, v, cnt, (off_t)off);
+                            if (w <= 0) {
+                                std::lock_guard<std::mutex> lk(wmu);
+                                if (werr.empty()) werr = std::string("I/O error: ") + strerror(errno);
+                                return;
+                            }
+                            left -= (size_t)w;
+                            off += (uint64_t)w;
+                            size_t adv = (size_t)w;
+                            while (cnt && adv >= v->iov_len) {
+                                adv -= v->iov_len;
+                                v++;
+                                cnt--;
+                            }
+                            if (cnt && adv) {
+                                v->iov_base = (char*)v->iov_base + adv;
+                                v->iov_len -= adv;
+                            }
+                        }
+                    }
+                };
+                size_t const nt = std::min(n_writers, std::max<size_t>(1, recs.size()));
+                std::vector<std::thread> pool;
+                for (size_t t = 1; t < nt; t++) pool.emplace_back(work);
+                work();
+                for (auto& t : pool) t.join();
+                if (!werr.empty()) throw AppError{werr};
                 t_write += now_s() - tw0;
                 bool const last = b.last;
                 b.used = 0;
@@ -382,7 +480,7 @@ uint64_t const eff_batch = std::max<uint64_t>(std::min<uint64_t>(batch_bytes, to
         uint64_t count = sq_unique_count(ctx); // writer.rs:177-184
         fseek(out, 19, SEEK_SET);
         fwrite(&count, 8, 1, out);
-        fseek(out, 0, SEEK_END);
+        fseek(out, (long)file_pos, SEEK_SET); // behind the last chunk record
     }
     { // writer.rs:292-329
         std::string m;
@@ -716,7 +814,7 @@ int main(int argc, char** argv) {
             if (!have_output) output = input + ".squish"; // lib.rs:31 (untrimmed input)
             uint64_t batch = 1ull << 30;
             if (const char* e = getenv("SQUISH_BATCH_BYTES")) batch = strtoull(e, nullptr, 10);
-            uint64_t sz = pack(input, output, device, batch);
+            uint64_t sz = pack(input, output, device, batch, max_threads);
             std::string shown = output.rfind("./", 0) == 0 ? output.substr(2) : output;
             printf("%s\nCompressed to %s\n%s: %s\n", green("Packing complete!").c_str(), shown.c_str(),
                    blue("Final archive size").c_str(), format_bytes(sz).c_str()); // lib.rs:49-55
