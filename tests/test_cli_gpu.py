@@ -136,3 +136,41 @@ def test_pack_unpack_roundtrip(tmp_path):
     assert r.returncode == 0, r.stderr
     a, b = arch.read_bytes(), small.read_bytes()
     assert len(a) == len(b) and a[:11] == b[:11] and a[19:] == b[19:]
+
+
+def test_sharded_pack_launcher_one_gpu_equals_driver_archive(tmp_path, oracle):
+    """squishrs_amd.sharded_pack (the multi-GPU launcher, here with ONE rank and the real HIP stages, small
+    super-batches so the dedup set persists across them): its archive equals the C++ driver's and the oracle's byte
+    for byte except the timestamp; -j 1 and -j 16 readers of the driver give the same bytes."""
+    import sys
+    tree = tmp_path / "in"
+    files = {
+        "a/one.txt": corpus.text_like(11, 123456),
+        "a/two.bin": corpus.mixed(12, 2097152 + 777),
+        "b/one_again.txt": corpus.text_like(11, 123456),
+        "b/rnd.bin": corpus.random_bytes(5, 9, 262144),
+        "c/empty": b"",
+        "c/zeros.bin": bytes(300000),
+        "c/two_again.bin": corpus.mixed(12, 2097152 + 777),
+    }
+    for rel, data in files.items():
+        p = tree / rel
+        p.parent.mkdir(parents=True, exist_ok=True)
+        p.write_bytes(data)
+    drv = tmp_path / "driver.squish"
+    r = _run("-j", "16", "pack", str(tree), "-o", str(drv))
+    assert r.returncode == 0, r.stderr
+    drv1 = tmp_path / "driver_j1.squish"
+    r = _run("-j", "1", "pack", str(tree), "-o", str(drv1))
+    assert r.returncode == 0, r.stderr
+    a, a1 = drv.read_bytes(), drv1.read_bytes()
+    assert a[19:] == a1[19:]
+    shd = tmp_path / "sharded.squish"
+    env = dict(os.environ, PYTHONPATH=ROOT)
+    r = subprocess.run([sys.executable, "-m", "squishrs_amd.sharded_pack", str(tree), "-o", str(shd), "--batch-chunks", "3"],
+                       capture_output=True, text=True, env=env, cwd=ROOT, timeout=600)
+    assert r.returncode == 0, r.stderr
+    b = shd.read_bytes()
+    assert b[:11] == a[:11] and b[19:] == a[19:], "sharded launcher's archive differs from the driver's"
+    order = _manifest_order(a)
+    assert a[19:] == oracle.pack_archive([(rel, files[rel]) for rel in order], timestamp=0)[19:]
