@@ -40,6 +40,11 @@ class ShardedPacker:
         Returns (all_hashes in global index order, n_total, my_first)."""
         if self.world == 1:
             return hashes[: n_local * 16], n_local, 0
+        if hashes.is_cuda and dist.get_backend(self.group) == "gloo":
+            # (rehearsal of the multi-rank path on one GPU: gloo moves host tensors; RCCL takes device tensors)
+            torch.cuda.current_stream().synchronize()
+            g, n_total, my_first = self.gather_hashes(hashes.cpu(), n_local)
+            return g.to(hashes.device), n_total, my_first
         dev = hashes.device
         cnt = torch.tensor([n_local], dtype=torch.int64, device=dev)
         counts = torch.zeros(self.world, dtype=torch.int64, device=dev)

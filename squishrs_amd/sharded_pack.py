@@ -104,6 +104,8 @@ def pack_sharded(files: List[Tuple[str, str]], out_path: Optional[str], stages, 
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     rank = dist.get_rank(group) if dist.is_initialized() else 0
     packer = ShardedPacker(stages, group)
+    # frames travel to the writer as device tensors with RCCL, as host tensors with gloo (CPU tests, rehearsals)
+    comm_dev = "cpu" if (dist.is_initialized() and dist.get_backend(group) == "gloo") else device
     sizes = [len(c) for c in contents] if contents is not None else [os.path.getsize(p) for _, p in files]
     fi, fo, ln = chunk_plan(sizes)
     n_chunks = len(ln)
@@ -157,11 +159,11 @@ def pack_sharded(files: List[Tuple[str, str]], out_path: Optional[str], stages, 
                 if r == 0:
                     r_flags, r_clen, r_blob = flags, clen, blob.cpu().numpy()
                 else:
-                    meta = torch.zeros(2 * r_cnt + 1, dtype=torch.int64, device=device)
+                    meta = torch.zeros(2 * r_cnt + 1, dtype=torch.int64, device=comm_dev)
                     dist.recv(meta, src=r, group=group)
                     m = meta.cpu().numpy()
                     r_flags, r_clen = m[:r_cnt].astype(np.uint8), m[r_cnt:2 * r_cnt]
-                    r_blob_t = torch.zeros(max(int(m[2 * r_cnt]), 1), dtype=torch.uint8, device=device)
+                    r_blob_t = torch.zeros(max(int(m[2 * r_cnt]), 1), dtype=torch.uint8, device=comm_dev)
                     dist.recv(r_blob_t, src=r, group=group)
                     r_blob = r_blob_t.cpu().numpy()
                 pos = 0
@@ -175,9 +177,9 @@ def pack_sharded(files: List[Tuple[str, str]], out_path: Optional[str], stages, 
                         pos += int(r_clen[j])
                         unique += 1
         else:
-            meta = torch.from_numpy(np.concatenate([flags.astype(np.int64), clen, [int(comp_off[-1])]]).astype(np.int64)).to(device)
+            meta = torch.from_numpy(np.concatenate([flags.astype(np.int64), clen, [int(comp_off[-1])]]).astype(np.int64)).to(comm_dev)
             dist.send(meta, dst=0, group=group)
-            dist.send(blob if blob.numel() else torch.zeros(1, dtype=torch.uint8, device=device), dst=0, group=group)
+            dist.send((blob if blob.numel() else torch.zeros(1, dtype=torch.uint8, device=device)).to(comm_dev), dst=0, group=group)
     if rank != 0:
         return None
     # ---- manifest (writer.rs:292-329): file_count, then per file path_len, path, orig_size, chunk_count, hashes
@@ -208,16 +210,18 @@ def main(argv=None):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     assert torch.cuda.is_available(), "sharded_pack needs GPUs (the product has no CPU path)"
-    torch.cuda.set_device(local_rank)
+    # SQUISH_DEVICE / SQUISH_BACKEND: rehearse several ranks on ONE GPU (all on that device, gloo for the exchange)
+    dev_ord = int(os.environ.get("SQUISH_DEVICE", local_rank))
+    torch.cuda.set_device(dev_ord)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl")
+        dist.init_process_group(os.environ.get("SQUISH_BACKEND", "nccl"))
     from .chunk import ChunkStore
     files = walk_files(a.input)
     sizes = [os.path.getsize(p) for _, p in files]
     n_chunks = sum((s + CHUNK_SIZE - 1) // CHUNK_SIZE for s in sizes)
     out = a.output or (os.path.basename(os.path.normpath(a.input)) + ".squish")   # lib.rs:49-55 default name
-    st = ChunkStore(device=local_rank, dedup_capacity=n_chunks + 1024)
+    st = ChunkStore(device=dev_ord, dedup_capacity=n_chunks + 1024)
     t0 = time.time()
     size = pack_sharded(files, out, st, device="cuda", batch_chunks=a.batch_chunks)
     if world > 1:
