@@ -644,10 +644,10 @@ static int compress_finish(sq_ctx* c, sq_lane* L, u8* d_comp, u64 comp_cap, u64*
         fprintf(stderr, "[squish_gpu prof] wave finish times ms: min %.3f p10 %.3f median %.3f p90 %.3f p99 %.3f max %.3f\n",
                 (double)fin.front() / 1e5, (double)fin[fin.size() / 10] / 1e5, (double)fin[fin.size() / 2] / 1e5,
                 (double)fin[fin.size() * 9 / 10] / 1e5, (double)fin[fin.size() * 99 / 100] / 1e5, (double)fin.back() / 1e5);
-        static const char* nm[33] = {"frame_total", "table_clear", "dubt_update", "dubt_find", "row_update|rb_compute", "row_find(exact)",
+        static const char* nm[33] = {"frame_total", "table_clear", "dubt_update|eval_setup", "dubt_find|eval_ownerloop", "row_update|rb_prepare", "row_find|rb_eval+exact",
                                      "entropy", "copies", "presplit+filterinit", "epoch_insert|rb_flush", "epoch_predicate|rb_refresh", "epoch_rollback|gather_lits",
-                                     "ins_phase1|rep_direct", "ins_phase23", "ins_tail", "bloom_rebuild",
-                                     "#tail_iters|#batches", "#bloom_overflow|#exact_searches", "#superbatches|#refreshes", "#candidates|#cand_rounds", "#survivors|#batch_answers", "#nLive_sum|#rep_direct", "#repairs_x1000+eager_x1e6", "#exact_finds",
+                                     "ins_phase1|rep_direct", "ins_phase23|eval_trips", "ins_tail", "bloom_rebuild",
+                                     "#tail_iters|#batches", "#bloom_overflow|#exact_searches", "#superbatches|#refreshes", "#candidates|#cand_rounds", "#survivors|#batch_answers", "#nLive_sum|#rep_direct", "#repairs_x1000+eager_x1e6|#pairs", "#exact_finds",
                                      "cert_predict", "tail_certify", "#tail_certs", "cert_scan_p2", "cert_blockwalk", "-", "-", "-", "chunks+1"};
         static const char* nmL[29] = {"frame_total", "table_clear", "dubt_update", "dubt_find", "row_update", "row_find",
                                       "entropy", "copies", "presplit+filterinit", "epoch_insert", "epoch_predicate", "epoch_rollback",

@@ -33,6 +33,9 @@
 #define SQZ_RB_EXACT 1u
 #define SQZ_RB_DONE 2u // the lane's candidates have been evaluated (device; the simulator evaluates every lane at once)
 #define SQZ_RB_ROUND 256u // candidate pairs evaluated per round
+#ifndef SQZ_RB_SPEC
+#define SQZ_RB_SPEC 256u  // ... of which speculative ones (beyond the first three lanes) up to this total (48 / 96 / 160 measured: fewer pairs, more rounds, no gain)
+#endif
 #define SQZ_RB_RLCAP 16u
 #define SQZ_RB_BECAP 8u
 
@@ -256,7 +259,11 @@ SQ_DEVFN void rb_eval(MatchState& ms, RowBatch& bt, u32 i0, u32 iendPos) {
     u32 const mycnt = cand_lane ? bt.cnt : 0u;
     u32 total;
     u32 const pbase = wv_excl_scan(mycnt, &total);
-    bool const sel = lane >= i0 && lane < bt.n && pbase + mycnt <= SQZ_RB_ROUND; // a contiguous run of lanes from i0
+    // a contiguous run of lanes from i0: the three positions the lazy parser is about to look at in any case, more
+    // only while they are cheap (SQZ_RB_SPEC pairs): candidate evaluation runs at the HBM's rate of random 64-byte
+    // sectors (measured: 8 pairs per input byte on mixed data), so pairs of positions the parser may skip are the
+    // one thing not to spend
+    bool const sel = lane >= i0 && lane < bt.n && pbase + mycnt <= SQZ_RB_ROUND && (lane < i0 + 3 || pbase + mycnt <= SQZ_RB_SPEC);
     u32 const cnt = (sel && cand_lane) ? mycnt : 0u;
     u64 const owners = wv_ballot(cnt != 0);
     SQ_L u16* const Ldesc = (SQ_L u16*)g_lds.u.rb.desc;
@@ -281,6 +288,8 @@ SQ_DEVFN void rb_eval(MatchState& ms, RowBatch& bt, u32 i0, u32 iendPos) {
         }
         bt.ldsOk = 1;
     }
+    PROF_ADD(2, t_ev); // setup: scan + LDS cells
+    PROF_T0(t_ol);
     u32 P = 0;
     {
         u64 const below = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
@@ -298,8 +307,11 @@ SQ_DEVFN void rb_eval(MatchState& ms, RowBatch& bt, u32 i0, u32 iendPos) {
         }
     }
     wv_fence();
+    PROF_ADD(3, t_ol); // owner loop
+    PROF_T0(t_tr);
     if (P) {
         PROF_CNT(19, 1);
+        PROF_CNT(22, P);
         u32 c[4], own[4], len[4], ord[4];
         bool has[4];
 #pragma unroll
@@ -359,6 +371,7 @@ SQ_DEVFN void rb_eval(MatchState& ms, RowBatch& bt, u32 i0, u32 iendPos) {
         }
     }
     wv_fence();
+    PROF_ADD(13, t_tr); // the two trips + compares + atomics
     u32 ml = 3, bestC = 0, be = 0;
     if (cnt) {
         // (a long candidate anywhere in front of the first stopper sends the position to the exact finder, even where
