@@ -168,6 +168,11 @@ void sq_host_free(void* p);
  * kernel time in ms through *ms.  bench.py reports it beside the 8 TB/s nominal peak. */
 int sq_calibrate_read_bw(sq_ctx* ctx, const uint8_t* d_buf, uint64_t nbytes, float* ms);
 
+/* Random-access calibration (16-byte loads at pseudo-random places of d_buf, 8 in flight per lane, 8 waves of 256
+ * lanes... per CU): kernel time in ms and the number of loads issued.  The compressor's candidate evaluation on
+ * compressible data is bound by this rate, not by streaming bandwidth; bench.py reports it beside configs[3]. */
+int sq_calibrate_gather(sq_ctx* ctx, const uint8_t* d_buf, uint64_t nbytes, uint32_t per_lane, float* ms, uint64_t* requests);
+
 /* Timing of the most recent stage launches of this ctx, in milliseconds, measured with HIP
  * events on the ctx stream (0 if the stage did not run). */
 typedef struct sq_timings {

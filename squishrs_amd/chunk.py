@@ -187,6 +187,13 @@ class ChunkStore:
         check(self._L.sq_calibrate_read_bw(self._h, buf.data_ptr(), buf.numel(), ctypes.byref(ms)))
         return ms.value
 
+    def gather_rate(self, buf, per_lane: int = 512) -> float:
+        """sq_calibrate_gather: random 16-byte loads per second over `buf` (device tensor)."""
+        ms = ctypes.c_float(0)
+        req = ctypes.c_uint64(0)
+        check(self._L.sq_calibrate_gather(self._h, buf.data_ptr(), buf.numel(), per_lane, ctypes.byref(ms), ctypes.byref(req)))
+        return req.value / (ms.value / 1e3)
+
     def timings(self) -> SqTimings:
         t = SqTimings()
         check(self._L.sq_last_timings(self._h, ctypes.byref(t)))

@@ -401,6 +401,25 @@ int sq_calibrate_read_bw(sq_ctx* c, const uint8_t* d_buf, uint64_t nbytes, float
     return SQ_OK;
 }
 
+int sq_calibrate_gather(sq_ctx* c, const uint8_t* d_buf, uint64_t nbytes, uint32_t per_lane, float* ms, uint64_t* requests) {
+    if (!c || !d_buf || !ms || !requests || ((uintptr_t)d_buf & 15) || nbytes < 4096 || per_lane == 0) return SQ_E_INVAL;
+    if (c->submitted != c->collected) return SQ_E_INVAL;
+    sq_lane* const L = &c->ln[0];
+    HIPCHK(hipSetDevice(c->device));
+    int r = L->b_misc.ensure(256);
+    if (r) return r;
+    per_lane = (per_lane + 7) & ~7u;
+    dim3 block(256), grid((unsigned)(c->num_cu * 8)); // 8 waves per CU x 4: the occupancy of the compressor and more
+    HIPCHK(hipEventRecord(L->ev[6], L->stream));
+    hipLaunchKernelGGL(sqd::k_gather_bw, grid, block, 0, L->stream, (const uint4*)d_buf, nbytes / 16, per_lane, (u32*)L->b_misc.p);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipEventRecord(L->ev[7], L->stream));
+    HIPCHK(hipStreamSynchronize(L->stream));
+    HIPCHK(hipEventElapsedTime(ms, L->ev[6], L->ev[7]));
+    *requests = (uint64_t)grid.x * 256 * per_lane;
+    return SQ_OK;
+}
+
 #ifndef SQ_NO_COMPRESS
 // Frames are produced into per-chunk slots (bound(len) bytes, 16-byte aligned).  h_comp_len ==
 // nullptr: the slots are a scratch buffer and the frames are then packed back to back into d_comp

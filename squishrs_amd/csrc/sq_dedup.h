@@ -152,4 +152,25 @@ k_read_bw(const uint4* __restrict__ p, u64 n16, u32* __restrict__ sink) {
     if (acc == 0x12345678u) *sink = acc; // never true in practice; keeps the loads alive
 }
 
+// Random-access calibration: every lane reads `per_lane` 16-byte words at pseudo-random 16-byte aligned places of the
+// buffer (an LCG per lane; 8 independent loads in flight per lane, like the candidate evaluation of the row-hash
+// search batches).  The rate of such requests, not the streaming bandwidth, bounds the compressor on compressible
+// data; bench.py reports it beside the configs[3] leg.
+__global__ void __launch_bounds__(256)
+k_gather_bw(const uint4* __restrict__ p, u64 n16, u32 per_lane, u32* __restrict__ sink) {
+    u64 x = ((u64)blockIdx.x * blockDim.x + threadIdx.x) * 0x9E3779B97F4A7C15ull + 0x632BE59BD9B4E019ull;
+    u32 acc = 0;
+    for (u32 i = 0; i < per_lane; i += 8) {
+        uint4 v[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            x = x * 6364136223846793005ull + 1442695040888963407ull;
+            v[k] = p[(x >> 20) % n16];
+        }
+#pragma unroll
+        for (int k = 0; k < 8; k++) acc ^= v[k].x ^ v[k].y ^ v[k].z ^ v[k].w;
+    }
+    if (acc == 0x12345678u) *sink = acc; // never true in practice; keeps the loads alive
+}
+
 } // namespace sqd
