@@ -293,6 +293,7 @@ def test_pack_submit_wait_two_batches_in_flight(oracle):
                          torch.zeros(n, dtype=torch.uint8, device="cuda"),
                          torch.empty(st.slots_bound(lens), dtype=torch.uint8, device="cuda")))
         results = []
+        torch.cuda.synchronize()   # (torch's fills of the output tensors run on torch's stream, the lanes on their own)
         st.pack_submit(*bufs[0], reset=True)
         st.pack_submit(*bufs[1])
         with pytest.raises(squishrs_amd.SquishError):       # both lanes busy
