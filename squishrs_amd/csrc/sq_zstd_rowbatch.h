@@ -629,6 +629,14 @@ SQ_DEV u32 compressBlock_lazy_rb_impl(MatchState& ms, SeqStore& ss, u32* rep, co
         if (ml > 3) *offOut = RB_GET(bt, off, i);
         return ml;
     };
+    // The parser's state is wave-uniform by construction; saying so (v_readfirstlane) where values come back from the
+    // finder keeps it in SGPRs: scalar ALU and scalar branches instead of VALU arithmetic under exec masks.
+    auto searchU = [&](u32 q, u32* offOut) -> u32 {
+        u32 o = *offOut;
+        u32 const r = wv_uni(search(wv_uni(q), &o));
+        *offOut = wv_uni(o);
+        return r;
+    };
     // length of the repcode match at q for offset `off` (0 if its first 4 bytes differ)
     auto rep_len = [&](u32 q, u32 off, bool mayRefresh) -> u32 {
         if (bt.valid && q >= bt.B0 && q < bt.B0 + bt.n && (bt.off1 == off || mayRefresh)) {
@@ -651,8 +659,13 @@ SQ_DEV u32 compressBlock_lazy_rb_impl(MatchState& ms, SeqStore& ss, u32* rep, co
         PROF_ADD(12, t_rd);
         return r;
     };
+    auto repU = [&](u32 q, u32 off, bool mayRefresh) -> u32 { return wv_uni(rep_len(wv_uni(q), wv_uni(off), mayRefresh)); };
 
     while (ip < ilimitPos) {
+        ip = wv_uni(ip);
+        anchor = wv_uni(anchor);
+        offset_1 = wv_uni(offset_1);
+        offset_2 = wv_uni(offset_2);
         u32 matchLength = 0;
         u32 offBase = 1; // REPCODE1_TO_OFFBASE
         u32 start = ip + 1;
@@ -660,9 +673,9 @@ SQ_DEV u32 compressBlock_lazy_rb_impl(MatchState& ms, SeqStore& ss, u32* rep, co
             // (the search first: it makes the batch that then answers the repcode test at ip + 1 as well; the two
             // are independent, the comparison below is libzstd's)
             u32 offbaseFound = 999999999;
-            u32 const ml2 = search(ip, &offbaseFound);
+            u32 const ml2 = searchU(ip, &offbaseFound);
             if (ms.fault) break;
-            if (offset_1 > 0) matchLength = rep_len(ip + 1, offset_1, true);
+            if (offset_1 > 0) matchLength = repU(ip + 1, offset_1, true);
             if (ml2 > matchLength) matchLength = ml2, start = ip, offBase = offbaseFound;
         }
         if (matchLength < 4) {
@@ -694,14 +707,14 @@ SQ_DEV u32 compressBlock_lazy_rb_impl(MatchState& ms, SeqStore& ss, u32* rep, co
         while (ip < ilimitPos) {
             ip++;
             if (offset_1 > 0) {
-                u32 const mlRep = rep_len(ip, offset_1, true);
+                u32 const mlRep = repU(ip, offset_1, true);
                 int const gain2 = (int)(mlRep * 3);
                 int const gain1 = (int)(matchLength * 3 - sq_highbit32(offBase) + 1);
                 if ((mlRep >= 4) && (gain2 > gain1)) matchLength = mlRep, offBase = 1, start = ip;
             }
             {
                 u32 ofbCandidate = 999999999;
-                u32 const ml2 = search(ip, &ofbCandidate);
+                u32 const ml2 = searchU(ip, &ofbCandidate);
                 int const gain2 = (int)(ml2 * 4 - sq_highbit32(ofbCandidate));
                 int const gain1 = (int)(matchLength * 4 - sq_highbit32(offBase) + 4);
                 if ((ml2 >= 4) && (gain2 > gain1)) {
@@ -712,14 +725,14 @@ SQ_DEV u32 compressBlock_lazy_rb_impl(MatchState& ms, SeqStore& ss, u32* rep, co
             if (ip < ilimitPos) {
                 ip++;
                 if (offset_1 > 0) {
-                    u32 const mlRep = rep_len(ip, offset_1, true);
+                    u32 const mlRep = repU(ip, offset_1, true);
                     int const gain2 = (int)(mlRep * 4);
                     int const gain1 = (int)(matchLength * 4 - sq_highbit32(offBase) + 1);
                     if ((mlRep >= 4) && (gain2 > gain1)) matchLength = mlRep, offBase = 1, start = ip;
                 }
                 {
                     u32 ofbCandidate = 999999999;
-                    u32 const ml2 = search(ip, &ofbCandidate);
+                    u32 const ml2 = searchU(ip, &ofbCandidate);
                     int const gain2 = (int)(ml2 * 4 - sq_highbit32(ofbCandidate));
                     int const gain1 = (int)(matchLength * 4 - sq_highbit32(offBase) + 7);
                     if ((ml2 >= 4) && (gain2 > gain1)) {
@@ -756,7 +769,7 @@ SQ_DEV u32 compressBlock_lazy_rb_impl(MatchState& ms, SeqStore& ss, u32* rep, co
         if (ms.lazySkipping) ms.lazySkipping = 0;
 
         while ((ip <= ilimitPos) && (offset_2 > 0)) {
-            u32 const ml2 = rep_len(ip, offset_2, false);
+            u32 const ml2 = repU(ip, offset_2, false);
             if (ml2 < 4) break;
             u32 const t = offset_2;
             offset_2 = offset_1;
