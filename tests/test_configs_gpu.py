@@ -381,3 +381,26 @@ def test_pack_submit_wait_host_buffers(oracle):
         assert st.len() == len(seen)
     finally:
         st.close()
+
+
+def test_rowbatch_every_kind_and_size_vs_oracle(gpu_store, oracle):
+    """The lazy2 / row-hash strategy (chunks > 256 KiB) over speculative search batches (sq_zstd_rowbatch.h): every
+    corpus kind at ragged sizes of that strategy -- long runs (every lane of a batch in one row: in-batch candidates
+    and delegation to the exact finder), records (matches at fixed distances: repcode cache and refresh), skewed and
+    random stretches (no-match fast-forward, lazy skipping), text (dozens of true candidates per search: windowed
+    evaluation), planted repeats -- every frame against the oracle."""
+    from test_compress_gpu import _batch_compress
+    rng = np.random.default_rng(77)
+    kinds = ["text", "records", "runs", "skewed", "mixed", "random", "zeros", "planted2", "planted4"]
+    chunks = []
+    for i in range(54):
+        n = int(rng.choice([262145, 262200, 300000, 524288, 524289, 1048576, 1500001, 2097151, 2097152,
+                            int(rng.integers(262145, 2097152))]))
+        chunks.append(corpus.make(kinds[i % len(kinds)], 5000 + i, n))
+    # two chunks made of alternating short stretches: the parser changes mode every few KiB
+    parts = [corpus.make(kinds[j % 6], 6000 + j, 3000 + 700 * (j % 5)) for j in range(300)]
+    chunks.append(b"".join(parts)[:2097152])
+    chunks.append((b"".join(parts[::-1]) * 2)[:1234567])
+    frames = _batch_compress(gpu_store, chunks)
+    bad = [(i, len(c)) for i, (c, f) in enumerate(zip(chunks, frames)) if f != oracle.compress_chunk(c)]
+    assert not bad, bad[:10]
