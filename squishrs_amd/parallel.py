@@ -35,17 +35,22 @@ class ShardedPacker:
         if self.world > 1 and torch.cuda.is_available() and hasattr(stages, "set_stream"):
             stages.set_stream(torch.cuda.current_stream().cuda_stream)
 
-    def gather_hashes(self, hashes: torch.Tensor, n_local: int):
+    def gather_hashes(self, hashes: torch.Tensor, n_local: int, uniform: bool = False):
         """All-gather of the ranks' hash arrays (16 B x n_local, padded to the max count).
-        Returns (all_hashes in global index order, n_total, my_first)."""
+        Returns (all_hashes in global index order, n_total, my_first).  uniform=True: the caller vouches that every
+        rank holds n_local chunks (bench.py), which saves the exchange of the counts and its host round trip."""
         if self.world == 1:
             return hashes[: n_local * 16], n_local, 0
         if hashes.is_cuda and dist.get_backend(self.group) == "gloo":
             # (rehearsal of the multi-rank path on one GPU: gloo moves host tensors; RCCL takes device tensors)
             torch.cuda.current_stream().synchronize()
-            g, n_total, my_first = self.gather_hashes(hashes.cpu(), n_local)
+            g, n_total, my_first = self.gather_hashes(hashes.cpu(), n_local, uniform)
             return g.to(hashes.device), n_total, my_first
         dev = hashes.device
+        if uniform:
+            recv = torch.empty(self.world * n_local * 16, dtype=torch.uint8, device=dev)
+            dist.all_gather_into_tensor(recv, hashes[: n_local * 16].contiguous(), group=self.group)
+            return recv, self.world * n_local, self.rank * n_local
         cnt = torch.tensor([n_local], dtype=torch.int64, device=dev)
         counts = torch.zeros(self.world, dtype=torch.int64, device=dev)
         dist.all_gather_into_tensor(counts, cnt, group=self.group)
@@ -64,14 +69,15 @@ class ShardedPacker:
         parts = [recv[r * n_max * 16: r * n_max * 16 + int(counts_h[r]) * 16] for r in range(self.world)]
         return torch.cat(parts), n_total, my_first
 
-    def pack(self, data, offs: np.ndarray, lens: np.ndarray, hashes, is_new, comp, layout: str = "packed"):
+    def pack(self, data, offs: np.ndarray, lens: np.ndarray, hashes, is_new, comp, layout: str = "packed",
+             uniform: bool = False):
         """hash -> all-gather -> global dedup -> compress own new chunks.
         layout "packed": frames back to back in `comp`, returns comp_off[n + 1];
         layout "slots" : frames left in their slots of `comp` (no packing pass), returns
                          (comp_off[n], comp_len[n])."""
         n = len(lens)
         self.stages.hash_device(data, offs, lens, hashes)
-        all_hashes, n_total, my_first = self.gather_hashes(hashes, n)
+        all_hashes, n_total, my_first = self.gather_hashes(hashes, n, uniform)
         self.stages.dedup_device(all_hashes, n_total, my_first, n, is_new)
         if layout == "slots":
             return self.stages.compress_device_slots(data, offs, lens, is_new, comp)

@@ -216,3 +216,38 @@ def test_sharded_pack_single_process_and_walk_order(tmp_path):
     body = {p: c for p, c in files}
     want = oracle_lib.load().pack_archive([(r, body[r]) for r, _ in walked], timestamp=99)
     assert open(out, "rb").read() == want and size == len(want)
+
+
+def _uniform_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    sys.path.insert(0, ROOT)
+    from squishrs_amd.parallel import ShardedPacker
+    p = ShardedPacker(OracleStages())
+    n = 5
+    mine = torch.arange(n * 16, dtype=torch.uint8) + rank * 80
+    a = p.gather_hashes(mine, n, uniform=True)
+    b = p.gather_hashes(mine, n)
+    q.put((rank, a[0].tolist() == b[0].tolist(), a[1], a[2], b[1], b[2]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_uniform_gather_skips_the_count_exchange():
+    """bench.py passes uniform=True (every rank holds n chunks): same gathered list, totals and first index."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_uniform_worker, args=(r, 3, port, q)) for r in range(3)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(3))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, same, nt_a, mf_a, nt_b, mf_b in res:
+        assert same and nt_a == nt_b == 15 and mf_a == mf_b == 5 * rank
