@@ -4,22 +4,31 @@
 // libzstd's lazy parser asks the row-hash finder one position at a time (ZSTD_RowFindBestMatch, reached from
 // /root/reference/src/util/chunk.rs:89-90), and on a GPU every such search is a chain of dependent memory round
 // trips (source bytes -> tag row -> entries -> candidate bytes) during which a wave does nothing else: round 1
-// measured ~1 us per search and one wave 50x slower than one CPU core.  Here ONE chain of round trips answers the
-// search at 64 consecutive positions, one per lane, before the parser needs them:
+// measured ~1 us per search and one wave 50x slower than one CPU core.  Here ONE chain of round trips prepares the
+// searches of 64 consecutive positions, one per lane, before the parser needs them:
 //
-//   * While the parser is not in "lazy skipping" mode, ZSTD_row_update inserts EVERY position between two searches
-//     (distances inside a batch are < 384, the skip rule of ZSTD_row_update_internal never fires), so the table a
-//     search at q = B0 + i sees is: the table as it stands when the batch is made (everything below B0 inserted)
-//     plus the positions B0 .. q-1.  Lane i therefore evaluates (a) the earlier positions of the batch that share
-//     its row AND tag (found by in-wave grouping of the hashes), most recent first, then (b) the row's entries in
-//     recency order, the r oldest of which -- r = earlier batch positions in the same row, whatever their tag --
-//     have been overwritten by then and are left out.  First longest candidate wins, exactly as in
-//     ZSTD_RowFindBestMatch.  The physical insertion of the batch's positions is deferred until the parser leaves
-//     the batch (or needs the exact finder), so the rows are read in the state every lane assumes.
-//   * Per lane the batch also leaves: the repcode-1 match length at its position for the parser's current
-//     offset_1 (refreshed in one round trip when a sequence changes the offset; the stale values then ARE the new
-//     offset_2's, which is what the parser checks right after a match), and the backward-extension count of its
-//     best candidate.  The parser runs on these registers (v_readlane) and touches memory only to store sequences.
+//   * Why that is exact.  While the parser is not in "lazy skipping" mode, ZSTD_row_update inserts EVERY position
+//     between two searches (distances inside a batch are < 384, the skip rule of ZSTD_row_update_internal never
+//     fires), so the table a search at q = B0 + i sees is: the table as it stands when the batch is made (everything
+//     below B0 inserted) plus the positions B0 .. q-1.  Lane i therefore has as candidates (a) the earlier positions
+//     of the batch that share its row AND tag (found by in-wave grouping of the hashes), most recent first, then
+//     (b) the row's entries in recency order, the r oldest of which -- r = earlier batch positions in the same row,
+//     whatever their tag -- have been overwritten by then and are left out.  First longest candidate wins, a slot
+//     that was never written ends the scan: ZSTD_RowFindBestMatch's rules.  The physical insertion of the batch's
+//     positions is deferred until the parser leaves the batch (or needs the exact finder), so the rows are read in
+//     the state every lane assumes.
+//   * rb_prepare (one chain of three trips per batch): source bytes, hashes, grouping, the 64-byte tag row -> every
+//     lane's candidate masks; and the repcode-1 match length at every lane for the parser's current offset_1
+//     (refreshed in one trip when a sequence changes the offset; the stale values then ARE the new offset_2's, which
+//     is what the parser checks right after a match).
+//   * rb_eval (two trips): the candidates are evaluated for a WINDOW of lanes starting at the position the parser
+//     asks for -- as many lanes as fit one round of 256 (owner, candidate) pairs, at least the three positions the
+//     lazy parser is about to look at, all 64 where candidates are few -- balanced over the wave through LDS, with
+//     no lane-serial loop: on repetitive data a search has dozens of TRUE candidates and the kernel runs at the
+//     memory system's rate of small random requests, so pairs of positions the parser skips are not to be spent.
+//     Per lane it leaves the best match and the backward-extension count of that candidate.
+//   * The parser runs on these registers (v_readlane) and touches memory only to store sequences; runs of positions
+//     known to give nothing are skipped in one step.
 //   * A lane whose answer cannot be had this way (a candidate that matches 32 bytes or more, positions within 32
 //     bytes of the chunk end) is flagged; the parser then inserts up to that position and calls the exact finder
 //     (row_find).  Lazy-skipping stretches (no match for 2 KiB) use the exact finder as before.
