@@ -212,9 +212,11 @@ static uint64_t pack(const std::string& input, const std::string& output, int de
     uint64_t total_bytes = 0;
     for (uint64_t z : sizes) total_bytes += z;
     // batch size: the configured one, but no larger than an eighth of the input (four batches rotate through the
-    // stages, two of them in flight on the GPU: enough batches for the stages to overlap) (small inputs should not pay
+    // stages, two of them in flight on the GPU: enough batches for the stages to overlap) -- and not below 256 MiB:
+    // the compressor runs one wave per chunk, a compressible 2 MiB chunk takes a wave the better part of a second,
+    // so a small input must reach the GPU in one or two batches for its chunks to be compressed side by side (small inputs should not pay
     // for page-locking gigabytes they never fill)
-uint64_t const eff_batch = std::max<uint64_t>(std::min<uint64_t>(batch_bytes, total_bytes / 8 + SQ_CHUNK_SIZE), 8u << 20);
+    uint64_t const eff_batch = std::max<uint64_t>(std::min<uint64_t>(batch_bytes, std::max<uint64_t>(total_bytes / 8 + SQ_CHUNK_SIZE, 256ull << 20)), 8u << 20);
     int const NB = 4; // reader: 1, gpu: 2 in flight (sq_pack_submit / sq_pack_wait), writer: 1
     Batch bt[4];
     {   // Page-locking costs ~0.2 s per GiB here and only pays when the GPU stage (two PCIe crossings) is the
