@@ -814,7 +814,7 @@ int main(int argc, char** argv) {
         if (pos[0] == "pack") {
             std::string input = pos[1];
             if (!have_output) output = input + ".squish"; // lib.rs:31 (untrimmed input)
-            uint64_t batch = 1ull << 30;
+            uint64_t batch = 4ull << 30; // 2,048 chunks of 2 MiB: one per compressor wave (an eighth of the input at most, see pack())
             if (const char* e = getenv("SQUISH_BATCH_BYTES")) batch = strtoull(e, nullptr, 10);
             uint64_t sz = pack(input, output, device, batch, max_threads);
             std::string shown = output.rfind("./", 0) == 0 ? output.substr(2) : output;
