@@ -996,7 +996,7 @@ u32 zs_MLcode(u32 mlBase) { /* ZSTD_MLcode */
 }
 
 static u32 kInvProbLog256[256];
-static void init_invprob(void) {
+__attribute__((constructor)) static void init_invprob(void) {  /* filled at load time: callers run on thread pools */
     /* kInverseProbabilityLog256[x] = floor(-log2(x/256) * 256), [0] = 0.  Computed with exact
      * integer arithmetic: find largest v with 2^(v/256) * x <= 256, i.e. compare
      * x^256 * 2^v <= 256^256 via repeated squaring in fixed point.  To stay simple and exact we

@@ -608,7 +608,7 @@ static void ps_merge(Fingerprint* acc, const Fingerprint* newfp) {
 static size_t splitBlock_byChunks(const u8* p, size_t blockSize, int level) {
     static const size_t rates[] = {43, 11, 5, 1};
     static const u32 hashParams[] = {8, 9, 10, 10};
-    static Fingerprint past, newEv; /* single-threaded oracle */
+    static __thread Fingerprint past, newEv; /* per thread: the oracle is called from thread pools (bench_threads.c, tools/gpu_fuzz.py) */
     int penalty = 3;
     size_t pos;
     const size_t CHUNKSIZE = 8 << 10;

@@ -97,3 +97,17 @@ def test_cross_shard_plan_for_config4():
         assert ((plan[dup] // n) != (np.nonzero(dup)[0] // n)).all()  # ... on another shard
         assert len(np.unique(plan)) == N - int(0.3 * N)
     assert (corpus.cross_shard_plan(1, 10) == np.arange(10)).all()
+
+
+def test_oracle_is_reentrant(oracle):
+    """The checker is called from thread pools (oracle/bench_threads.c, tools/gpu_fuzz.py): frames made on 16 threads
+    must equal the ones made one at a time.  (Round 2: the pre-block splitter's fingerprints were one static pair
+    shared by all threads, and a GPU fuzz run blamed the device for the oracle's own corruption.)"""
+    from concurrent.futures import ThreadPoolExecutor
+    import corpus
+    chunks = [corpus.make(["text", "records", "mixed", "skewed", "zeros"][i % 5], i, 300_000 + 37_001 * i)
+              for i in range(20)]
+    single = [oracle.compress_chunk(c) for c in chunks]
+    for _ in range(2):
+        with ThreadPoolExecutor(16) as ex:
+            assert list(ex.map(oracle.compress_chunk, chunks)) == single
