@@ -469,8 +469,8 @@ static int compress_enqueue(sq_ctx* c, sq_lane* L, const u8* d_data, const u32* 
     size_t etab_bytes = 0;
     if (fast) {
         etab_bytes = 0; // the certificate's set lives in LDS now; a wave's slice only keeps its 256 bytes of saved state
-        int occ = 0; // resident waves per CU (LDS-bound)
-        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, sqz::k_incompressible_batch, 64, 0);
+        int occ = 0; // resident workgroups (of SQZ_FAST_WG_WAVES waves, one chunk each) per CU
+        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, sqz::k_incompressible_batch, 64 * SQZ_FAST_WG_WAVES, 0);
         if (occ < 1) occ = 4;
         if (const char* e = getenv("SQ_STAGE1_WAVES_PER_CU")) { // experiment: leave room for another lane's kernels
             int const w = atoi(e);
@@ -499,7 +499,7 @@ static int compress_enqueue(sq_ctx* c, sq_lane* L, const u8* d_data, const u32* 
         (void)hipFuncGetAttributes(&fa, (const void*)sqz::k_compress_batch);
         fprintf(stderr, "[squish_gpu] compress kernel: occupancy %d blocks/CU, regs %d, lds %zu, scratch %zu; waves %u, ws_each %zu\n",
                 nb, fa.numRegs, fa.sharedSizeBytes, fa.localSizeBytes, waves, ws_each);
-        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, sqz::k_incompressible_batch, 64, 0);
+        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, sqz::k_incompressible_batch, 64 * SQZ_FAST_WG_WAVES, 0);
         (void)hipFuncGetAttributes(&fa, (const void*)sqz::k_incompressible_batch);
         fprintf(stderr, "[squish_gpu] incompressible-chunk kernel: occupancy %d blocks/CU, regs %d, lds %zu, scratch %zu; waves %u, table %zu\n",
                 nb, fa.numRegs, fa.sharedSizeBytes, fa.localSizeBytes, fwaves, etab_bytes);
@@ -507,7 +507,7 @@ static int compress_enqueue(sq_ctx* c, sq_lane* L, const u8* d_data, const u32* 
     L->last.fast_ms = 0;
     if (fast) {
         HIPCHK(hipEventRecord(L->ev[8], L->stream));
-        hipLaunchKernelGGL(sqz::k_incompressible_batch, dim3(fwaves), dim3(64), 0, L->stream, d_data,
+        hipLaunchKernelGGL(sqz::k_incompressible_batch, dim3(fwaves), dim3(64 * SQZ_FAST_WG_WAVES), 0, L->stream, d_data,
                            (const u64*)L->b_off.p, (const u32*)L->b_len.p, d_select, n, d_slots,
                            (const u64*)L->b_slot_off.p, (u32*)L->b_frame_len.p, (u32*)L->b_cert.p, (u8*)L->b_etab.p,
                            (u64)etab_bytes, (u32*)L->b_misc.p + 32 /*queue*/, (const u32*)c->d_sched_tab,

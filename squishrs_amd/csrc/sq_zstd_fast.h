@@ -34,14 +34,46 @@ namespace sqz {
 #endif
 #define SQZ_FAST_BUCKET_MAX 24u // a bucket holds 3.4 values on average; beyond this the data is not random
 
-// LDS of one wave of k_incompressible_batch (18.3 KB: 8 waves per CU)
+// One chunk is certified by a WORKGROUP of SQZ_FAST_WG_WAVES waves that share the chunk's set S in LDS: the
+// filter, the bucketed values and the hit list exist once per chunk, each wave scans its own contiguous part of
+// the chunk with a candidate list of its own.  Two waves per chunk halve the LDS per wave (8 workgroups = 16 waves
+// per CU instead of 8 waves) and the registers the build needs per lane (each wave gathers half of S), which is
+// what lets the VALU-bound scan run at 3-4 waves per SIMD instead of 2.
+#ifndef SQZ_FAST_WG_WAVES
+#define SQZ_FAST_WG_WAVES 2u
+#endif
+#ifndef SQZ_FAST_WAVES_PER_SIMD
+#define SQZ_FAST_WAVES_PER_SIMD 4
+#endif
+#if SQ_ON_DEVICE
+#define FW_NW SQZ_FAST_WG_WAVES
+SQ_DEV u32 fw_wave() { return wv_uni((u32)threadIdx.x >> 6); } // this wave's number inside its workgroup
+SQ_DEV void fw_sync() { __syncthreads(); }                      // every wave of the workgroup reaches every fw_sync()
+SQ_DEV bool fw_first() { return threadIdx.x == 0; }
+#else
+#define FW_NW 1u
+SQ_DEV u32 fw_wave() { return 0; }
+SQ_DEV void fw_sync() {}
+SQ_DEV bool fw_first() { return true; }
+#endif
+// words of FastLds::sh
+#define FW_SH_NHITS 0u  // hits listed so far (may run past SQZ_FAST_HITS: the list is then full)
+#define FW_SH_CERT0 1u  // certEnd  (atomic minimum over the waves)
+#define FW_SH_CERT1 2u  // certEnd1
+#define FW_SH_FLAGS 3u  // 1: the repeats inside S do not fit the hit list, 2: a bucket too large for this path
+#define FW_SH_OK 4u     // HUF pre-check: every block's literals uncompressible
+#define FW_SH_IDX 5u    // the chunk index the workgroup pulled from the queue
+#define FW_SH_FIN 8u    // [FW_NW] position each wave's scan ended at
+
+// LDS of one workgroup of k_incompressible_batch (19.4 KB at two waves: 8 workgroups per CU)
 struct FastLds {
-    u32 bloom[SQZ_BLOOM_WORDS];      // certificate Bloom filter; afterwards the 256-bin sample histograms
+    u32 bloom[SQZ_BLOOM_WORDS];      // certificate Bloom filter; afterwards the 256-bin sample histograms (256 words per wave)
     u16 vals[SQZ_FAST_VALS];         // per scheduled position: bits 6..21 of its 4-byte value, grouped by bits 22..31
     u32 ends[SQZ_FAST_KEYS / 2 + 2]; // per bucket, packed 2 x u16: first counts, then starts, finally END offsets
-    u32 cand[256];                   // a round's Bloom positives: 128 x (position, bytes)
+    u32 cand[FW_NW * 256];           // per wave, a few rounds' Bloom positives: 128 x (position, bytes)
     u32 hits[2 * SQZ_FAST_HITS];     // (position, bytes) of scanned positions whose bytes equal a scheduled position's;
                                      // position 0 = two scheduled positions with equal bytes
+    u32 sh[16];                      // words shared by the waves (FW_SH_*)
 #ifdef SQ_PROF
     unsigned long long prof[8]; // 100 MHz ticks: 0 build, 1 scan loop, 2 look-ups (inside 1), 3 hit resolution, 4 pre-check + frame, 5 whole chunk
 #endif
@@ -92,7 +124,7 @@ SQ_DEVFN u32 fast_literals_uncompressible(const u8* blk, u32 size, u32* count /*
 #define FPROF_ADD(L, slot, v)                                              \
     do {                                                                   \
         unsigned long long e_ = __builtin_amdgcn_s_memrealtime();          \
-        if (wv_lane() == 0) (L)->prof[slot] += e_ - (v);                   \
+        if (threadIdx.x == 0) (L)->prof[slot] += e_ - (v);                 \
     } while (0)
 #else
 #define FPROF_T0(v) do { } while (0)
@@ -251,14 +283,25 @@ SQ_DEV void cert_lds_core(CertCtx& cx, FastLds* L, u8* rawOut) {
     SQ_L u16* const vals = (SQ_L u16*)L->vals; // 16-bit tags: with the bucket's 10 bits, 26 bits of the value
     SQ_L u32* const ends = (SQ_L u32*)L->ends;
     SQ_L u32* const hits = (SQ_L u32*)L->hits;
-    u32 nHits = 0;
 #if SQ_ON_DEVICE
     u32 const lane = wv_lane();
+    u32 const wv = fw_wave();
+    u32 const tid = 64 * wv + lane;
+    constexpr u32 NW = FW_NW, NT = 64 * FW_NW;
+    constexpr u32 ITS_ALL = SQZ_FAST_VALS / 512;      // batches of 512 scheduled positions
+    constexpr u32 ITS = (ITS_ALL + NW - 1) / NW;      // ... of which this wave takes numbers wv, wv + NW, ...
     u64 const below = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
-    SQ_L u32* const cand = (SQ_L u32*)L->cand;
-    for (u32 i = lane; i < SQZ_BLOOM_WORDS; i += 64) bloom[i] = 0;
-    for (u32 i = lane; i < SQZ_FAST_KEYS / 2 + 2; i += 64) ends[i] = 0;
-    wv_fence();
+    SQ_L u32* const cand = (SQ_L u32*)L->cand + 256 * wv;
+    SQ_L u32* const sh = (SQ_L u32*)L->sh;
+    for (u32 i = tid; i < SQZ_BLOOM_WORDS; i += NT) bloom[i] = 0;
+    for (u32 i = tid; i < SQZ_FAST_KEYS / 2 + 2; i += NT) ends[i] = 0;
+    if (tid == 0) {
+        sh[FW_SH_NHITS] = 0;
+        sh[FW_SH_CERT0] = certEnd;
+        sh[FW_SH_CERT1] = certEnd1;
+        sh[FW_SH_FLAGS] = 0;
+    }
+    fw_sync();
     u32 vmin = 0xFFFFFFFFu, vmin1 = 0xFFFFFFFFu; // lane-local minima of the violating scheduled positions
     auto note = [&](u32 sviol, u32& v0, u32& v1) {
         if (sviol < blk1)
@@ -266,7 +309,7 @@ SQ_DEV void cert_lds_core(CertCtx& cx, FastLds* L, u8* rawOut) {
         else
             v1 = sviol < v1 ? sviol : v1;
     };
-    auto settle = [&](u32 v0, u32 v1) { // wave minima of the violations -> certEnd / certEnd1
+    auto settle = [&](u32 v0, u32 v1) { // wave minima of the violations -> the workgroup's certEnd / certEnd1
         if (wv_ballot((v0 & v1) != 0xFFFFFFFFu)) {
             u32 x = v0, z = v1;
             for (int sft = 32; sft >= 1; sft >>= 1) {
@@ -274,52 +317,53 @@ SQ_DEV void cert_lds_core(CertCtx& cx, FastLds* L, u8* rawOut) {
                 x = y < x ? y : x;
                 z = w < z ? w : z;
             }
-            x = wv_uni(x);
-            z = wv_uni(z);
-            if (x < certEnd) certEnd = x;
-            if (z < certEnd1) certEnd1 = z;
+            if (lane == 0) {
+                __hip_atomic_fetch_min(&sh[FW_SH_CERT0], x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                __hip_atomic_fetch_min(&sh[FW_SH_CERT1], z, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
         }
     };
     auto pushHit = [&](bool have, u32 p, u32 vp) -> bool { // false: the list is full
         u64 const m = wv_ballot(have);
         if (!m) return true;
-        u32 const slot = nHits + (u32)__popcll(m & below);
+        u32 const cnt = (u32)__popcll(m);
+        u32 at = 0;
+        if (lane == 0) at = __hip_atomic_fetch_add(&sh[FW_SH_NHITS], cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        at = wv_uni(at);
+        u32 const slot = at + (u32)__popcll(m & below);
         if (have && slot < SQZ_FAST_HITS) {
             hits[2 * slot] = p;
             hits[2 * slot + 1] = vp;
         }
-        nHits += (u32)__popcll(m);
-        if (nHits > SQZ_FAST_HITS) {
-            nHits = SQZ_FAST_HITS;
-            return false;
-        }
-        return true;
+        return at + cnt <= SQZ_FAST_HITS;
     };
     FPROF_T0(t_build);
     // ---- build pass 1: Bloom filter, bucket counts, repcode test.  The values at the scheduled positions are
     // gathered ONCE (an 8-byte load gives the bytes at s and at s + 1) and stay in registers for the scatter
     // below: every gather is a 64-byte sector of HBM, 3,500 of them per chunk and pass.
     u32 const nBuild = (cx.dbg & 1) ? 0u : nCert; // SQ_FAST_DBG timing experiments: 1 = no build, 2 = no scan
-    u32 vv[SQZ_FAST_VALS / 64];
+    u32 vv[8 * ITS];
     if (cx.repOff <= 1) {
-        // all positions first (seven short trips to the L2-resident table), then ALL gathers in flight at
-        // once: one trip to HBM per chunk instead of seven
-        u32 spA[SQZ_FAST_VALS / 64];
-        u64 q[SQZ_FAST_VALS / 64];
+        // all positions first (short trips to the L2-resident table), then ALL gathers in flight at
+        // once: one trip to HBM per chunk
+        u32 spA[8 * ITS];
+        u64 q[8 * ITS];
 #pragma unroll
-        for (u32 it = 0; it < SQZ_FAST_VALS / 512; it++) {
+        for (u32 it = 0; it < ITS; it++) {
+            u32 const i0 = 512 * (it * NW + wv);
             u32 sp[8];
 #pragma unroll
             for (u32 g = 0; g < 8; g++) sp[g] = 0;
-            if (512 * it < nBuild) cert_pos8(cx, 512 * it + lane, nCert, sp);
+            if (i0 < nBuild) cert_pos8(cx, i0 + lane, nCert, sp);
 #pragma unroll
             for (u32 g = 0; g < 8; g++) spA[8 * it + g] = sp[g];
         }
 #pragma unroll
-        for (u32 it = 0; it < SQZ_FAST_VALS / 512; it++) {
+        for (u32 it = 0; it < ITS; it++) {
+            u32 const i0 = 512 * (it * NW + wv);
 #pragma unroll
             for (u32 g = 0; g < 8; g++) q[8 * it + g] = 0;
-            if (512 * it < nBuild) {
+            if (i0 < nBuild) {
 #pragma unroll
                 for (u32 g = 0; g < 8; g++) q[8 * it + g] = sq_grd64(base + spA[8 * it + g]); // s + 8 <= block end
             }
@@ -327,7 +371,7 @@ SQ_DEV void cert_lds_core(CertCtx& cx, FastLds* L, u8* rawOut) {
         wv_fence();
         u64 repBits = 0; // (the upper halves of the 8-byte loads are dead after this loop)
 #pragma unroll
-        for (u32 it = 0; it < SQZ_FAST_VALS / 512; it++) {
+        for (u32 it = 0; it < ITS; it++) {
             u32 lo32[8];
 #pragma unroll
             for (u32 g = 0; g < 8; g++) lo32[g] = (u32)q[8 * it + g];
@@ -340,8 +384,8 @@ SQ_DEV void cert_lds_core(CertCtx& cx, FastLds* L, u8* rawOut) {
             }
         }
 #pragma unroll
-        for (u32 it = 0; it < SQZ_FAST_VALS / 512; it++) {
-            u32 const i0 = 512 * it;
+        for (u32 it = 0; it < ITS; it++) {
+            u32 const i0 = 512 * (it * NW + wv);
             if (i0 < nBuild) {
 #pragma unroll
                 for (u32 g = 0; g < 8; g++) {
@@ -362,8 +406,8 @@ SQ_DEV void cert_lds_core(CertCtx& cx, FastLds* L, u8* rawOut) {
         }
     } else {
 #pragma unroll
-        for (u32 it = 0; it < SQZ_FAST_VALS / 512; it++) {
-            u32 const i0 = 512 * it;
+        for (u32 it = 0; it < ITS; it++) {
+            u32 const i0 = 512 * (it * NW + wv);
 #pragma unroll
             for (u32 g = 0; g < 8; g++) vv[8 * it + g] = 0;
             if (i0 < nBuild) {
@@ -387,10 +431,9 @@ SQ_DEV void cert_lds_core(CertCtx& cx, FastLds* L, u8* rawOut) {
             }
         }
     }
-    wv_fence();
-    // ---- prefix sum: counts -> bucket starts (16 buckets = 8 words per lane)
-    bool bigBucket = false;
-    {
+    fw_sync(); // every wave's counts are in
+    // ---- prefix sum: counts -> bucket starts (16 buckets = 8 words per lane; one wave does it)
+    if (wv == 0) {
         u32 w[8], c[16], tot = 0;
 #pragma unroll
         for (u32 k = 0; k < 8; k++) w[k] = ends[8 * lane + k];
@@ -403,7 +446,7 @@ SQ_DEV void cert_lds_core(CertCtx& cx, FastLds* L, u8* rawOut) {
         u32 mx = 0;
 #pragma unroll
         for (u32 k = 0; k < 16; k++) mx = c[k] > mx ? c[k] : mx;
-        bigBucket = wv_ballot(mx > SQZ_FAST_BUCKET_MAX) != 0;
+        if (wv_ballot(mx > SQZ_FAST_BUCKET_MAX) != 0 && lane == 0) sh[FW_SH_FLAGS] = 2;
         u32 all = 0;
         u32 run = wv_excl_scan(tot, &all);
 #pragma unroll
@@ -414,17 +457,17 @@ SQ_DEV void cert_lds_core(CertCtx& cx, FastLds* L, u8* rawOut) {
             run += c[2 * k + 1];
             ends[8 * lane + k] = s0 | (s1 << 16);
         }
-        wv_fence();
     }
-    if (bigBucket) { // no certificate
+    fw_sync();
+    if (sh[FW_SH_FLAGS] & 2) { // no certificate (every wave takes this exit)
         cx.certEnd = SQZ_WINDOW_START;
         cx.certEnd1 = (blk1 != 0xFFFFFFFFu) ? SQZ_WINDOW_START : 0u;
         return;
     }
     // ---- build pass 2: scatter the values (from registers); a bucket's start counts up to its end
 #pragma unroll
-    for (u32 it = 0; it < SQZ_FAST_VALS / 512; it++) {
-        u32 const i0 = 512 * it;
+    for (u32 it = 0; it < ITS; it++) {
+        u32 const i0 = 512 * (it * NW + wv);
         if (i0 < nBuild) {
 #pragma unroll
             for (u32 g = 0; g < 8; g++)
@@ -435,10 +478,9 @@ SQ_DEV void cert_lds_core(CertCtx& cx, FastLds* L, u8* rawOut) {
                 }
         }
     }
-    wv_fence();
+    fw_sync();
     // ---- scheduled positions with equal values: equal neighbours inside a bucket
-    bool hitsFull = false;
-    for (u32 k0 = 0; k0 < ((cx.dbg & 128) ? 0u : SQZ_FAST_KEYS); k0 += 64) { // 128: timing experiment
+    for (u32 k0 = 64 * wv; k0 < ((cx.dbg & 128) ? 0u : SQZ_FAST_KEYS); k0 += NT) { // 128: timing experiment
         u32 const k = k0 + lane;
         u32 const lo = k ? fast_get16(ends, k - 1) : 0u, hi = fast_get16(ends, k);
         {   // quick look first: a bucket holds 3.4 values on average; its first 12 are read with independent
@@ -472,11 +514,15 @@ SQ_DEV void cert_lds_core(CertCtx& cx, FastLds* L, u8* rawOut) {
                 }
             }
             if (!wv_ballot(dup)) break;
-            if (!pushHit(dup, 0u, dupv)) hitsFull = true;
+            if (!pushHit(dup, 0u, dupv) && lane == 0)
+                __hip_atomic_fetch_or(&sh[FW_SH_FLAGS], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
     }
     settle(vmin, vmin1);
-    if (hitsFull) { // cannot even list the repeats inside the schedule: no certificate
+    fw_sync();
+    certEnd = sh[FW_SH_CERT0];
+    certEnd1 = sh[FW_SH_CERT1];
+    if (sh[FW_SH_FLAGS] & 1) { // cannot even list the repeats inside the schedule: no certificate
         certEnd = certEnd1 = SQZ_WINDOW_START;
     }
     FPROF_ADD(L, 0, t_build);
@@ -487,12 +533,17 @@ SQ_DEV void cert_lds_core(CertCtx& cx, FastLds* L, u8* rawOut) {
     s32 const p0 = (s32)SQZ_WINDOW_START - (s32)(src0 - a0); // position of a0 (may be negative)
     const u8* const lastByte = base + cx.chunkEndPos - 1;
     const u8* const aLast = lastByte - ((size_t)lastByte & 15);
-    s32 pos = p0;
     bool const rawCopy = rawOut != nullptr && src0 == a0;
     auto scanStop = [&]() -> u32 {
         u32 const ce = (blk1 != 0xFFFFFFFFu) ? certEnd1 : certEnd;
         return ce < pEnd ? ce : pEnd;
     };
+    // the rounds of 1 KiB from p0 up to the stop are dealt out in contiguous runs, one per wave
+    u32 const nRounds = p0 < (s32)scanStop() ? ((u32)((s32)scanStop() - p0) + 1023u) >> 10 : 0u;
+    u32 const perWave = (nRounds + NW - 1) / NW;
+    auto runStart = [&](u32 w) -> s32 { return p0 + (s32)(1024u * (perWave * w < nRounds ? perWave * w : nRounds)); };
+    s32 pos = runStart(wv);
+    s32 const myStop = (runStart(wv + 1) < (s32)scanStop()) ? runStart(wv + 1) : (s32)scanStop();
     u32 const lastOff = (u32)(aLast - a0);
     auto loadRound = [&](s32 rp) -> sq_v4u { // uniform base + 32-bit lane offset, clamped to the last window
         u32 const o = (u32)(rp - p0) + 16 * lane;
@@ -574,7 +625,7 @@ SQ_DEV void cert_lds_core(CertCtx& cx, FastLds* L, u8* rawOut) {
     };
     // look the collected positives up, 64 at a time, while at least `atLeast` are waiting; false = list of hits full
     u32 nCand = 0;
-    s32 pendFrom = p0; // first position whose positives have not all been looked up yet
+    s32 pendFrom = pos; // first position whose positives have not all been looked up yet
     auto lookUp = [&](u32 atLeast) -> bool {
         bool ok = true;
         FPROF_T0(t_look);
@@ -706,111 +757,137 @@ SQ_DEV void cert_lds_core(CertCtx& cx, FastLds* L, u8* rawOut) {
             // ONE look-up site for the five rounds below (inlined into each of them, the look-up code made
             // the loop several times the size of the instruction cache's share of a wave)
             if (nCand >= SQZ_FAST_LOOKUP_BATCH && !lookUp(1)) {
-                cx.nOvf = 2u | (nHits << 8);
+                cx.nOvf = 2u | (sh[FW_SH_NHITS] << 8);
                 full = true;
                 break;
             }
             if (!round(AL, wA, wB, lA)) { full = true; break; }
-            if (pos >= (s32)scanStop()) break;
+            if (pos >= myStop) break;
             wA = loadRound(pos + 4096);
             loadLevels(AL, pos + 4096, lA);
             if (!round(AL, wB, wC, lB)) { full = true; break; }
-            if (pos >= (s32)scanStop()) break;
+            if (pos >= myStop) break;
             wB = loadRound(pos + 4096);
             loadLevels(AL, pos + 4096, lB);
             if (!round(AL, wC, wD, lC)) { full = true; break; }
-            if (pos >= (s32)scanStop()) break;
+            if (pos >= myStop) break;
             wC = loadRound(pos + 4096);
             loadLevels(AL, pos + 4096, lC);
             if (!round(AL, wD, wE, lD)) { full = true; break; }
-            if (pos >= (s32)scanStop()) break;
+            if (pos >= myStop) break;
             wD = loadRound(pos + 4096);
             loadLevels(AL, pos + 4096, lD);
             if (!round(AL, wE, wA, lE)) { full = true; break; }
-            if (pos >= (s32)scanStop()) break;
+            if (pos >= myStop) break;
         }
     };
-    if (pos < (s32)scanStop() && !(cx.dbg & 2)) {
+    if (pos < myStop && !(cx.dbg & 2)) {
         if (src0 == a0)
             scan(std::true_type{});
         else
             scan(std::false_type{});
     }
     if (scanned) {
-        if (rawCopy) cx.rawEnd = (u32)pos < cx.chunkEndPos ? (u32)pos : SQZ_WINDOW_START + ((cx.chunkEndPos - SQZ_WINDOW_START) & ~15u);
         if (!full && !lookUp(1)) full = true; // the positives still waiting
-        if (full) { // more genuine repeats than the list holds (compressible data): positions >= pendFrom
-            // stay unverified, which only matters to searches beyond them
+        if (full && lane == 0) { // more genuine repeats than the list holds (compressible data): positions >=
+            // pendFrom stay unverified, which only matters to searches beyond them
             u32 const cut = (u32)(pendFrom < (s32)SQZ_WINDOW_START ? (s32)SQZ_WINDOW_START : pendFrom) + 1;
-            if (cut < certEnd) certEnd = cut;
-            if (cut < certEnd1) certEnd1 = cut;
+            __hip_atomic_fetch_min(&sh[FW_SH_CERT0], cut, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            __hip_atomic_fetch_min(&sh[FW_SH_CERT1], cut, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
+    }
+    if (lane == 0) sh[FW_SH_FIN + wv] = (u32)pos;
+    fw_sync();
+    if (rawCopy) { // the chunk's prefix that is in place: the runs of the waves, up to the first one that stopped early
+        s32 at = runStart(0);
+        bool any = false;
+        for (u32 w = 0; w < NW; w++) {
+            s32 const fin = (s32)sh[FW_SH_FIN + w];
+            any = any || fin > runStart(w);
+            at = fin;
+            if (fin < runStart(w + 1)) break;
+        }
+        if (any) cx.rawEnd = (u32)at < cx.chunkEndPos ? (u32)at : SQZ_WINDOW_START + ((cx.chunkEndPos - SQZ_WINDOW_START) & ~15u);
     }
     FPROF_ADD(L, 1, t_scan);
     FPROF_T0(t_res);
     // ---- resolve the hits by walking S: a scheduled s fails to be certified when an equal value sits at
     // an earlier position (a scanned position p, or for a pair inside the schedule the earliest member)
+    u32 const nHits = sh[FW_SH_NHITS] < SQZ_FAST_HITS ? sh[FW_SH_NHITS] : SQZ_FAST_HITS;
     if (nHits) {
-        // the positions and values of S once more, all gathers in flight at once, for every hit together
-        u32 spA[SQZ_FAST_VALS / 64], vA[SQZ_FAST_VALS / 64];
+        // the positions and values of S once more (each wave its share), all gathers in flight at once, for
+        // every hit together
+        u32 spA[8 * ITS], vA[8 * ITS];
 #pragma unroll
-        for (u32 it = 0; it < SQZ_FAST_VALS / 512; it++) {
+        for (u32 it = 0; it < ITS; it++) {
+            u32 const i0 = 512 * (it * NW + wv);
             u32 sp[8];
 #pragma unroll
             for (u32 g = 0; g < 8; g++) sp[g] = 0;
-            if (512 * it < nCert) cert_pos8(cx, 512 * it + lane, nCert, sp);
+            if (i0 < nCert) cert_pos8(cx, i0 + lane, nCert, sp);
 #pragma unroll
             for (u32 g = 0; g < 8; g++) spA[8 * it + g] = sp[g];
         }
 #pragma unroll
-        for (u32 it = 0; it < SQZ_FAST_VALS / 512; it++) {
+        for (u32 it = 0; it < ITS; it++) {
+            u32 const i0 = 512 * (it * NW + wv);
 #pragma unroll
             for (u32 g = 0; g < 8; g++) vA[8 * it + g] = 0;
-            if (512 * it < nCert) {
+            if (i0 < nCert) {
 #pragma unroll
                 for (u32 g = 0; g < 8; g++) vA[8 * it + g] = sq_grd32(base + spA[8 * it + g]);
             }
         }
         wv_fence();
-        for (u32 hIdx = 0; hIdx < nHits; hIdx++) {
+        u32 v0 = 0xFFFFFFFFu, v1 = 0xFFFFFFFFu;
+        for (u32 hIdx = 0; hIdx < nHits; hIdx++) { // (the hit list is the workgroup's: every wave walks all of it)
             u32 const hp = hits[2 * hIdx], hv = hits[2 * hIdx + 1];
-            u32 v0 = 0xFFFFFFFFu, v1 = 0xFFFFFFFFu;
             if (hp != 0) { // a scanned position p with the bytes hv: every scheduled s > p with those bytes
 #pragma unroll
-                for (u32 i = 0; i < SQZ_FAST_VALS / 64; i++)
-                    if (64 * i + lane < nCert && vA[i] == hv && spA[i] > hp) note(spA[i], v0, v1);
+                for (u32 it = 0; it < ITS; it++)
+#pragma unroll
+                    for (u32 g = 0; g < 8; g++)
+                        if (512 * (it * NW + wv) + 64 * g + lane < nCert && vA[8 * it + g] == hv && spA[8 * it + g] > hp)
+                            note(spA[8 * it + g], v0, v1);
             } else {
                 // two scheduled positions share bits 6..31 of their values (hv).  Collect the (few) members of
                 // that class; a member whose full value equals an earlier member's is a search that can succeed.
                 SQ_L u32* const mem = (SQ_L u32*)L->cand; // [0] count, then (position, value) pairs
-                if (lane == 0) mem[0] = 0;
-                wv_fence();
+                if (tid == 0) mem[0] = 0;
+                fw_sync();
 #pragma unroll
-                for (u32 i = 0; i < SQZ_FAST_VALS / 64; i++)
-                    if (64 * i + lane < nCert && (vA[i] & 0xFFFFFFC0u) == hv) {
-                        u32 const at = __hip_atomic_fetch_add(&mem[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                        if (at < 60) {
-                            mem[2 + 2 * at] = spA[i];
-                            mem[3 + 2 * at] = vA[i];
+                for (u32 it = 0; it < ITS; it++)
+#pragma unroll
+                    for (u32 g = 0; g < 8; g++)
+                        if (512 * (it * NW + wv) + 64 * g + lane < nCert && (vA[8 * it + g] & 0xFFFFFFC0u) == hv) {
+                            u32 const at = __hip_atomic_fetch_add(&mem[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                            if (at < 60) {
+                                mem[2 + 2 * at] = spA[8 * it + g];
+                                mem[3 + 2 * at] = vA[8 * it + g];
+                            }
                         }
-                    }
-                wv_fence();
+                fw_sync();
                 u32 const nm = mem[0];
-                if (lane < nm && lane < 60) {
+                if (wv == 0 && lane < nm && lane < 60) {
                     u32 const ms = mem[2 + 2 * lane], mv = mem[3 + 2 * lane];
                     bool rpt = nm > 60; // more members than we keep: every one counts as a repeat (conservative)
                     for (u32 j = 0; j < nm && j < 60; j++) rpt = rpt || (mem[3 + 2 * j] == mv && mem[2 + 2 * j] < ms);
                     if (rpt) note(ms, v0, v1);
                 }
+                fw_sync(); // mem is reset by the next hit of this kind
             }
-            settle(v0, v1);
         }
+        settle(v0, v1);
     }
+    fw_sync();
+    certEnd = sh[FW_SH_CERT0];
+    certEnd1 = sh[FW_SH_CERT1];
+    if (sh[FW_SH_FLAGS] & 1) certEnd = certEnd1 = SQZ_WINDOW_START;
     wv_fence();
     FPROF_ADD(L, 3, t_res);
 #else
     // scalar twin: the same statement, computed plainly
-    (void)bloom; (void)vals; (void)ends; (void)hits; (void)nHits; (void)lvlWords;
+    (void)bloom; (void)vals; (void)ends; (void)hits; (void)lvlWords;
     auto note = [&](u32 sviol) {
         if (sviol < blk1)
             certEnd = sviol < certEnd ? sviol : certEnd;
@@ -896,22 +973,31 @@ SQ_DEV u32 fastpath_frame_wave(const u8* src, u32 n, u8* dst, u32 cap, u32* E, u
             if (len1) whole = whole && (cx.certEnd1 >= SQZ_WINDOW_START + SQZ_BLOCKSIZE_MAX + len1 - 8);
             if (dbg & 4) whole = false; // timing experiment: certificate only
             if (whole && sized && room) {
-                u32 ok = fast_literals_uncompressible(src, len0, L->bloom);
-                if (ok && len1) ok = fast_literals_uncompressible(src + len0, len1, L->bloom);
-                if (ok) {
-                    (void)fast_frame_header(dst, n);
+                // HUF's sampled pre-check, one block per wave
+                u32 const wv = fw_wave();
+                if (fw_first()) L->sh[FW_SH_OK] = 1;
+                fw_sync();
+                for (u32 b = wv; b < nBlocks; b += FW_NW)
+                    if (!fast_literals_uncompressible(src + (b ? len0 : 0u), b ? len1 : len0, L->bloom + 256 * wv)) {
+                        WV_SERIAL L->sh[FW_SH_OK] = 0;
+                    }
+                fw_sync();
+                if (L->sh[FW_SH_OK]) {
+                    if (wv == 0) (void)fast_frame_header(dst, n);
                     u8* op = dst + hdr;
                     u32 const done = cx.rawEnd - SQZ_WINDOW_START; // chunk bytes the scan has already put in place
                     for (u32 b = 0; b < nBlocks; b++) {
                         u32 const bs = b ? len1 : len0, b0 = b ? len0 : 0u;
-                        u32 const h = ((b + 1 == nBlocks) ? 1u : 0u) + (0u << 1) + (bs << 3); // ZSTD_noCompressBlock
-                        WV_SERIAL {
-                            op[0] = (u8)h;
-                            op[1] = (u8)(h >> 8);
-                            op[2] = (u8)(h >> 16);
+                        if (b % FW_NW == wv) {
+                            u32 const h = ((b + 1 == nBlocks) ? 1u : 0u) + (0u << 1) + (bs << 3); // ZSTD_noCompressBlock
+                            WV_SERIAL {
+                                op[0] = (u8)h;
+                                op[1] = (u8)(h >> 8);
+                                op[2] = (u8)(h >> 16);
+                            }
+                            u32 const have = done > b0 ? (done - b0 < bs ? done - b0 : bs) : 0u;
+                            if (have < bs) wv_memcpy(op + 3 + have, src + b0 + have, bs - have);
                         }
-                        u32 const have = done > b0 ? (done - b0 < bs ? done - b0 : bs) : 0u;
-                        if (have < bs) wv_memcpy(op + 3 + have, src + b0 + have, bs - have);
                         op += 3 + bs;
                     }
                     frame = (u32)(op - dst);
@@ -920,7 +1006,7 @@ SQ_DEV u32 fastpath_frame_wave(const u8* src, u32 n, u8* dst, u32 cap, u32* E, u
             FPROF_ADD(L, 4, t_frame);
         }
     }
-    WV_SERIAL {
+    if (fw_wave() == 0) WV_SERIAL {
         certOut[0] = c0;
         certOut[1] = c1;
     }
@@ -929,9 +1015,9 @@ SQ_DEV u32 fastpath_frame_wave(const u8* src, u32 n, u8* dst, u32 cap, u32* E, u
 }
 
 #if SQ_ON_DEVICE
-// Persistent waves, one certificate table each; every wave pulls chunk indices from *queue until
-// exhausted (every wave reaches idx >= n).  frame_len[idx] = frame size, or 0 = not decided here.
-__global__ void __launch_bounds__(64, 2)
+// Persistent workgroups of FW_NW waves; every workgroup pulls chunk indices from *queue until exhausted (every
+// workgroup reaches idx >= n).  frame_len[idx] = frame size, or 0 = not decided here.
+__global__ void __launch_bounds__(64 * SQZ_FAST_WG_WAVES, SQZ_FAST_WAVES_PER_SIMD)
 k_incompressible_batch(const u8* data, const u64* off, const u32* len, const u8* select, u32 n, u8* slots,
                        const u64* slot_off, u32* frame_len, u32* cert_out, u8* etab_pool, u64 etab_bytes,
                        u32* queue, const u32* schedTab, u32 dbg, u32 persist, u32* work) {
@@ -939,26 +1025,28 @@ k_incompressible_batch(const u8* data, const u64* off, const u32* len, const u8*
     // lists: [0] / [1] their lengths, then n slots for the "heavy" ones (certified in neither block: the
     // whole exact path) and n slots for the others.
     __shared__ FastLds lds;
-    // a wave's slice: its table, then 256 bytes that keep its generation counter between launches
+    // a workgroup's slice: its table (none in the LDS edition), then 256 bytes that keep its generation counter
+    // between launches
     u32* const E = (u32*)(etab_pool + (u64)blockIdx.x * (etab_bytes + 256));
     u32* const saved = (u32*)((u8*)E + etab_bytes);
+    bool const first = threadIdx.x == 0;
     // 0: the table holds unknown words; `persist`: the host vouches that the pool is as the previous
     // launch left it, so the saved counter is still true and the tags go on counting
     u32 gen = persist ? gld32(saved) : 0u;
 #ifdef SQ_PROF
-    if (wv_lane() == 0)
+    if (first)
         for (int k = 0; k < 8; k++) lds.prof[k] = 0;
-    wv_fence();
 #endif
     for (;;) {
-        u32 idx = 0;
-        if (wv_lane() == 0) idx = atomicAdd(queue, 1u);
-        idx = wv_uni(idx);
+        if (first) lds.sh[FW_SH_IDX] = atomicAdd(queue, 1u);
+        fw_sync();
+        u32 const idx = wv_uni(lds.sh[FW_SH_IDX]);
+        fw_sync(); // (the word is written again at the top of the next turn)
         if (idx >= n) break;
         u32 r = 0;
         if (select == nullptr || select[idx] != 0) {
             if (gen == 0 || gen >= SQZ_HT_GEN_MAX) {
-                wv_fill32(E, 0, etab_bytes / 4);
+                if (fw_wave() == 0) wv_fill32(E, 0, etab_bytes / 4);
                 gen = 0;
             }
             gen++;
@@ -968,11 +1056,11 @@ k_incompressible_batch(const u8* data, const u64* off, const u32* len, const u8*
             r = fastpath_frame_wave(data + off[idx], len[idx], slots + slot_off[idx], cap, E, gen << SQZ_HT_GEN_SHIFT,
                                     schedTab, &lds, cert_out + 2 * (size_t)idx, dbg);
             FPROF_ADD(&lds, 5, t_chunk);
-        } else if (wv_lane() == 0) {
+        } else if (first) {
             cert_out[2 * (size_t)idx] = 0;
             cert_out[2 * (size_t)idx + 1] = 0;
         }
-        if (wv_lane() == 0) {
+        if (first) {
             frame_len[idx] = r;
             if (r)
                 atomicAdd(queue + 1, 1u);
@@ -986,10 +1074,10 @@ k_incompressible_batch(const u8* data, const u64* off, const u32* len, const u8*
             }
         }
     }
-    if (wv_lane() == 0) saved[0] = gen;
+    if (first) saved[0] = gen;
 #ifdef SQ_PROF
-    wv_fence();
-    if (wv_lane() == 0)
+    fw_sync();
+    if (first)
         for (int k = 0; k < 8; k++) ((unsigned long long*)(saved + 8))[k] = lds.prof[k];
 #endif
 }
