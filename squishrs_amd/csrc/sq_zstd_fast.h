@@ -40,7 +40,7 @@ namespace sqz {
 // per CU instead of 8 waves) and the registers the build needs per lane (each wave gathers half of S), which is
 // what lets the VALU-bound scan run at 3-4 waves per SIMD instead of 2.
 #ifndef SQZ_FAST_WG_WAVES
-#define SQZ_FAST_WG_WAVES 2u
+#define SQZ_FAST_WG_WAVES 4u
 #endif
 #ifndef SQZ_FAST_WAVES_PER_SIMD
 #define SQZ_FAST_WAVES_PER_SIMD 4
@@ -248,20 +248,20 @@ SQ_DEV void cert_pos8(const CertCtx& cx, u32 i, u32 nCert, u32 (&sp)[8]) {
     for (u32 g = 0; g < 8; g++) sp[g] = t[g] + ad[g];
 }
 
-// the three 2-byte windows of a scheduled value as keys of the scan's filter (see the scan)
+// the three 2-byte windows of a scheduled value as keys of the scan's filter (see the scan).  A key's cell is the
+// BYTE at (key & 0x1FFF) and its bit there is key >> 13: address and bit index are then one v_bfe each on the
+// scanning side (no shift-and-mask pair), whatever byte offset the window sits at in its register.
 SQ_DEV void vbloom_add3(SQ_L u32* const B, u32 v) {
-#if SQ_ON_DEVICE
 #pragma unroll
     for (u32 k = 0; k < 3; k++) {
         u32 const key = (v >> (8 * k)) & 0xFFFFu;
-        __hip_atomic_fetch_or(&B[key >> 5], 1u << (key & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    }
+        u32 const word = (key & 0x1FFFu) >> 2, bit = 8 * (key & 3u) + (key >> 13);
+#if SQ_ON_DEVICE
+        __hip_atomic_fetch_or(&B[word], 1u << bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 #else
-    for (u32 k = 0; k < 3; k++) {
-        u32 const key = (v >> (8 * k)) & 0xFFFFu;
-        B[key >> 5] |= 1u << (key & 31);
-    }
+        B[word] |= 1u << bit;
 #endif
+    }
 }
 
 // cx: base, schedTab, certCnt0, nCert, base1Pos, tabOff1 (0), repOff, chunkEndPos are inputs;
@@ -680,21 +680,30 @@ SQ_DEV void cert_lds_core(CertCtx& cx, FastLds* L, u8* rawOut) {
         // windows (16 of its own bytes, 2 reaching into the next lane's) is looked up once, and a position
         // passes when the bits of its own window and of the next two are set: three probes (0.3 % false
         // positives at 10,500 keys in 64 Kibit) for the price of one.
+        // The 18 answers are collected Horner-wise (one v_lshl_or each), i.e. in REVERSE order: window j ends up
+        // at bit 17 - j, the three-window AND works the same on the mirrored word, and one v_bfrev turns it back.
         u32 bm = 0;
 #pragma unroll
         for (u32 q = 0; q < 5; q++) {
             u32 const nk = q < 4 ? 4u : 2u;
-            u32 s[4], pw[4];
-            s[0] = d[q];
-            s[1] = d[q] >> 8;
-            s[2] = d[q] >> 16;
-            s[3] = q < 4 ? __builtin_amdgcn_alignbyte(d[q < 4 ? q + 1 : q], d[q], 3) : 0u;
+            u32 const y = q < 4 ? __builtin_amdgcn_alignbyte(d[q < 4 ? q + 1 : q], d[q], 3) : 0u; // the window across two words
+            u32 ad[4], bi[4], pw[4];
 #pragma unroll
-            for (u32 k = 0; k < nk; k++) pw[k] = *(const SQ_L u32*)((const SQ_L u8*)B + ((s[k] >> 3) & 0x1FFCu));
+            for (u32 k = 0; k < nk; k++) {
+                u32 const src = k < 3 ? d[q] : y, sh = k < 3 ? 8 * k : 0u;
+                ad[k] = __builtin_amdgcn_ubfe(src, sh, 13u);
+                bi[k] = __builtin_amdgcn_ubfe(src, sh + 13u, 3u);
+            }
 #pragma unroll
-            for (u32 k = 0; k < nk; k++) bm |= __builtin_amdgcn_ubfe(pw[k], s[k], 1u) << (4 * q + k);
+            for (u32 k = 0; k < nk; k++) pw[k] = *((const SQ_L u8*)B + ad[k]);
+#pragma unroll
+            for (u32 k = 0; k < nk; k++) {
+                u32 const bit = __builtin_amdgcn_ubfe(pw[k], bi[k], 1u);
+                // (spelled out: left to itself hipcc turns the chain into shifts and three-way ORs, 7 instead of 4 per word)
+                asm("v_lshl_or_b32 %0, %1, 1, %2" : "=v"(bm) : "v"(bm), "v"(bit));
+            }
         }
-        u32 cm = bm & (bm >> 1) & (bm >> 2) & okMask;
+        u32 cm = (__builtin_bitreverse32(bm & (bm << 1) & (bm << 2)) >> 14) & okMask;
         if constexpr (decltype(AL)::value) {
             // the window's bitmap word; a block's searches stop 8 bytes before its end (a short last block
             // uses a prefix of the table)
