@@ -682,26 +682,38 @@ SQ_DEV void cert_lds_core(CertCtx& cx, FastLds* L, u8* rawOut) {
         // positives at 10,500 keys in 64 Kibit) for the price of one.
         // The 18 answers are collected Horner-wise (one v_lshl_or each), i.e. in REVERSE order: window j ends up
         // at bit 17 - j, the three-window AND works the same on the mirrored word, and one v_bfrev turns it back.
-        u32 bm = 0;
+        // Order of issue: all 18 addresses, all 18 reads, then the 18 bit indices (VALU work that covers the reads'
+        // latency), then the answers.  (Compiled as written above -- four reads, their answers, the next four --
+        // a round paid five LDS round trips one after the other.)
+        u32 src[18], pw[18];
 #pragma unroll
         for (u32 q = 0; q < 5; q++) {
-            u32 const nk = q < 4 ? 4u : 2u;
             u32 const y = q < 4 ? __builtin_amdgcn_alignbyte(d[q < 4 ? q + 1 : q], d[q], 3) : 0u; // the window across two words
-            u32 ad[4], bi[4], pw[4];
 #pragma unroll
-            for (u32 k = 0; k < nk; k++) {
-                u32 const src = k < 3 ? d[q] : y, sh = k < 3 ? 8 * k : 0u;
-                ad[k] = __builtin_amdgcn_ubfe(src, sh, 13u);
-                bi[k] = __builtin_amdgcn_ubfe(src, sh + 13u, 3u);
-            }
+            for (u32 k = 0; k < (q < 4 ? 4u : 2u); k++) src[4 * q + k] = k < 3 ? d[q] : y;
+        }
+        // (the reads and their one wait are spelled out: hipcc's scheduler keeps at most eight of them in flight and
+        // puts the waits where it likes; lgkmcnt(0) is right whatever else is outstanding)
+        u32 const ldsB = (u32)(size_t)B;
 #pragma unroll
-            for (u32 k = 0; k < nk; k++) pw[k] = *((const SQ_L u8*)B + ad[k]);
+        for (u32 j = 0; j < 18; j++) {
+            u32 const ad = __builtin_amdgcn_ubfe(src[j], (j & 3) < 3 ? 8 * (j & 3) : 0u, 13u) + ldsB;
+            asm volatile("ds_read_u8 %0, %1" : "=v"(pw[j]) : "v"(ad));
+        }
+        u32 bi[18];
 #pragma unroll
-            for (u32 k = 0; k < nk; k++) {
-                u32 const bit = __builtin_amdgcn_ubfe(pw[k], bi[k], 1u);
-                // (spelled out: left to itself hipcc turns the chain into shifts and three-way ORs, 7 instead of 4 per word)
-                asm("v_lshl_or_b32 %0, %1, 1, %2" : "=v"(bm) : "v"(bm), "v"(bit));
-            }
+        for (u32 j = 0; j < 18; j++) bi[j] = __builtin_amdgcn_ubfe(src[j], ((j & 3) < 3 ? 8 * (j & 3) : 0u) + 13u, 3u);
+        asm volatile("" : "+v"(bi[0]), "+v"(bi[1]), "+v"(bi[2]), "+v"(bi[3]), "+v"(bi[4]), "+v"(bi[5]), "+v"(bi[6]), "+v"(bi[7]), "+v"(bi[8]),
+                          "+v"(bi[9]), "+v"(bi[10]), "+v"(bi[11]), "+v"(bi[12]), "+v"(bi[13]), "+v"(bi[14]), "+v"(bi[15]), "+v"(bi[16]), "+v"(bi[17]));
+        asm volatile("s_waitcnt lgkmcnt(0)"
+                     : "+v"(pw[0]), "+v"(pw[1]), "+v"(pw[2]), "+v"(pw[3]), "+v"(pw[4]), "+v"(pw[5]), "+v"(pw[6]), "+v"(pw[7]), "+v"(pw[8]),
+                       "+v"(pw[9]), "+v"(pw[10]), "+v"(pw[11]), "+v"(pw[12]), "+v"(pw[13]), "+v"(pw[14]), "+v"(pw[15]), "+v"(pw[16]), "+v"(pw[17]));
+        u32 bm = 0;
+#pragma unroll
+        for (u32 j = 0; j < 18; j++) {
+            u32 const bit = __builtin_amdgcn_ubfe(pw[j], bi[j], 1u);
+            // (spelled out: left to itself hipcc turns the chain into shifts and three-way ORs, 7 instead of 4 per word)
+            asm("v_lshl_or_b32 %0, %1, 1, %2" : "=v"(bm) : "v"(bm), "v"(bit));
         }
         u32 cm = (__builtin_bitreverse32(bm & (bm << 1) & (bm << 2)) >> 14) & okMask;
         if constexpr (decltype(AL)::value) {

@@ -53,3 +53,13 @@ def test_product_does_not_touch_oracle():
             if f.endswith((".py", ".h", ".hip", ".cpp")):
                 txt = open(os.path.join(dp, f), errors="ignore").read()
                 assert "oracle/" not in txt and "sqo_" not in txt and "sq_oracle" not in txt, f
+
+
+def test_hand_issued_lds_reads_are_not_touched_before_their_wait():
+    """Stage 1 issues the 18 filter reads of a round as inline asm with one hand-placed wait (sq_zstd_fast.h); the
+    compiler must not copy / spill their destination registers in between.  tools/check_async_reads.py compiles the
+    library to ISA (hipcc cross-compiles without a GPU) and scans every such group."""
+    import subprocess
+    import sys
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "check_async_reads.py")], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
