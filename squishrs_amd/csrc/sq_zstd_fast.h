@@ -61,15 +61,17 @@ SQ_DEV bool fw_first() { return true; }
 #define FW_SH_CERT0 1u  // certEnd  (atomic minimum over the waves)
 #define FW_SH_CERT1 2u  // certEnd1
 #define FW_SH_FLAGS 3u  // 1: the repeats inside S do not fit the hit list, 2: a bucket too large for this path
-#define FW_SH_OK 4u     // HUF pre-check: every block's literals uncompressible
 #define FW_SH_IDX 5u    // the chunk index the workgroup pulled from the queue
 #define FW_SH_FIN 8u    // [FW_NW] position each wave's scan ended at
+#define FW_SH_SAMPLE 12u // [4] largest count of each 4 KiB sample of the HUF pre-check
 
-// LDS of one workgroup of k_incompressible_batch (19.4 KB at two waves: 8 workgroups per CU)
+// LDS of one workgroup of k_incompressible_batch (28.9 KB at four waves: the 4 workgroups = 16 waves per CU that the
+// 128 registers per lane allow use 116 of the CU's 160 KB)
 struct FastLds {
     u32 bloom[SQZ_BLOOM_WORDS];      // certificate Bloom filter; afterwards the 256-bin sample histograms (256 words per wave)
     u16 vals[SQZ_FAST_VALS];         // per scheduled position: bits 6..21 of its 4-byte value, grouped by bits 22..31
     u32 ends[SQZ_FAST_KEYS / 2 + 2]; // per bucket, packed 2 x u16: first counts, then starts, finally END offsets
+    u16 idx[SQZ_FAST_VALS];          // beside vals: which scheduled search (its number in the schedule) the value belongs to
     u32 cand[FW_NW * 256];           // per wave, a few rounds' Bloom positives: 128 x (position, bytes)
     u32 hits[2 * SQZ_FAST_HITS];     // (position, bytes) of scanned positions whose bytes equal a scheduled position's;
                                      // position 0 = two scheduled positions with equal bytes
@@ -105,18 +107,6 @@ SQ_DEV u32 fast_frame_header(u8* dst, u32 n) {
         }
     }
     return 5 + (fcsCode == 0 ? 1 : (fcsCode == 1 ? 2 : 4));
-}
-
-// 1 if HUF's sampled pre-check calls this block's literals uncompressible
-SQ_DEVFN u32 fast_literals_uncompressible(const u8* blk, u32 size, u32* count /*256 words, LDS*/) {
-    u32 l1, l2, dummy;
-    wv_zero_lds(count, 256);
-    wv_hist_bytes(count, blk, 4096);
-    wv_max_and_last(count, 256, &l1, &dummy);
-    wv_zero_lds(count, 256);
-    wv_hist_bytes(count, blk + size - 4096, 4096);
-    wv_max_and_last(count, 256, &l2, &dummy);
-    return l1 + l2 <= ((2 * 4096) >> 7) + 4;
 }
 
 #if defined(SQ_PROF) && SQ_ON_DEVICE
@@ -282,6 +272,7 @@ SQ_DEV void cert_lds_core(CertCtx& cx, FastLds* L, u8* rawOut) {
     SQ_L u32* const bloom = (SQ_L u32*)L->bloom;
     SQ_L u16* const vals = (SQ_L u16*)L->vals; // 16-bit tags: with the bucket's 10 bits, 26 bits of the value
     SQ_L u32* const ends = (SQ_L u32*)L->ends;
+    SQ_L u16* const idxs = (SQ_L u16*)L->idx;
     SQ_L u32* const hits = (SQ_L u32*)L->hits;
 #if SQ_ON_DEVICE
     u32 const lane = wv_lane();
@@ -474,7 +465,10 @@ SQ_DEV void cert_lds_core(CertCtx& cx, FastLds* L, u8* rawOut) {
                 if (i0 + 64 * g + lane < nCert) {
                     u32 const vg = vv[8 * it + g];
                     u32 const slot = fast_cnt16_add(ends, vg >> 22);
-                    if (slot < SQZ_FAST_VALS) vals[slot] = (u16)(vg >> 6);
+                    if (slot < SQZ_FAST_VALS) {
+                        vals[slot] = (u16)(vg >> 6);
+                        idxs[slot] = (u16)(i0 + 64 * g + lane);
+                    }
                 }
         }
     }
@@ -835,67 +829,32 @@ SQ_DEV void cert_lds_core(CertCtx& cx, FastLds* L, u8* rawOut) {
     // ---- resolve the hits by walking S: a scheduled s fails to be certified when an equal value sits at
     // an earlier position (a scanned position p, or for a pair inside the schedule the earliest member)
     u32 const nHits = sh[FW_SH_NHITS] < SQZ_FAST_HITS ? sh[FW_SH_NHITS] : SQZ_FAST_HITS;
-    if (nHits) {
-        // the positions and values of S once more (each wave its share), all gathers in flight at once, for
-        // every hit together
-        u32 spA[8 * ITS], vA[8 * ITS];
-#pragma unroll
-        for (u32 it = 0; it < ITS; it++) {
-            u32 const i0 = 512 * (it * NW + wv);
-            u32 sp[8];
-#pragma unroll
-            for (u32 g = 0; g < 8; g++) sp[g] = 0;
-            if (i0 < nCert) cert_pos8(cx, i0 + lane, nCert, sp);
-#pragma unroll
-            for (u32 g = 0; g < 8; g++) spA[8 * it + g] = sp[g];
-        }
-#pragma unroll
-        for (u32 it = 0; it < ITS; it++) {
-            u32 const i0 = 512 * (it * NW + wv);
-#pragma unroll
-            for (u32 g = 0; g < 8; g++) vA[8 * it + g] = 0;
-            if (i0 < nCert) {
-#pragma unroll
-                for (u32 g = 0; g < 8; g++) vA[8 * it + g] = sq_grd32(base + spA[8 * it + g]);
-            }
-        }
-        wv_fence();
+    if (nHits && wv == 0) {
+        // One hit per lane.  A hit names a class of scheduled values -- its bucket's entries with its 16-bit tag
+        // (26 bits of the value) -- and idx[] says which searches those are: their positions come from the schedule
+        // table and their 4 bytes from the chunk, a handful of loads per hit (S itself is not gathered again).
+        static_assert(SQZ_FAST_HITS <= 64, "one hit per lane");
+        bool const have = lane < nHits;
+        u32 const hp = have ? hits[2 * lane] : 0u, hv = have ? hits[2 * lane + 1] : 0u;
+        u32 const k = hv >> 22, tag = (hv >> 6) & 0xFFFFu;
+        u32 const lo = (have && k) ? fast_get16(ends, k - 1) : 0u, hi = have ? fast_get16(ends, k) : 0u;
+        auto posOf = [&](u32 i) -> u32 { // as cert_pos8
+            bool const first = i < cx.certCnt0;
+            u32 const slot = first ? i : SQZ_SCHEDTAB_N + cx.tabOff1 + (i - cx.certCnt0);
+            return sq_gld32(cx.schedTab + 2 + slot) + (first ? SQZ_WINDOW_START : cx.base1Pos);
+        };
         u32 v0 = 0xFFFFFFFFu, v1 = 0xFFFFFFFFu;
-        for (u32 hIdx = 0; hIdx < nHits; hIdx++) { // (the hit list is the workgroup's: every wave walks all of it)
-            u32 const hp = hits[2 * hIdx], hv = hits[2 * hIdx + 1];
+        for (u32 a = lo; a < hi; a++) { // (a bucket holds 3.4 values on average, SQZ_FAST_BUCKET_MAX at most)
+            if (vals[a] != tag) continue;
+            u32 const sa = posOf(idxs[a]), va = sq_grd32(base + sa);
             if (hp != 0) { // a scanned position p with the bytes hv: every scheduled s > p with those bytes
-#pragma unroll
-                for (u32 it = 0; it < ITS; it++)
-#pragma unroll
-                    for (u32 g = 0; g < 8; g++)
-                        if (512 * (it * NW + wv) + 64 * g + lane < nCert && vA[8 * it + g] == hv && spA[8 * it + g] > hp)
-                            note(spA[8 * it + g], v0, v1);
-            } else {
-                // two scheduled positions share bits 6..31 of their values (hv).  Collect the (few) members of
-                // that class; a member whose full value equals an earlier member's is a search that can succeed.
-                SQ_L u32* const mem = (SQ_L u32*)L->cand; // [0] count, then (position, value) pairs
-                if (tid == 0) mem[0] = 0;
-                fw_sync();
-#pragma unroll
-                for (u32 it = 0; it < ITS; it++)
-#pragma unroll
-                    for (u32 g = 0; g < 8; g++)
-                        if (512 * (it * NW + wv) + 64 * g + lane < nCert && (vA[8 * it + g] & 0xFFFFFFC0u) == hv) {
-                            u32 const at = __hip_atomic_fetch_add(&mem[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                            if (at < 60) {
-                                mem[2 + 2 * at] = spA[8 * it + g];
-                                mem[3 + 2 * at] = vA[8 * it + g];
-                            }
-                        }
-                fw_sync();
-                u32 const nm = mem[0];
-                if (wv == 0 && lane < nm && lane < 60) {
-                    u32 const ms = mem[2 + 2 * lane], mv = mem[3 + 2 * lane];
-                    bool rpt = nm > 60; // more members than we keep: every one counts as a repeat (conservative)
-                    for (u32 j = 0; j < nm && j < 60; j++) rpt = rpt || (mem[3 + 2 * j] == mv && mem[2 + 2 * j] < ms);
-                    if (rpt) note(ms, v0, v1);
+                if (va == hv && sa > hp) note(sa, v0, v1);
+            } else { // two scheduled positions share bits 6..31: of two with equal bytes, the later search can succeed
+                for (u32 b = a + 1; b < hi; b++) {
+                    if (vals[b] != tag) continue;
+                    u32 const sb = posOf(idxs[b]), vb = sq_grd32(base + sb);
+                    if (va == vb) note(sa > sb ? sa : sb, v0, v1);
                 }
-                fw_sync(); // mem is reset by the next hit of this kind
             }
         }
         settle(v0, v1);
@@ -994,16 +953,24 @@ SQ_DEV u32 fastpath_frame_wave(const u8* src, u32 n, u8* dst, u32 cap, u32* E, u
             if (len1) whole = whole && (cx.certEnd1 >= SQZ_WINDOW_START + SQZ_BLOCKSIZE_MAX + len1 - 8);
             if (dbg & 4) whole = false; // timing experiment: certificate only
             if (whole && sized && room) {
-                // HUF's sampled pre-check, one block per wave
+                // HUF's sampled pre-check: the 4 KiB samples (first and last of each block) are dealt out to the
+                // waves; largest1 + largest2 of a block are added up through LDS
                 u32 const wv = fw_wave();
-                if (fw_first()) L->sh[FW_SH_OK] = 1;
+                u32 const nSamples = 2 * nBlocks;
+                for (u32 j = wv; j < nSamples; j += FW_NW) {
+                    u32 const b = j >> 1, bs = b ? len1 : len0;
+                    const u8* const at = src + (b ? len0 : 0u) + ((j & 1) ? bs - 4096 : 0u);
+                    u32 l = 0, dummy;
+                    wv_zero_lds(L->bloom + 256 * wv, 256);
+                    wv_hist_bytes(L->bloom + 256 * wv, at, 4096);
+                    wv_max_and_last(L->bloom + 256 * wv, 256, &l, &dummy);
+                    WV_SERIAL L->sh[FW_SH_SAMPLE + j] = l;
+                }
                 fw_sync();
-                for (u32 b = wv; b < nBlocks; b += FW_NW)
-                    if (!fast_literals_uncompressible(src + (b ? len0 : 0u), b ? len1 : len0, L->bloom + 256 * wv)) {
-                        WV_SERIAL L->sh[FW_SH_OK] = 0;
-                    }
-                fw_sync();
-                if (L->sh[FW_SH_OK]) {
+                u32 ok = 1; // (every wave reads the same four words)
+                for (u32 b = 0; b < nBlocks; b++)
+                    if (L->sh[FW_SH_SAMPLE + 2 * b] + L->sh[FW_SH_SAMPLE + 2 * b + 1] > ((2 * 4096) >> 7) + 4) ok = 0;
+                if (ok) {
                     if (wv == 0) (void)fast_frame_header(dst, n);
                     u8* op = dst + hdr;
                     u32 const done = cx.rawEnd - SQZ_WINDOW_START; // chunk bytes the scan has already put in place
