@@ -42,6 +42,9 @@ namespace sqz {
 #ifndef SQZ_FAST_WG_WAVES
 #define SQZ_FAST_WG_WAVES 4u
 #endif
+#ifndef SQZ_FAST_DEPTH
+#define SQZ_FAST_DEPTH 5u // rounds of the scan's stream in flight per wave
+#endif
 #ifndef SQZ_FAST_WAVES_PER_SIMD
 #define SQZ_FAST_WAVES_PER_SIMD 4
 #endif
@@ -760,40 +763,44 @@ SQ_DEV void cert_lds_core(CertCtx& cx, FastLds* L, u8* rawOut) {
     bool full = false, scanned = false;
     auto scan = [&](auto AL) {
         scanned = true;
-        sq_v4u wA = loadRound(pos), wB = loadRound(pos + 1024), wC = loadRound(pos + 2048), wD = loadRound(pos + 3072), wE;
-        u32 lA, lB, lC, lD, lE;
-        loadLevels(AL, pos, lA);
-        loadLevels(AL, pos + 1024, lB);
-        loadLevels(AL, pos + 2048, lC);
-        loadLevels(AL, pos + 3072, lD);
+        // SQZ_FAST_DEPTH rounds of 1 KiB in flight per wave: w[i] is used by one round of the unrolled body and
+        // loaded again right after it
+        constexpr u32 D = SQZ_FAST_DEPTH;
+        sq_v4u w[D];
+        u32 lv[D];
+#pragma unroll
+        for (u32 i = 0; i + 1 < D; i++) {
+            w[i] = loadRound(pos + (s32)(1024 * i));
+            loadLevels(AL, pos + (s32)(1024 * i), lv[i]);
+        }
         for (;;) {
-            wE = loadRound(pos + 4096);
-            loadLevels(AL, pos + 4096, lE);
-            // ONE look-up site for the five rounds below (inlined into each of them, the look-up code made
+            w[D - 1] = loadRound(pos + (s32)(1024 * (D - 1)));
+            loadLevels(AL, pos + (s32)(1024 * (D - 1)), lv[D - 1]);
+            // ONE look-up site for the D rounds below (inlined into each of them, the look-up code made
             // the loop several times the size of the instruction cache's share of a wave)
             if (nCand >= SQZ_FAST_LOOKUP_BATCH && !lookUp(1)) {
                 cx.nOvf = 2u | (sh[FW_SH_NHITS] << 8);
                 full = true;
                 break;
             }
-            if (!round(AL, wA, wB, lA)) { full = true; break; }
-            if (pos >= myStop) break;
-            wA = loadRound(pos + 4096);
-            loadLevels(AL, pos + 4096, lA);
-            if (!round(AL, wB, wC, lB)) { full = true; break; }
-            if (pos >= myStop) break;
-            wB = loadRound(pos + 4096);
-            loadLevels(AL, pos + 4096, lB);
-            if (!round(AL, wC, wD, lC)) { full = true; break; }
-            if (pos >= myStop) break;
-            wC = loadRound(pos + 4096);
-            loadLevels(AL, pos + 4096, lC);
-            if (!round(AL, wD, wE, lD)) { full = true; break; }
-            if (pos >= myStop) break;
-            wD = loadRound(pos + 4096);
-            loadLevels(AL, pos + 4096, lD);
-            if (!round(AL, wE, wA, lE)) { full = true; break; }
-            if (pos >= myStop) break;
+            bool done = false;
+#pragma unroll
+            for (u32 i = 0; i < D; i++) {
+                if (!round(AL, w[i], w[(i + 1) % D], lv[i])) {
+                    full = true;
+                    done = true;
+                    break;
+                }
+                if (pos >= myStop) {
+                    done = true;
+                    break;
+                }
+                if (i + 1 < D) {
+                    w[i] = loadRound(pos + (s32)(1024 * (D - 1)));
+                    loadLevels(AL, pos + (s32)(1024 * (D - 1)), lv[i]);
+                }
+            }
+            if (done) break;
         }
     };
     if (pos < myStop && !(cx.dbg & 2)) {
