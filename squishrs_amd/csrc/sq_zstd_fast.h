@@ -13,8 +13,9 @@
 // together with the certificate ends already computed here.
 //
 // Why a separate kernel: this path is a few streaming passes with all of its state in LDS (the
-// certificate's set S, 25 KB per wave: 6 waves per CU); k_compress_batch carries the whole zstd state
-// machine (248 VGPRs, 20 KB of LDS of entropy tables) and keeps the certificate's table in HBM.
+// certificate's set S, 29 KB per chunk, shared by the four waves of a workgroup at 128 VGPRs: 16 waves
+// per CU); k_compress_batch carries the whole zstd state machine (248 VGPRs, 20 KB of LDS of entropy
+// tables per wave) and keeps the certificate's table in HBM.
 #pragma once
 #include "sq_zstd_match.h"
 #include <type_traits>
@@ -38,7 +39,7 @@ namespace sqz {
 // filter, the bucketed values and the hit list exist once per chunk, each wave scans its own contiguous part of
 // the chunk with a candidate list of its own.  Two waves per chunk halve the LDS per wave (8 workgroups = 16 waves
 // per CU instead of 8 waves) and the registers the build needs per lane (each wave gathers half of S), which is
-// what lets the VALU-bound scan run at 3-4 waves per SIMD instead of 2.
+// what lets the scan run at 4 waves per SIMD instead of 2 ("workgroup edition").
 #ifndef SQZ_FAST_WG_WAVES
 #define SQZ_FAST_WG_WAVES 4u
 #endif
