@@ -458,6 +458,10 @@ static int compress_enqueue(sq_ctx* c, sq_lane* L, const u8* d_data, const u32* 
 
     // persistent compressor waves, one private workspace each
     u32 waves = c->cfg.compress_waves ? c->cfg.compress_waves : (u32)c->num_cu * 8;
+    if (const char* e = getenv("SQ_STAGE2_WAVES_PER_CU")) { // experiment: leave wave slots to the other lane's kernels
+        int const w = atoi(e);
+        if (w >= 1 && w <= 8 && !c->cfg.compress_waves) waves = (u32)c->num_cu * (u32)w;
+    }
     waves = std::min(waves, n);
     const size_t ws_each = sqz::workspace_bytes(max_len);
     // keep the workspace pool within ~96 GiB

@@ -60,6 +60,15 @@ SQ_DEV u32 fw_wave() { return 0; }
 SQ_DEV void fw_sync() {}
 SQ_DEV bool fw_first() { return true; }
 #endif
+// f(integral_constant<I>) for I = I0 .. N - 1, stopping at the first call that returns false (returns false then)
+template <u32 I, u32 N, class F>
+SQ_DEV bool fw_static_for(F&& f) {
+    if constexpr (I < N) {
+        if (!f(std::integral_constant<u32, I>{})) return false;
+        return fw_static_for<I + 1, N>(f);
+    } else
+        return true;
+}
 // words of FastLds::sh
 #define FW_SH_NHITS 0u  // hits listed so far (may run past SQZ_FAST_HITS: the list is then full)
 #define FW_SH_CERT0 1u  // certEnd  (atomic minimum over the waves)
@@ -784,23 +793,20 @@ SQ_DEV void cert_lds_core(CertCtx& cx, FastLds* L, u8* rawOut) {
                 full = true;
                 break;
             }
-            bool done = false;
-#pragma unroll
-            for (u32 i = 0; i < D; i++) {
+            // (a compile-time loop: the rotation w[i] / w[(i + 1) % D] must be register names, not indices)
+            bool const done = !fw_static_for<0, D>([&](auto I) -> bool {
+                constexpr u32 i = decltype(I)::value;
                 if (!round(AL, w[i], w[(i + 1) % D], lv[i])) {
                     full = true;
-                    done = true;
-                    break;
+                    return false;
                 }
-                if (pos >= myStop) {
-                    done = true;
-                    break;
-                }
-                if (i + 1 < D) {
+                if (pos >= myStop) return false;
+                if constexpr (i + 1 < D) {
                     w[i] = loadRound(pos + (s32)(1024 * (D - 1)));
                     loadLevels(AL, pos + (s32)(1024 * (D - 1)), lv[i]);
                 }
-            }
+                return true;
+            });
             if (done) break;
         }
     };
