@@ -404,3 +404,45 @@ def test_rowbatch_every_kind_and_size_vs_oracle(gpu_store, oracle):
     frames = _batch_compress(gpu_store, chunks)
     bad = [(i, len(c)) for i, (c, f) in enumerate(zip(chunks, frames)) if f != oracle.compress_chunk(c)]
     assert not bad, bad[:10]
+
+
+def test_stage1_workgroup_edges_sizes_and_alignments(gpu_store, oracle):
+    """Stage 1 (one chunk per workgroup of four waves, sq_zstd_fast.h): every way the work is dealt out.  Sizes at the
+    strategy's and the path's boundaries (16 KiB + 1, 40,960 = the smallest block HUF's sampled pre-check accepts, one
+    block / two blocks, a second block too short to be searched, fewer rounds than waves), at every start alignment
+    modulo 16 (an aligned chunk takes the bitmap variant of the scan and lets the scan write the raw blocks, any
+    other start takes the level-word variant and the tail copy), with contents that end certified (random), are handed
+    over (planted repeats in either block) or are not this path's at all (text, zeros) -- every frame against the
+    oracle."""
+    import torch
+    import squishrs_amd
+    rng = np.random.default_rng(2024)
+    sizes = [16385, 16400, 17408, 20000, 40959, 40960, 40961, 65535, 65536, 65537, 100000, 131071, 131072, 131073,
+             131080, 131081, 135000, 172032, 172033, 200000, 262143, 262144]
+    kinds = ["random", "random", "planted0", "planted3", "planted6", "planted9", "random", "text", "zeros", "skewed"]
+    chunks, starts = [], []
+    pos = 0
+    for i in range(160):
+        n = sizes[i % len(sizes)] if i < 132 else int(rng.integers(16385, 262145))
+        k = kinds[i % len(kinds)]
+        if k.startswith("planted") and n < 20000:
+            k = "random"
+        chunks.append(corpus.make(k, 9000 + i, n))
+        pos = (pos + 63) // 64 * 64 + (i % 16)          # start alignment i mod 16
+        starts.append(pos)
+        pos += n
+    buf = np.zeros(pos + 256, dtype=np.uint8)
+    for s, c in zip(starts, chunks):
+        buf[s:s + len(c)] = np.frombuffer(c, dtype=np.uint8)
+    d = torch.from_numpy(buf).cuda()
+    offs = np.array(starts, dtype=np.uint64)
+    lens = np.array([len(c) for c in chunks], dtype=np.uint32)
+    comp = torch.zeros(int(sum(squishrs_amd.compress_bound(len(c)) + 64 for c in chunks)), dtype=torch.uint8, device="cuda")
+    for _ in range(2):                                  # the second pass runs on persisted table generations
+        coff = gpu_store.compress_device(d, offs, lens, None, comp)
+        host = comp.cpu().numpy()
+        bad = [(i, len(c), starts[i] % 16) for i, c in enumerate(chunks)
+               if host[int(coff[i]):int(coff[i + 1])].tobytes() != oracle.compress_chunk(c)]
+        assert not bad, bad[:10]
+    decided = gpu_store.timings().fast_decided
+    assert decided >= 20, f"stage 1 decided only {decided} of the random chunks"
