@@ -154,6 +154,25 @@ int sq_pack_submit(sq_ctx* ctx, const uint8_t* data, const uint64_t* h_off, cons
                    uint8_t* hashes, uint8_t* is_new, uint8_t* comp, uint64_t comp_cap, uint32_t flags);
 int sq_pack_wait(sq_ctx* ctx, uint64_t* h_comp_off, uint32_t* h_comp_len);
 
+/* ---- sharded pipelined form (one process per GPU): sq_pack_submit cut in two where the ranks exchange
+ * their hashes, so that with two batches in flight the exchange of batch k+1 -- the caller's collective, e.g. one RCCL
+ * all-gather -- happens while batch k compresses.  Device pointers only.
+ *   sq_shard_submit_hash: enqueue the hash of the batch (this rank's n chunks) on the next free lane; d_hashes = n x 16.
+ *   sq_shard_wait_hash:   block the host until those hashes are in d_hashes (the collective may start).
+ *   sq_shard_submit_rest: given the hashes of ALL ranks in global chunk-index order (this rank's at my_first .. my_first
+ *     + n), enqueue the global dedup (== sq_dedup_global: the set is replicated on every rank and every rank resolves
+ *     "first occurrence in global index order" identically) and the compression of this rank's new chunks into slots
+ *     (== sq_compress_batch_slots with select = is_new) behind the hash; flags bit 0 as for sq_pack_submit.  The batch
+ *     is then in flight exactly as after sq_pack_submit and is collected by sq_pack_wait.  d_all_hashes, d_is_new and
+ *     d_comp must stay valid until then.  The reference's counterpart of the exchange is the one DashMap all Rayon
+ *     workers share (src/util/chunk.rs:52-56,83).
+ * SQ_E_INVAL: no lane free, or the calls out of order. */
+int sq_shard_submit_hash(sq_ctx* ctx, const uint8_t* d_data, const uint64_t* h_off, const uint32_t* h_len, uint32_t n,
+                         uint8_t* d_hashes);
+int sq_shard_wait_hash(sq_ctx* ctx);
+int sq_shard_submit_rest(sq_ctx* ctx, const uint8_t* d_all_hashes, uint64_t n_total, uint64_t my_first, uint8_t* d_is_new,
+                         uint8_t* d_comp, uint64_t comp_cap, uint32_t flags);
+
 /* Page-locked host buffers for the batch forms (hipHostMalloc).  The reference's packer reads every
  * chunk into a heap buffer (BufReader + chunk_buf, src/archive/writer.rs:233-246) and hands the frames on
  * as Vec<u8> (chunk.rs:60-64); a host driver of this library reads into / writes from buffers it gets

@@ -175,6 +175,21 @@ class ChunkStore:
         check(self._L.sq_pack_wait(self._h, comp_off.ctypes.data, comp_len.ctypes.data))
         return comp_off, comp_len
 
+    def shard_submit_hash(self, data, offs: np.ndarray, lens: np.ndarray, hashes):
+        """sq_shard_submit_hash: enqueue the hash of this rank's batch on the next free lane."""
+        check(self._L.sq_shard_submit_hash(self._h, data.data_ptr(), offs.ctypes.data, lens.ctypes.data, len(lens),
+                                           hashes.data_ptr()))
+
+    def shard_wait_hash(self):
+        """sq_shard_wait_hash: the hashes of the batch submitted last are in place (the exchange may start)."""
+        check(self._L.sq_shard_wait_hash(self._h))
+
+    def shard_submit_rest(self, all_hashes, n_total: int, my_first: int, is_new, comp, reset: bool = False):
+        """sq_shard_submit_rest: global dedup over every rank's hashes + compression of this rank's new chunks, enqueued
+        behind the hash; collected by pack_wait."""
+        check(self._L.sq_shard_submit_rest(self._h, all_hashes.data_ptr(), n_total, my_first, is_new.data_ptr(),
+                                           comp.data_ptr(), comp.numel(), 1 if reset else 0))
+
     def stage2_list(self, cap: int = 1 << 20) -> np.ndarray:
         """Indices of the chunks the last compress launch's first stage left to the compressor proper."""
         out = np.zeros(cap, dtype=np.uint32)

@@ -100,6 +100,9 @@ struct sq_lane {
     u8 *job_h_hashes = nullptr, *job_h_isnew = nullptr, *job_h_comp = nullptr;
     u64 job_comp_cap = 0;
     std::vector<u64> job_out_off;
+    // sharded form: the batch whose hash was enqueued by sq_shard_submit_hash and waits for sq_shard_submit_rest
+    const u8* shard_data = nullptr;
+    std::vector<u32> shard_len;
 };
 
 struct sq_ctx {
@@ -119,6 +122,7 @@ struct sq_ctx {
     sq_lane ln[2];
     u32 last_lane = 0; // lane of the batch finished most recently (sq_debug_stage2_list)
     u32 submitted = 0, collected = 0; // sq_pack_submit / sq_pack_wait tickets (submitted - collected <= 2)
+    bool shard_pending = false;       // sq_shard_submit_hash called, sq_shard_submit_rest not yet
 };
 
 static bool is_device_ptr(const void* p) {
@@ -257,7 +261,7 @@ void sq_ctx_destroy(sq_ctx* c) {
 
 int sq_ctx_set_stream(sq_ctx* c, void* s) {
     if (!c) return SQ_E_INVAL;
-    if (c->submitted != c->collected) return SQ_E_INVAL; // batches of sq_pack_submit are in flight: collect them first
+    if (c->submitted != c->collected || c->shard_pending) return SQ_E_INVAL; // batches of sq_pack_submit are in flight: collect them first
     sq_lane* const L = &c->ln[0];
     HIPCHK(hipSetDevice(c->device));
     HIPCHK(hipStreamSynchronize(L->stream));
@@ -286,7 +290,7 @@ uint64_t sq_unique_count(const sq_ctx* c) {
 
 int sq_dedup_reset(sq_ctx* c) {
     if (!c) return SQ_E_INVAL;
-    if (c->submitted != c->collected) return SQ_E_INVAL; // batches of sq_pack_submit are in flight: collect them first
+    if (c->submitted != c->collected || c->shard_pending) return SQ_E_INVAL; // batches of sq_pack_submit are in flight: collect them first
     sq_lane* const L = &c->ln[0];
     HIPCHK(hipSetDevice(c->device));
     HIPCHK(hipMemsetAsync(c->d_table, 0, (c->table_mask + 1) * sizeof(u32), L->stream));
@@ -333,7 +337,7 @@ static int launch_hash(sq_ctx* c, sq_lane* L, const u8* d_data, u32 n, u8* d_has
 int sq_hash_batch(sq_ctx* c, const uint8_t* d_data, const uint64_t* h_off, const uint32_t* h_len,
                   uint32_t n, uint8_t* d_hashes) {
     if (!c || (n && (!d_data || !h_off || !h_len || !d_hashes))) return SQ_E_INVAL;
-    if (c->submitted != c->collected) return SQ_E_INVAL; // batches of sq_pack_submit are in flight: collect them first
+    if (c->submitted != c->collected || c->shard_pending) return SQ_E_INVAL; // batches of sq_pack_submit are in flight: collect them first
     sq_lane* const L = &c->ln[0];
     HIPCHK(hipSetDevice(c->device));
     int r;
@@ -374,7 +378,7 @@ int sq_dedup_global(sq_ctx* c, const uint8_t* d_all_hashes, uint64_t n_total, ui
                     uint32_t my_n, uint8_t* d_is_new) {
     if (!c || (n_total && !d_all_hashes) || (my_n && !d_is_new) || my_first + my_n > n_total)
         return SQ_E_INVAL;
-    if (c->submitted != c->collected) return SQ_E_INVAL; // batches of sq_pack_submit are in flight: collect them first
+    if (c->submitted != c->collected || c->shard_pending) return SQ_E_INVAL; // batches of sq_pack_submit are in flight: collect them first
     sq_lane* const L = &c->ln[0];
     HIPCHK(hipSetDevice(c->device));
     int r = dedup_async(c, L, d_all_hashes, n_total, my_first, my_n, d_is_new);
@@ -766,7 +770,7 @@ int sq_compress_batch(sq_ctx* c, const uint8_t* d_data, const uint64_t* h_off, c
     return SQ_E_COMPRESS;
 #else
     if (!c || !h_comp_off || (n && (!d_data || !h_off || !h_len || !d_comp))) return SQ_E_INVAL;
-    if (c->submitted != c->collected) return SQ_E_INVAL; // batches of sq_pack_submit are in flight: collect them first
+    if (c->submitted != c->collected || c->shard_pending) return SQ_E_INVAL; // batches of sq_pack_submit are in flight: collect them first
     sq_lane* const L = &c->ln[0];
     HIPCHK(hipSetDevice(c->device));
     int r;
@@ -784,7 +788,7 @@ int sq_compress_batch_slots(sq_ctx* c, const uint8_t* d_data, const uint64_t* h_
     return SQ_E_COMPRESS;
 #else
     if (!c || (n && (!d_data || !h_off || !h_len || !d_comp || !h_comp_off || !h_comp_len))) return SQ_E_INVAL;
-    if (c->submitted != c->collected) return SQ_E_INVAL; // batches of sq_pack_submit are in flight: collect them first
+    if (c->submitted != c->collected || c->shard_pending) return SQ_E_INVAL; // batches of sq_pack_submit are in flight: collect them first
     sq_lane* const L = &c->ln[0];
     HIPCHK(hipSetDevice(c->device));
     int r;
@@ -828,7 +832,7 @@ int sq_pack_batch(sq_ctx* c, const uint8_t* data, const uint64_t* off, const uin
     return SQ_E_COMPRESS;
 #else
     if (!c || !comp_off || (n && (!data || !off || !len || !hashes || !is_new || !comp))) return SQ_E_INVAL;
-    if (c->submitted != c->collected) return SQ_E_INVAL; // batches of sq_pack_submit are in flight: collect them first
+    if (c->submitted != c->collected || c->shard_pending) return SQ_E_INVAL; // batches of sq_pack_submit are in flight: collect them first
     sq_lane* const L = &c->ln[0];
     HIPCHK(hipSetDevice(c->device));
     if (n == 0) {
@@ -910,7 +914,7 @@ int sq_pack_submit(sq_ctx* c, const uint8_t* data, const uint64_t* h_off, const 
     return SQ_E_COMPRESS;
 #else
     if (!c || (n && (!data || !h_off || !h_len || !hashes || !is_new || !comp))) return SQ_E_INVAL;
-    if (c->submitted - c->collected >= 2) return SQ_E_INVAL; // both lanes busy: collect one with sq_pack_wait first
+    if (c->submitted - c->collected >= 2 || c->shard_pending) return SQ_E_INVAL; // both lanes busy: collect one with sq_pack_wait first
     HIPCHK(hipSetDevice(c->device));
     for (u32 i = 0; i < n; i++)
         if (h_len[i] > c->cfg.max_chunk) return SQ_E_INVAL;
@@ -980,6 +984,70 @@ int sq_pack_submit(sq_ctx* c, const uint8_t* data, const uint64_t* h_off, const 
                            (const u64*)L->b_slot_off.p, (const u32*)L->b_frame_len.p, (const u64*)L->b_out_off.p, n, d_comp);
         HIPCHK(hipGetLastError());
         HIPCHK(hipEventRecord(L->ev[7], L->stream));
+    }
+    L->busy = true;
+    c->submitted++;
+    return SQ_OK;
+#endif
+}
+
+// ---- sharded pipelined form: the caller's exchange of hashes sits between the hash and the rest of a batch --------
+int sq_shard_submit_hash(sq_ctx* c, const uint8_t* d_data, const uint64_t* h_off, const uint32_t* h_len, uint32_t n,
+                         uint8_t* d_hashes) {
+    if (!c || (n && (!d_data || !h_off || !h_len || !d_hashes))) return SQ_E_INVAL;
+    if (c->shard_pending || c->submitted - c->collected >= 2) return SQ_E_INVAL;
+    if (n && (!is_device_ptr(d_data) || !is_device_ptr(d_hashes))) return SQ_E_INVAL;
+    for (u32 i = 0; i < n; i++)
+        if (h_len[i] > c->cfg.max_chunk) return SQ_E_INVAL;
+    HIPCHK(hipSetDevice(c->device));
+    sq_lane* const L = &c->ln[c->submitted & 1];
+    int r;
+    if ((r = upload_off_len(c, L, h_off, h_len, n))) return r;
+    if ((r = launch_hash(c, L, d_data, n, d_hashes))) return r;
+    if (n == 0) HIPCHK(hipEventRecord(L->ev[1], L->stream));
+    L->shard_data = d_data;
+    L->shard_len.assign(h_len, h_len + n);
+    L->job_host = false;
+    c->shard_pending = true;
+    return SQ_OK;
+}
+
+int sq_shard_wait_hash(sq_ctx* c) {
+    if (!c || !c->shard_pending) return SQ_E_INVAL;
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipEventSynchronize(c->ln[c->submitted & 1].ev[1]));
+    return SQ_OK;
+}
+
+int sq_shard_submit_rest(sq_ctx* c, const uint8_t* d_all_hashes, uint64_t n_total, uint64_t my_first, uint8_t* d_is_new,
+                         uint8_t* d_comp, uint64_t comp_cap, uint32_t flags) {
+#ifdef SQ_NO_COMPRESS
+    (void)c; (void)d_all_hashes; (void)n_total; (void)my_first; (void)d_is_new; (void)d_comp; (void)comp_cap; (void)flags;
+    return SQ_E_COMPRESS;
+#else
+    if (!c || !c->shard_pending) return SQ_E_INVAL;
+    sq_lane* const L = &c->ln[c->submitted & 1];
+    sq_lane* const other = &c->ln[(c->submitted & 1) ^ 1];
+    u32 const n = (u32)L->shard_len.size();
+    if ((n_total && !d_all_hashes) || my_first + n > n_total || (n && (!d_is_new || !d_comp))) return SQ_E_INVAL;
+    if (n && (!is_device_ptr(d_all_hashes) || !is_device_ptr(d_is_new) || !is_device_ptr(d_comp))) return SQ_E_INVAL;
+    if (sq_slots_bound(L->shard_len.data(), n) > comp_cap) return SQ_E_CAP;
+    HIPCHK(hipSetDevice(c->device));
+    int r;
+    // the dedup set is shared: this batch's reset / insert must follow the previous batch's dedup kernels
+    if (other->busy) HIPCHK(hipStreamWaitEvent(L->stream, other->dedup_done, 0));
+    if (flags & 1u) {
+        HIPCHK(hipMemsetAsync(c->d_table, 0, (c->table_mask + 1) * sizeof(u32), L->stream));
+        HIPCHK(hipMemsetAsync(c->d_unique, 0, 64, L->stream));
+        c->n_seen = 0;
+    }
+    L->job_seen_before = c->n_seen;
+    c->shard_pending = false; // (whatever happens below, the hash step is consumed)
+    if ((r = dedup_async(c, L, d_all_hashes, n_total, my_first, n, d_is_new))) return r; // (fails before touching the set)
+    HIPCHK(hipEventRecord(L->dedup_done, L->stream));
+    if ((r = compress_enqueue(c, L, L->shard_data, L->shard_len.data(), n, d_is_new, d_comp, comp_cap, true))) {
+        (void)hipStreamSynchronize(L->stream);
+        return r;
     }
     L->busy = true;
     c->submitted++;

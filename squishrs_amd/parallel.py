@@ -34,6 +34,8 @@ class ShardedPacker:
         # has no collective between the stages and keeps whatever stream the ctx has.
         if self.world > 1 and torch.cuda.is_available() and hasattr(stages, "set_stream"):
             stages.set_stream(torch.cuda.current_stream().cuda_stream)
+        self._comm = None       # stream of the exchanges of the pipelined form (submit / wait)
+        self._inflight = []     # per batch in flight: what must stay alive until it is collected
 
     def gather_hashes(self, hashes: torch.Tensor, n_local: int, uniform: bool = False):
         """All-gather of the ranks' hash arrays (16 B x n_local, padded to the max count).
@@ -82,3 +84,31 @@ class ShardedPacker:
         if layout == "slots":
             return self.stages.compress_device_slots(data, offs, lens, is_new, comp)
         return self.stages.compress_device(data, offs, lens, is_new, comp)
+
+    # ---- pipelined form: two batches in flight, the exchange of batch k+1 under the compression of batch k ----------
+    def submit(self, data, offs: np.ndarray, lens: np.ndarray, hashes, is_new, comp, reset: bool = False,
+               uniform: bool = False):
+        """Enqueue one batch (slots layout): hash -> [host waits for the hashes] -> all-gather -> global dedup +
+        compression of this rank's new chunks enqueued behind it.  Returns at once; collect with wait().  At most two
+        batches in flight, each with its own hashes / is_new / comp buffers.  The collective runs on a stream of its
+        own: torch's current stream may be one of the context's lanes (see __init__) and would put the exchange
+        behind the other batch's kernels."""
+        n = len(lens)
+        st = self.stages
+        st.shard_submit_hash(data, offs, lens, hashes)
+        st.shard_wait_hash()
+        if self.world > 1 and torch.cuda.is_available() and hashes.is_cuda:
+            if self._comm is None:
+                self._comm = torch.cuda.Stream()
+            with torch.cuda.stream(self._comm):
+                all_hashes, n_total, my_first = self.gather_hashes(hashes, n, uniform)
+            self._comm.synchronize()
+        else:
+            all_hashes, n_total, my_first = self.gather_hashes(hashes, n, uniform)
+        st.shard_submit_rest(all_hashes, n_total, my_first, is_new, comp, reset)
+        self._inflight.append((all_hashes, n))
+
+    def wait(self):
+        """(slot offsets[n], frame lengths[n]) of the oldest batch in flight."""
+        _keep, n = self._inflight.pop(0)
+        return self.stages.pack_wait(n)

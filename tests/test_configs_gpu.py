@@ -446,3 +446,50 @@ def test_stage1_workgroup_edges_sizes_and_alignments(gpu_store, oracle):
         assert not bad, bad[:10]
     decided = gpu_store.timings().fast_decided
     assert decided >= 20, f"stage 1 decided only {decided} of the random chunks"
+
+
+def test_shard_split_form_two_batches_in_flight(oracle):
+    """sq_shard_submit_hash / sq_shard_wait_hash / sq_shard_submit_rest (the sharded pipelined form; here one rank, so
+    the "gathered" hashes are the batch's own): two batches in flight with cross-batch duplicates give the flags, the
+    unique count and the frames of sq_pack_submit; calls out of order are refused."""
+    import torch
+    import squishrs_amd
+    from squishrs_amd import SquishError
+    rng = np.random.default_rng(31)
+    L, n = 65536, 96
+    base = [corpus.make("random" if i % 3 else "text", 700 + i, L) for i in range(n)]
+    b0 = base[:64]
+    b1 = base[32:]                                   # 32 duplicates of batch 0, then 32 new
+    st = squishrs_amd.ChunkStore(device=0, max_chunk=L, dedup_capacity=4096)
+
+    def dev(chunks):
+        d = torch.frombuffer(bytearray(b"".join(chunks)), dtype=torch.uint8).cuda()
+        k = len(chunks)
+        offs = np.arange(k, dtype=np.uint64) * np.uint64(L)
+        lens = np.full(k, L, dtype=np.uint32)
+        return d, offs, lens, torch.zeros(k * 16, dtype=torch.uint8, device="cuda"), \
+            torch.zeros(k, dtype=torch.uint8, device="cuda"), torch.empty(st.slots_bound(lens), dtype=torch.uint8, device="cuda")
+
+    A, B = dev(b0), dev(b1)
+    with pytest.raises(SquishError):
+        st.shard_wait_hash()                         # nothing submitted
+    st.shard_submit_hash(A[0], A[1], A[2], A[3])
+    with pytest.raises(SquishError):
+        st.shard_submit_hash(B[0], B[1], B[2], B[3])  # the first batch's rest is still owed
+    st.shard_wait_hash()
+    st.shard_submit_rest(A[3], 64, 0, A[4], A[5], reset=True)
+    st.shard_submit_hash(B[0], B[1], B[2], B[3])
+    st.shard_wait_hash()
+    st.shard_submit_rest(B[3], 64, 0, B[4], B[5])
+    offA, lenA = st.pack_wait(64)
+    offB, lenB = st.pack_wait(64)
+    assert A[4].cpu().tolist() == [1] * 64
+    assert B[4].cpu().tolist() == [0] * 32 + [1] * 32
+    assert st.len() == 96
+    for (d, offs, lens, h, isn, comp), off, ln, chunks in ((A, offA, lenA, b0), (B, offB, lenB, b1)):
+        hh = h.cpu().numpy().reshape(-1, 16)
+        for i in (0, 31, 32, 63):
+            assert hh[i].tobytes() == oracle.hash_chunk(chunks[i])
+            fr = comp[int(off[i]):int(off[i]) + int(ln[i])].cpu().numpy().tobytes()
+            assert fr == (oracle.compress_chunk(chunks[i]) if isn[i] else b"")
+    st.close()

@@ -67,6 +67,32 @@ class OracleStages:
         return off, ln
 
 
+    # ---- the split form of the pipelined sharded packer (sq_shard_submit_hash / _wait_hash / _submit_rest / sq_pack_wait)
+    def shard_submit_hash(self, data, offs, lens, hashes):
+        assert getattr(self, "_pending", None) is None, "two hash steps without the rest of the first"
+        self.hash_device(data, offs, lens, hashes)
+        self._pending = (data, offs, lens)
+
+    def shard_wait_hash(self):
+        assert self._pending is not None
+
+    def shard_submit_rest(self, all_hashes, n_total, my_first, is_new, comp, reset=False):
+        data, offs, lens = self._pending
+        self._pending = None
+        if reset:
+            self.seen = set()
+        self.dedup_device(all_hashes, n_total, my_first, len(lens), is_new)
+        if not hasattr(self, "_done"):
+            self._done = []
+        assert len(self._done) < 2, "more than two batches in flight"
+        self._done.append(self.compress_device_slots(data, offs, lens, is_new, comp))
+
+    def pack_wait(self, n):
+        off, ln = self._done.pop(0)
+        assert len(off) == n
+        return off, ln
+
+
 def _make_chunks():
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import corpus
@@ -251,3 +277,61 @@ def test_uniform_gather_skips_the_count_exchange():
         assert p.exitcode == 0
     for rank, same, nt_a, mf_a, nt_b, mf_b in res:
         assert same and nt_a == nt_b == 15 and mf_a == mf_b == 5 * rank
+
+
+def _pipelined_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    sys.path.insert(0, ROOT)
+    from squishrs_amd.parallel import ShardedPacker, shard_range
+    chunks, order = _make_chunks()
+    first, n = shard_range(len(chunks), rank, world)
+    mine = chunks[first:first + n]
+    lens = np.array([len(c) for c in mine], dtype=np.uint32)
+    offs = np.zeros(n, dtype=np.uint64)
+    offs[1:] = np.cumsum(lens.astype(np.uint64))[:-1]
+    data = torch.frombuffer(bytearray(b"".join(mine)), dtype=torch.uint8)
+    bufs = [(torch.zeros(n * 16, dtype=torch.uint8), torch.zeros(n, dtype=torch.uint8),
+             torch.zeros(int(lens.sum()) + 4096 + 256 * n, dtype=torch.uint8)) for _ in range(2)]
+    st = OracleStages()
+    p = ShardedPacker(st)
+    # three batches, two in flight: the first on a fresh set, the second WITHOUT a reset (everything is a duplicate
+    # now), the third with a reset again
+    got = []
+    p.submit(data, offs, lens, *bufs[0], reset=True)
+    p.submit(data, offs, lens, *bufs[1], reset=False)
+    got.append((bufs[0][1].tolist(), [int(x) for x in p.wait()[1]]))
+    got.append((bufs[1][1].tolist(), [int(x) for x in p.wait()[1]]))
+    p.submit(data, offs, lens, *bufs[0], reset=True)
+    got.append((bufs[0][1].tolist(), [int(x) for x in p.wait()[1]]))
+    # the synchronous form on a fresh stand-in is the model
+    st2 = OracleStages()
+    is_new = torch.zeros(n, dtype=torch.uint8)
+    _, slen = ShardedPacker(st2).pack(data, offs, lens, bufs[1][0], is_new, bufs[1][2], layout="slots")
+    q.put((rank, got, is_new.tolist(), [int(x) for x in slen]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_pipelined_sharded_packer_two_in_flight():
+    """ShardedPacker.submit / wait (the form bench.py --gpus N times): hash, exchange, global dedup + compression per
+    batch with two batches in flight; results equal the synchronous form's, and a batch submitted without a reset sees
+    the set the batch before left."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_pipelined_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, got, model_new, model_len in res:
+        assert got[0] == (model_new, model_len)
+        assert got[1][0] == [0] * len(model_new) and got[1][1] == [0] * len(model_new)
+        assert got[2] == (model_new, model_len)
