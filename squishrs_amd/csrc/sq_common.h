@@ -68,6 +68,9 @@ SQ_DEV u32 sq_grd32(const u8* p) { return *(const SQ_G sq_u32_ua*)p; }
 SQ_DEV u64 sq_grd64(const u8* p) { return *(const SQ_G sq_u64_ua*)p; }
 SQ_DEV sq_v4u sq_grd128(const u8* p) { return *(const SQ_G sq_v4u_ua*)p; }
 SQ_DEV void sq_gwr128(u8* p, sq_v4u v) { *(SQ_G sq_v4u_ua*)p = v; }
+// streaming variants (nt): data that is read or written once and should not displace what the gathers brought into L2
+SQ_DEV sq_v4u sq_grd128_nt(const u8* p) { return __builtin_nontemporal_load((const SQ_G sq_v4u_ua*)p); }
+SQ_DEV void sq_gwr128_nt(u8* p, sq_v4u v) { __builtin_nontemporal_store(v, (SQ_G sq_v4u_ua*)p); }
 SQ_DEV void sq_gwr8(u8* p, u32 v) { *(SQ_G u8*)p = (u8)v; }
 SQ_DEV u32 sq_gld32(const u32* p) { return *(const SQ_G u32*)p; }          // aligned table word
 SQ_DEV void sq_gst32(u32* p, u32 v) { *(SQ_G u32*)p = v; }
