@@ -146,7 +146,9 @@ k_read_bw(const uint4* __restrict__ p, u64 n16, u32* __restrict__ sink) {
     const u64 stride = (u64)gridDim.x * blockDim.x;
     u32 acc = 0;
     for (; i < n16; i += stride) {
-        uint4 v = p[i];
+        // (non-temporal, as the hash kernel's and stage 1's streams are: the roof these are compared with)
+        typedef unsigned int v4u __attribute__((ext_vector_type(4)));
+        v4u const v = __builtin_nontemporal_load((const __attribute__((address_space(1))) v4u*)(p + i));
         acc ^= v.x ^ v.y ^ v.z ^ v.w;
     }
     if (acc == 0x12345678u) *sink = acc; // never true in practice; keeps the loads alive

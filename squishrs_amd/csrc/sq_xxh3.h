@@ -136,10 +136,21 @@ __device__ __forceinline__ void contrib(const uint4& v, u64 sk0, u64 sk1, u64& c
     c0 += (u64)(u32)k0 * (u64)(u32)(k0 >> 32) + d1; // acc[i0]   += mul(k0) ; acc[i0] (= (i0+1)^1) += d1
     c1 += (u64)(u32)k1 * (u64)(u32)(k1 >> 32) + d0; // acc[i0+1] += mul(k1) ; acc[i0+1] += d0
 }
+#ifndef SQX_NT
+#define SQX_NT 1 // non-temporal chunk loads: hash kernel 4.30 -> 3.95 ms (6.7 TB/s), step with two batches in flight 23.5 -> 22.5 ms
+#endif
 __device__ __forceinline__ uint4 ld16(const u8* p) {
+#if SQX_NT
+    // every chunk is read exactly once here: non-temporal loads keep the stream from displacing the L2 lines the
+    // compress stage of the other batch in flight is gathering
+    typedef unsigned int v4u_ua __attribute__((ext_vector_type(4), aligned(1)));
+    v4u_ua const w = __builtin_nontemporal_load((const __attribute__((address_space(1))) v4u_ua*)p);
+    return make_uint4(w.x, w.y, w.z, w.w);
+#else
     uint4 v;
     __builtin_memcpy(&v, p, 16);
     return v;
+#endif
 }
 
 // One wave, one chunk.  Every lane returns the full hash.
