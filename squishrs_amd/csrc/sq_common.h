@@ -71,6 +71,18 @@ SQ_DEV void sq_gwr128(u8* p, sq_v4u v) { *(SQ_G sq_v4u_ua*)p = v; }
 // streaming variants (nt): data that is read or written once and should not displace what the gathers brought into L2
 SQ_DEV sq_v4u sq_grd128_nt(const u8* p) { return __builtin_nontemporal_load((const SQ_G sq_v4u_ua*)p); }
 SQ_DEV void sq_gwr128_nt(u8* p, sq_v4u v) { __builtin_nontemporal_store(v, (SQ_G sq_v4u_ua*)p); }
+// the streaming passes of the compressor proper (copies, histograms, certificate scans, table clears); 0 for A/B runs.
+// Headline step 22.3 -> 21.6 ms, configs[3] sample unchanged within 2 % (profiles/round2b_stream_nontemporal.txt).
+#ifndef SQ_STREAM_NT
+#define SQ_STREAM_NT 1
+#endif
+#if SQ_STREAM_NT
+SQ_DEV sq_v4u sq_grd128_s(const u8* p) { return sq_grd128_nt(p); }
+SQ_DEV void sq_gwr128_s(u8* p, sq_v4u v) { sq_gwr128_nt(p, v); }
+#else
+SQ_DEV sq_v4u sq_grd128_s(const u8* p) { return sq_grd128(p); }
+SQ_DEV void sq_gwr128_s(u8* p, sq_v4u v) { sq_gwr128(p, v); }
+#endif
 SQ_DEV void sq_gwr8(u8* p, u32 v) { *(SQ_G u8*)p = (u8)v; }
 SQ_DEV u32 sq_gld32(const u32* p) { return *(const SQ_G u32*)p; }          // aligned table word
 SQ_DEV void sq_gst32(u32* p, u32 v) { *(SQ_G u32*)p = v; }

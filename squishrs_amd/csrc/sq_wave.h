@@ -226,7 +226,7 @@ SQ_DEV void wv_fill32(u32* dst, u32 v, size_t nwords) { // dst 16-byte aligned, 
     sq_v4u q = (sq_v4u){v, v, v, v};
     u8* d = (u8*)dst;
     const size_t n16 = nwords / 4;
-    for (size_t i = wv_lane(); i < n16; i += 64) sq_gwr128(d + 16 * i, q);
+    for (size_t i = wv_lane(); i < n16; i += 64) sq_gwr128_s(d + 16 * i, q);
     wv_mem_sync();
 #else
     for (size_t i = 0; i < nwords; i++) dst[i] = v;
@@ -240,11 +240,11 @@ SQ_DEV void wv_memcpy(u8* dst, const u8* src, u32 n) {
     for (; pos + 7 * 1024 + 16 <= n; pos += 8192) {
         sq_v4u v[8];
 #pragma unroll
-        for (u32 k = 0; k < 8; k++) v[k] = sq_grd128(src + pos + 1024 * k);
+        for (u32 k = 0; k < 8; k++) v[k] = sq_grd128_s(src + pos + 1024 * k);
 #pragma unroll
-        for (u32 k = 0; k < 8; k++) sq_gwr128(dst + pos + 1024 * k, v[k]);
+        for (u32 k = 0; k < 8; k++) sq_gwr128_s(dst + pos + 1024 * k, v[k]);
     }
-    for (; pos + 16 <= n; pos += 1024) sq_gwr128(dst + pos, sq_grd128(src + pos));
+    for (; pos + 16 <= n; pos += 1024) sq_gwr128_s(dst + pos, sq_grd128_s(src + pos));
     if (pos < n)
         for (u32 k = pos; k < n; k++) sq_gwr8(dst + k, sq_grd8(src + k)); // the single partial lane
     wv_mem_sync();
@@ -313,10 +313,10 @@ SQ_DEV void wv_hist_bytes(u32* count /*LDS*/, const u8* src, u32 n) {
         }
     };
     if (pos + 1024 + 16 <= n) {
-        sq_v4u a = sq_grd128(src + pos), b = sq_grd128(src + pos + 1024);
+        sq_v4u a = sq_grd128_s(src + pos), b = sq_grd128_s(src + pos + 1024);
         pos += 2048;
         for (; pos + 1024 + 16 <= n; pos += 2048) {
-            sq_v4u const na = sq_grd128(src + pos), nb = sq_grd128(src + pos + 1024);
+            sq_v4u const na = sq_grd128_s(src + pos), nb = sq_grd128_s(src + pos + 1024);
             count16(a);
             count16(b);
             a = na;
@@ -326,7 +326,7 @@ SQ_DEV void wv_hist_bytes(u32* count /*LDS*/, const u8* src, u32 n) {
         count16(b);
     }
     for (; pos + 16 <= n; pos += 1024) {
-        sq_v4u a = sq_grd128(src + pos);
+        sq_v4u a = sq_grd128_s(src + pos);
 #pragma unroll
         for (int k = 0; k < 4; k++) {
             u32 w = a[k];

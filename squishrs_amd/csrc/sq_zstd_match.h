@@ -813,7 +813,7 @@ SQ_DEVFN bool filter_wake(MatchState& ms, u32 curr) {
         const u8* const aLast = lastByte - ((size_t)lastByte & 15);
         auto loadRound = [&](s32 rp) -> sq_v4u {
             const u8* ad = a0 + (size_t)(u32)(rp - p0) + 16 * lane;
-            return sq_grd128(ad < aLast ? ad : aLast);
+            return sq_grd128_s(ad < aLast ? ad : aLast);
         };
         for (s32 pos = p0; pos < (s32)to; pos += 4096) { // four rounds of 1 KiB per step, loads first
             sq_v4u w[5];
@@ -1172,7 +1172,7 @@ SQ_DEVFN void cert_compute_core(CertCtx& cx) {
     };
     auto loadRound = [&](s32 rp) -> sq_v4u { // bytes of the round that starts at position rp
         const u8* ad = a0 + (size_t)(u32)(rp - p0) + 16 * lane;
-        return sq_grd128(ad < aLast ? ad : aLast);
+        return sq_grd128_s(ad < aLast ? ad : aLast);
     };
     // Bloom tests of one round: returns the lane's candidate mask (bit j <-> position lo + j) and
     // leaves the lane's 20 bytes in d[]
