@@ -166,7 +166,9 @@ int sq_pack_wait(sq_ctx* ctx, uint64_t* h_comp_off, uint32_t* h_comp_len);
  *     is then in flight exactly as after sq_pack_submit and is collected by sq_pack_wait.  d_all_hashes, d_is_new and
  *     d_comp must stay valid until then.  The reference's counterpart of the exchange is the one DashMap all Rayon
  *     workers share (src/util/chunk.rs:52-56,83).
- * SQ_E_INVAL: no lane free, or the calls out of order. */
+ * SQ_E_INVAL: no lane free, or the calls out of order.  A failing sq_shard_submit_rest (SQ_E_CAP: dedup capacity or
+ * comp_cap too small, both detected before anything is enqueued) commits nothing to the dedup set and consumes the
+ * hash step: start the batch again with sq_shard_submit_hash. */
 int sq_shard_submit_hash(sq_ctx* ctx, const uint8_t* d_data, const uint64_t* h_off, const uint32_t* h_len, uint32_t n,
                          uint8_t* d_hashes);
 int sq_shard_wait_hash(sq_ctx* ctx);
