@@ -47,8 +47,14 @@ typedef struct sq_config {
     uint64_t max_batch_bytes;  /* input bytes per call when staged from host (0 = 1 GiB) */
     uint64_t dedup_capacity;   /* distinct chunks the dedup set can hold (0 = 1<<22) */
     uint32_t compress_waves;   /* persistent compressor wavefronts (0 = auto) */
-    uint32_t reserved;
+    uint32_t flags;            /* SQ_CFG_*; 0 = defaults */
 } sq_config;
+/* How sq_pack_batch / sq_pack_submit order the hash and the first compress stage of a batch (same results either way):
+ * by default chosen per batch from the duplicate ratio of the batch before -- few duplicates: "fused", the first
+ * compress stage runs before the dedup decision and computes the hash of every chunk it streams (one read of the chunk
+ * instead of two); many duplicates: "split", hash -> dedup -> compress only the new chunks. */
+#define SQ_CFG_NEVER_FUSE_HASH 1u
+#define SQ_CFG_ALWAYS_FUSE_HASH 2u
 
 /* Lifecycle.  One ctx per driver thread (a ctx is not re-entrant); the dedup set inside is the
  * counterpart of ChunkStore.primary_store (src/util/chunk.rs:20-24,52-56). */

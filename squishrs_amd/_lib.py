@@ -13,6 +13,7 @@ SQ_OK = 0
 SQ_E_INVAL, SQ_E_NOMEM, SQ_E_CAP, SQ_E_DEVICE, SQ_E_COMPRESS, SQ_E_NODEVICE = -1, -2, -3, -4, -5, -6
 SQ_ABI_VERSION = 1
 SQ_CHUNK_SIZE = 2048 * 1024
+SQ_CFG_NEVER_FUSE_HASH, SQ_CFG_ALWAYS_FUSE_HASH = 1, 2
 
 EXPORTS = [
     "sq_abi_version", "sq_strerror", "sq_compress_bound", "sq_ctx_create", "sq_ctx_destroy",
@@ -28,7 +29,7 @@ class SqConfig(ctypes.Structure):
     _fields_ = [("abi_version", ctypes.c_uint32), ("device", ctypes.c_int32),
                 ("max_chunk", ctypes.c_uint32), ("max_batch_chunks", ctypes.c_uint32),
                 ("max_batch_bytes", ctypes.c_uint64), ("dedup_capacity", ctypes.c_uint64),
-                ("compress_waves", ctypes.c_uint32), ("reserved", ctypes.c_uint32)]
+                ("compress_waves", ctypes.c_uint32), ("flags", ctypes.c_uint32)]
 
 
 class SqTimings(ctypes.Structure):

@@ -54,9 +54,12 @@ class ChunkStore:
     """== ChunkStore (src/util/chunk.rs:19-24,52-56,80-136); the dedup set lives in HBM."""
 
     def __init__(self, device: int = 0, max_chunk: int = CHUNK_SIZE, dedup_capacity: int = 1 << 22,
-                 compress_waves: int = 0):
+                 compress_waves: int = 0, fuse_hash: Optional[bool] = None):
+        """fuse_hash: None = the library chooses per batch (from the previous batch's duplicate ratio) whether the
+        first compress stage also computes the hashes; True / False force one form (same results)."""
         L = _lib.load()
-        cfg = SqConfig(_lib.SQ_ABI_VERSION, device, max_chunk, 0, 0, dedup_capacity, compress_waves, 0)
+        flags = 0 if fuse_hash is None else (_lib.SQ_CFG_ALWAYS_FUSE_HASH if fuse_hash else _lib.SQ_CFG_NEVER_FUSE_HASH)
+        cfg = SqConfig(_lib.SQ_ABI_VERSION, device, max_chunk, 0, 0, dedup_capacity, compress_waves, flags)
         h = ctypes.c_void_p()
         check(L.sq_ctx_create(ctypes.byref(cfg), ctypes.byref(h)))
         self._h = h

@@ -19,11 +19,36 @@
 #include <new>
 #include <vector>
 
+// Experiment / bring-up switches of the environment: read ONCE (the first sq_ctx_create), never on the per-batch path.
+struct sq_env {
+    bool debug = false, debug_stats = false, hash_wave_per_chunk = false, no_fastpath = false;
+    int stage1_wgs_per_cu = 0, stage2_waves_per_cu = 0, fast_dbg = 0;
+    int stage1_grid = -1; // SQ_STAGE1_GRID: 1 = one workgroup per chunk instead of persistent workgroups (experiment)
+    int fuse_hash = -1; // SQ_FUSE_HASH: 0 never, 1 always, unset: chosen per batch from the previous batch's duplicate ratio
+    bool allow_any_arch = false;
+};
+static sq_env g_env;
+static void sq_env_read() {
+    static bool done = false;
+    if (done) return;
+    done = true;
+    g_env.debug = getenv("SQ_DEBUG") != nullptr;
+    g_env.debug_stats = getenv("SQ_DEBUG_STATS") != nullptr;
+    g_env.hash_wave_per_chunk = getenv("SQ_HASH_WAVE_PER_CHUNK") != nullptr;
+    g_env.no_fastpath = getenv("SQ_NO_FASTPATH") != nullptr;
+    g_env.allow_any_arch = getenv("SQ_ALLOW_ANY_ARCH") != nullptr;
+    if (const char* e = getenv("SQ_STAGE1_WAVES_PER_CU")) g_env.stage1_wgs_per_cu = atoi(e);
+    if (const char* e = getenv("SQ_STAGE2_WAVES_PER_CU")) g_env.stage2_waves_per_cu = atoi(e);
+    if (const char* e = getenv("SQ_FAST_DBG")) g_env.fast_dbg = atoi(e);
+    if (const char* e = getenv("SQ_FUSE_HASH")) g_env.fuse_hash = atoi(e) ? 1 : 0;
+    if (const char* e = getenv("SQ_STAGE1_GRID")) g_env.stage1_grid = atoi(e);
+}
+
 #define HIPCHK(x)                                                                                  \
     do {                                                                                           \
         hipError_t e_ = (x);                                                                       \
         if (e_ != hipSuccess) {                                                                    \
-            if (getenv("SQ_DEBUG"))                                                                \
+            if (g_env.debug)                                                                       \
                 fprintf(stderr, "[squish_gpu] %s:%d %s -> %s\n", __FILE__, __LINE__, #x,           \
                         hipGetErrorString(e_));                                                    \
             return (e_ == hipErrorOutOfMemory) ? SQ_E_NOMEM : SQ_E_DEVICE;                         \
@@ -73,7 +98,7 @@ struct sq_lane {
     hipEvent_t ev[10] = {};
     hipEvent_t dedup_done = nullptr; // recorded after this lane's dedup kernels: the other lane's dedup waits for it
     DevBuf b_off, b_len, b_slot_off, b_frame_len, b_out_off, b_isnew, b_hashes, b_stage_in,
-        b_stage_out, b_slots, b_ws, b_misc, b_cert, b_etab, b_work;
+        b_stage_out, b_slots, b_ws, b_misc, b_cert, b_etab, b_work, b_hashed, b_hpool;
     // shapes of the two table pools at the last launch that completed (persistent generation tags)
     void* ws_ptr_last = nullptr;
     size_t ws_each_last = 0;
@@ -93,8 +118,9 @@ struct sq_lane {
     u32 job_max_len = 0;
     u32 job_waves = 0, job_fwaves = 0;
     size_t job_ws_each = 0, job_etab_bytes = 0;
-    bool job_fast = false;
-    u64 job_seen_before = 0;
+    bool job_fast = false, job_in_place = false, job_fused = false;
+    u8* job_slots = nullptr;
+    u32 job_ws_persist = 0, job_etab_persist = 0;
     // host-pointer batch of sq_pack_submit: where the results go at sq_pack_wait
     bool job_host = false;
     u8 *job_h_hashes = nullptr, *job_h_isnew = nullptr, *job_h_comp = nullptr;
@@ -122,6 +148,7 @@ struct sq_ctx {
     sq_lane ln[2];
     u32 last_lane = 0; // lane of the batch finished most recently (sq_debug_stage2_list)
     u32 submitted = 0, collected = 0; // sq_pack_submit / sq_pack_wait tickets (submitted - collected <= 2)
+    float dup_ratio_last = 0.f;       // duplicates / chunks of the batch collected last (chooses the fused form)
     bool shard_pending = false;       // sq_shard_submit_hash called, sq_shard_submit_rest not yet
 };
 
@@ -169,6 +196,7 @@ int sq_ctx_create(const sq_config* cfg_in, sq_ctx** out) {
     if (cfg.max_batch_bytes == 0) cfg.max_batch_bytes = 1ull << 30;
     if (cfg.dedup_capacity == 0) cfg.dedup_capacity = 1ull << 22;
 
+    sq_env_read();
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
         (void)hipGetLastError();
@@ -178,7 +206,7 @@ int sq_ctx_create(const sq_config* cfg_in, sq_ctx** out) {
     HIPCHK(hipSetDevice(cfg.device));
     hipDeviceProp_t prop;
     HIPCHK(hipGetDeviceProperties(&prop, cfg.device));
-    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0 && !getenv("SQ_ALLOW_ANY_ARCH")) return SQ_E_NODEVICE;
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0 && !g_env.allow_any_arch) return SQ_E_NODEVICE;
 
     sq_ctx* c = new (std::nothrow) sq_ctx();
     if (!c) return SQ_E_NOMEM;
@@ -223,7 +251,7 @@ int sq_ctx_create(const sq_config* cfg_in, sq_ctx** out) {
     }
 #ifndef SQ_NO_COMPRESS
     {
-        std::vector<u32> tab(SQZ_SCHEDTAB_WORDS, 0);
+        std::vector<u32> tab(SQZ_SCHEDTAB_WORDS + 4, 0); // (+ padding: stage 1 reads the last 2-byte bitmap word with a 4-byte load)
         sqz::sched_tab_fill(tab.data());
         if (hipMalloc((void**)&c->d_sched_tab, tab.size() * 4) != hipSuccess ||
             hipMemcpy(c->d_sched_tab, tab.data(), tab.size() * 4, hipMemcpyHostToDevice) != hipSuccess) {
@@ -243,7 +271,8 @@ void sq_ctx_destroy(sq_ctx* c) {
         sq_lane* const L = &ln;
         if (L->stream) (void)hipStreamSynchronize(L->stream);
         for (DevBuf* b : {&L->b_off, &L->b_len, &L->b_slot_off, &L->b_frame_len, &L->b_out_off, &L->b_isnew,
-                          &L->b_hashes, &L->b_stage_in, &L->b_stage_out, &L->b_slots, &L->b_ws, &L->b_misc, &L->b_cert, &L->b_etab, &L->b_work})
+                          &L->b_hashes, &L->b_stage_in, &L->b_stage_out, &L->b_slots, &L->b_ws, &L->b_misc, &L->b_cert, &L->b_etab, &L->b_work,
+                          &L->b_hashed, &L->b_hpool})
             b->release();
         if (L->h_pinned) (void)hipHostFree(L->h_pinned);
         if (L->h_len_pinned) (void)hipHostFree(L->h_len_pinned);
@@ -316,18 +345,20 @@ static int upload_off_len(sq_ctx* c, sq_lane* L, const u64* h_off, const u32* h_
     return SQ_OK;
 }
 
-static int launch_hash(sq_ctx* c, sq_lane* L, const u8* d_data, u32 n, u8* d_hashes) {
+// d_summed / d_sums (or null): chunks whose block sums the fused form of compress stage 1 has left in its pool
+static int launch_hash(sq_ctx* c, sq_lane* L, const u8* d_data, u32 n, u8* d_hashes, const u8* d_summed = nullptr,
+                       const u8* d_sums = nullptr) {
     if (n == 0) return SQ_OK;
     const u32 wpb = 4;
     HIPCHK(hipEventRecord(L->ev[0], L->stream));
-    if (getenv("SQ_HASH_WAVE_PER_CHUNK")) { // the first mapping: one wave per chunk
+    if (g_env.hash_wave_per_chunk && !d_summed) { // the first mapping: one wave per chunk
         dim3 grid((n + wpb - 1) / wpb), block(64 * wpb);
         hipLaunchKernelGGL(sqx::k_xxh3_128_batch, grid, block, 0, L->stream, d_data, (const u64*)L->b_off.p,
                            (const u32*)L->b_len.p, n, d_hashes);
     } else { // 16 lanes per chunk, four chunks per wave
         dim3 grid((n + 4 * wpb - 1) / (4 * wpb)), block(64 * wpb);
         hipLaunchKernelGGL(sqx::k_xxh3_128_rows, grid, block, 0, L->stream, d_data, (const u64*)L->b_off.p,
-                           (const u32*)L->b_len.p, n, d_hashes);
+                           (const u32*)L->b_len.p, n, d_hashes, d_summed, d_sums, (u64)SQZ_FAST_HPOOL_BYTES);
     }
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(L->ev[1], L->stream));
@@ -429,12 +460,18 @@ int sq_calibrate_gather(sq_ctx* c, const uint8_t* d_buf, uint64_t nbytes, uint32
 // nullptr: the slots are a scratch buffer and the frames are then packed back to back into d_comp
 // (h_comp_off: n + 1 offsets).  Otherwise the slots ARE d_comp and the frames stay where they were
 // produced (h_comp_off: n slot offsets, h_comp_len: n frame lengths): no packing pass.
-// Two halves: compress_enqueue puts every kernel and the small result copies on the lane's stream and returns;
-// compress_finish waits for them, hands out offsets / lengths and (packed layout) runs the packing pass.
-static int compress_enqueue(sq_ctx* c, sq_lane* L, const u8* d_data, const u32* h_len, u32 n, const u8* d_select,
-                            u8* d_comp, u64 comp_cap, bool in_place) {
+// Three steps, all of them only ENQUEUE on the lane's stream: compress_prepare sizes and allocates everything a batch
+// needs (every fallible allocation and argument check of the compress stage happens here, BEFORE a caller commits the
+// batch to the shared dedup set), compress_stage1 launches the incompressible-chunk kernel, compress_stage2 the
+// compressor proper and the small result copies.  compress_finish waits for them, hands out offsets / lengths and
+// (packed layout) runs the packing pass.
+// fused: stage 1 will run on every chunk before the dedup decision and also hash what it streams (sq_zstd_fast.h).
+static int compress_prepare(sq_ctx* c, sq_lane* L, const u32* h_len, u32 n, u8* d_comp, u64 comp_cap, bool in_place, bool fused) {
     int r;
     L->job_n = n;
+    L->job_in_place = in_place;
+    L->job_fused = false;
+    L->job_fast = false;
     if (n == 0) return SQ_OK;
     // slot offsets on the host (prefix sum of bounds)
     std::vector<u64>& slot_off = L->job_slot_off;
@@ -455,52 +492,71 @@ static int compress_enqueue(sq_ctx* c, sq_lane* L, const u8* d_data, const u32* 
         if (acc > comp_cap) return SQ_E_CAP;
     } else if ((r = L->b_slots.ensure(acc)))
         return r;
-    u8* const d_slots = in_place ? d_comp : (u8*)L->b_slots.p;
-    HIPCHK(hipMemcpyAsync(L->b_slot_off.p, slot_off.data(), ((size_t)n + 1) * 8, hipMemcpyHostToDevice,
-                          L->stream));
-    HIPCHK(hipMemsetAsync(L->b_frame_len.p, 0, (size_t)n * 4, L->stream));
+    L->job_slots = in_place ? d_comp : (u8*)L->b_slots.p;
 
     // persistent compressor waves, one private workspace each
     u32 waves = c->cfg.compress_waves ? c->cfg.compress_waves : (u32)c->num_cu * 8;
-    if (const char* e = getenv("SQ_STAGE2_WAVES_PER_CU")) { // experiment: leave wave slots to the other lane's kernels
-        int const w = atoi(e);
-        if (w >= 1 && w <= 8 && !c->cfg.compress_waves) waves = (u32)c->num_cu * (u32)w;
-    }
+    if (g_env.stage2_waves_per_cu >= 1 && g_env.stage2_waves_per_cu <= 8 && !c->cfg.compress_waves) // experiment: leave wave slots to the other lane's kernels
+        waves = (u32)c->num_cu * (u32)g_env.stage2_waves_per_cu;
     waves = std::min(waves, n);
     const size_t ws_each = sqz::workspace_bytes(max_len);
     // keep the workspace pool within ~96 GiB
     while (waves > 64 && (u64)waves * ws_each > (96ull << 30)) waves /= 2;
-    // Stage 1, the incompressible-chunk kernel (sq_zstd_fast.h): as many waves as fit (its state is all
+    // Stage 1, the incompressible-chunk kernel (sq_zstd_fast.h): as many workgroups as fit (its state is all
     // in LDS).  It only applies to chunks of 16 KiB < len <= 256 KiB.
-    const bool fast = max_len > (16u << 10) && !getenv("SQ_NO_FASTPATH");
+    const bool fast = max_len > (16u << 10) && !g_env.no_fastpath;
     u32 fwaves = 0;
     size_t etab_bytes = 0;
     if (fast) {
-        etab_bytes = 0; // the certificate's set lives in LDS now; a wave's slice only keeps its 256 bytes of saved state
+        etab_bytes = 0; // the certificate's set lives in LDS now; a workgroup's slice only keeps its 256 bytes of saved state
         int occ = 0; // resident workgroups (of SQZ_FAST_WG_WAVES waves, one chunk each) per CU
         (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, sqz::k_incompressible_batch, 64 * SQZ_FAST_WG_WAVES, 0);
         if (occ < 1) occ = 4;
-        if (const char* e = getenv("SQ_STAGE1_WAVES_PER_CU")) { // experiment: leave room for another lane's kernels
-            int const w = atoi(e);
-            if (w >= 1 && w < occ) occ = w;
-        }
+        if (g_env.stage1_wgs_per_cu >= 1 && g_env.stage1_wgs_per_cu < occ) occ = g_env.stage1_wgs_per_cu; // experiment: leave room for another lane's kernels
         fwaves = c->cfg.compress_waves ? c->cfg.compress_waves * 2 : (u32)c->num_cu * (u32)occ;
         fwaves = std::min(fwaves, n);
+        if (g_env.stage1_grid == 1) fwaves = n;
         if ((r = L->b_cert.ensure((size_t)n * 8))) return r;
         if ((r = L->b_work.ensure(((size_t)2 * n + 2) * 4))) return r;
-        HIPCHK(hipMemsetAsync(L->b_work.p, 0, 8, L->stream));
+        if (fused) {
+            if ((r = L->b_hashed.ensure((size_t)n + 16))) return r;
+            if ((r = L->b_hpool.ensure((size_t)n * SQZ_FAST_HPOOL_BYTES))) return r;
+        }
     }
     if ((r = L->b_ws.ensure((size_t)waves * ws_each + 256))) return r;
     if (fast && (r = L->b_etab.ensure((size_t)fwaves * (etab_bytes + 256)))) return r;
+    if ((r = L->b_misc.ensure(256))) return r;
+    if (in_place && L->h_len_cap < (size_t)n * 4) {
+        if (L->h_len_pinned) (void)hipHostFree(L->h_len_pinned);
+        L->h_len_pinned = nullptr;
+        L->h_len_cap = 0;
+        size_t const want = (size_t)n * 4 + ((size_t)n >> 1) + 4096;
+        if (hipHostMalloc(&L->h_len_pinned, want, hipHostMallocDefault) != hipSuccess) {
+            (void)hipGetLastError();
+            return SQ_E_NOMEM;
+        }
+        L->h_len_cap = want;
+    }
     // the pools keep their generation tags from launch to launch as long as nothing about them changes
-    const u32 ws_persist = (L->b_ws.p == L->ws_ptr_last && ws_each == L->ws_each_last && waves == L->ws_waves_last && fast) ? 1u : 0u;
-    const u32 etab_persist = (fast && L->b_etab.p == L->etab_ptr_last && etab_bytes == L->etab_bytes_last && fwaves == L->etab_waves_last) ? 1u : 0u;
+    L->job_ws_persist = (L->b_ws.p == L->ws_ptr_last && ws_each == L->ws_each_last && waves == L->ws_waves_last && fast) ? 1u : 0u;
+    L->job_etab_persist = (fast && L->b_etab.p == L->etab_ptr_last && etab_bytes == L->etab_bytes_last && fwaves == L->etab_waves_last) ? 1u : 0u;
     L->ws_ptr_last = nullptr; // becomes valid again when this launch has completed
     L->etab_ptr_last = nullptr;
-    if ((r = L->b_misc.ensure(256))) return r;
+    L->job_max_len = max_len;
+    L->job_waves = waves;
+    L->job_fwaves = fwaves;
+    L->job_ws_each = ws_each;
+    L->job_etab_bytes = etab_bytes;
+    L->job_fast = fast;
+    L->job_fused = fused && fast;
+    L->last.fast_ms = 0;
+    // nothing below can fail for lack of memory
+    HIPCHK(hipMemcpyAsync(L->b_slot_off.p, slot_off.data(), ((size_t)n + 1) * 8, hipMemcpyHostToDevice, L->stream));
+    HIPCHK(hipMemsetAsync(L->b_frame_len.p, 0, (size_t)n * 4, L->stream));
+    if (fast) HIPCHK(hipMemsetAsync(L->b_work.p, 0, 8, L->stream));
+    if (L->job_fused) HIPCHK(hipMemsetAsync(L->b_hashed.p, 0, (size_t)n, L->stream));
     HIPCHK(hipMemsetAsync(L->b_misc.p, 0, 256, L->stream));
-
-    if (getenv("SQ_DEBUG")) {
+    if (g_env.debug) {
         int nb = 0;
         (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, sqz::k_compress_batch, 64, 0);
         hipFuncAttributes fa;
@@ -509,29 +565,50 @@ static int compress_enqueue(sq_ctx* c, sq_lane* L, const u8* d_data, const u32* 
                 nb, fa.numRegs, fa.sharedSizeBytes, fa.localSizeBytes, waves, ws_each);
         (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, sqz::k_incompressible_batch, 64 * SQZ_FAST_WG_WAVES, 0);
         (void)hipFuncGetAttributes(&fa, (const void*)sqz::k_incompressible_batch);
-        fprintf(stderr, "[squish_gpu] incompressible-chunk kernel: occupancy %d blocks/CU, regs %d, lds %zu, scratch %zu; waves %u, table %zu\n",
-                nb, fa.numRegs, fa.sharedSizeBytes, fa.localSizeBytes, fwaves, etab_bytes);
+        fprintf(stderr, "[squish_gpu] incompressible-chunk kernel: occupancy %d blocks/CU, regs %d, lds %zu, scratch %zu; workgroups %u, fused hash %d\n",
+                nb, fa.numRegs, fa.sharedSizeBytes, fa.localSizeBytes, fwaves, (int)L->job_fused);
     }
-    L->last.fast_ms = 0;
-    if (fast) {
-        HIPCHK(hipEventRecord(L->ev[8], L->stream));
-        hipLaunchKernelGGL(sqz::k_incompressible_batch, dim3(fwaves), dim3(64 * SQZ_FAST_WG_WAVES), 0, L->stream, d_data,
-                           (const u64*)L->b_off.p, (const u32*)L->b_len.p, d_select, n, d_slots,
-                           (const u64*)L->b_slot_off.p, (u32*)L->b_frame_len.p, (u32*)L->b_cert.p, (u8*)L->b_etab.p,
-                           (u64)etab_bytes, (u32*)L->b_misc.p + 32 /*queue*/, (const u32*)c->d_sched_tab,
-                           (u32)(getenv("SQ_FAST_DBG") ? atoi(getenv("SQ_FAST_DBG")) : 0), etab_persist, (u32*)L->b_work.p);
+    return SQ_OK;
+}
+
+// Stage 1.  d_select: the chunks to look at (null = all).  fused (L->job_fused must hold): the kernel also leaves the
+// XXH3 block sums of every chunk it streams in L->b_hpool, L->b_hashed says which.
+static int compress_stage1(sq_ctx* c, sq_lane* L, const u8* d_data, const u8* d_select, bool fused) {
+    u32 const n = L->job_n;
+    if (n == 0 || !L->job_fast) return SQ_OK;
+    fused = fused && L->job_fused;
+    HIPCHK(hipEventRecord(L->ev[8], L->stream));
+    hipLaunchKernelGGL(sqz::k_incompressible_batch, dim3(L->job_fwaves), dim3(64 * SQZ_FAST_WG_WAVES), 0, L->stream, d_data,
+                       (const u64*)L->b_off.p, (const u32*)L->b_len.p, d_select, n, L->job_slots,
+                       (const u64*)L->b_slot_off.p, (u32*)L->b_frame_len.p, (u32*)L->b_cert.p, (u8*)L->b_etab.p,
+                       (u64)L->job_etab_bytes, (u32*)L->b_misc.p + 32 /*queue*/, (const u32*)c->d_sched_tab,
+                       (u32)g_env.fast_dbg, L->job_etab_persist, (u32*)L->b_work.p,
+                       fused ? (u8*)L->b_hashed.p : (u8*)nullptr, fused ? (u8*)L->b_hpool.p : (u8*)nullptr);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipEventRecord(L->ev[9], L->stream));
+    return SQ_OK;
+}
+
+// Stage 2, the compressor proper, for everything stage 1 left undecided (of the selected chunks), then the small
+// result copies.  Fused form: stage 1 ran before the dedup decision, so the frames it wrote for duplicates are dropped
+// here (their lengths zeroed) and the compressor skips the duplicates on its work lists.
+static int compress_stage2(sq_ctx* c, sq_lane* L, const u8* d_data, const u8* d_select) {
+    u32 const n = L->job_n;
+    if (n == 0) return SQ_OK;
+    bool const fast = L->job_fast, in_place = L->job_in_place;
+    if (L->job_fused && d_select) {
+        hipLaunchKernelGGL(sqd::k_drop_unselected, dim3((n + 255) / 256), dim3(256), 0, L->stream, (u32*)L->b_frame_len.p, d_select, n,
+                           (u32*)L->b_misc.p + 33 /* stage 1's count of decided chunks */);
         HIPCHK(hipGetLastError());
-        HIPCHK(hipEventRecord(L->ev[9], L->stream));
     }
-    // Stage 2, the compressor proper, for everything stage 1 left undecided
     HIPCHK(hipEventRecord(L->ev[4], L->stream));
     {
-        dim3 block(64), grid(waves);
+        dim3 block(64), grid(L->job_waves);
         hipLaunchKernelGGL(sqz::k_compress_batch, grid, block, 0, L->stream, d_data, (const u64*)L->b_off.p,
-                           (const u32*)L->b_len.p, d_select, n, d_slots,
+                           (const u32*)L->b_len.p, d_select, n, L->job_slots,
                            (const u64*)L->b_slot_off.p, (u32*)L->b_frame_len.p, (u8*)L->b_ws.p,
-                           (u64)ws_each, (u32*)L->b_misc.p /*queue*/, (u32*)L->b_misc.p + 16 /*err*/,
-                           (const u32*)c->d_sched_tab, fast ? (const u32*)L->b_cert.p : (const u32*)nullptr, ws_persist,
+                           (u64)L->job_ws_each, (u32*)L->b_misc.p /*queue*/, (u32*)L->b_misc.p + 16 /*err*/,
+                           (const u32*)c->d_sched_tab, fast ? (const u32*)L->b_cert.p : (const u32*)nullptr, L->job_ws_persist,
                            fast ? (const u32*)L->b_work.p : (const u32*)nullptr);
         HIPCHK(hipGetLastError());
     }
@@ -550,12 +627,12 @@ static int compress_enqueue(sq_ctx* c, sq_lane* L, const u8* d_data, const u32* 
         if (hipStreamQuery(L->stream) == hipErrorNotReady) {
             hipStream_t s2;
             (void)hipStreamCreateWithFlags(&s2, hipStreamNonBlocking);
-            const sqz::WsLayout WL = sqz::ws_layout(max_len);
-            for (u32 w = 0; w < std::min(waves, 4u); w++) {
+            const sqz::WsLayout WL = sqz::ws_layout(L->job_max_len);
+            for (u32 w = 0; w < std::min(L->job_waves, 4u); w++) {
                 u32 tr[64];
                 // per-chunk layouts differ from the pool layout: dump the dummy area of every
                 // distinct layout used in this batch (bring-up batches are uniform)
-                (void)hipMemcpyAsync(tr, (u8*)L->b_ws.p + (size_t)w * ws_each + WL.dummy, sizeof(tr),
+                (void)hipMemcpyAsync(tr, (u8*)L->b_ws.p + (size_t)w * L->job_ws_each + WL.dummy, sizeof(tr),
                                      hipMemcpyDeviceToHost, s2);
                 (void)hipStreamSynchronize(s2);
                 fprintf(stderr, "[squish_gpu watchdog] wave %u trace:", w);
@@ -568,17 +645,8 @@ static int compress_enqueue(sq_ctx* c, sq_lane* L, const u8* d_data, const u32* 
     }
 #endif
     if (in_place) {
-        if (L->h_len_cap < (size_t)n * 4) {
-            if (L->h_len_pinned) (void)hipHostFree(L->h_len_pinned);
-            L->h_len_pinned = nullptr;
-            L->h_len_cap = 0;
-            size_t const want = (size_t)n * 4 + ((size_t)n >> 1) + 4096;
-            if (hipHostMalloc(&L->h_len_pinned, want, hipHostMallocDefault) != hipSuccess) return SQ_E_NOMEM;
-            L->h_len_cap = want;
-        }
         HIPCHK(hipMemcpyAsync(L->h_len_pinned, L->b_frame_len.p, (size_t)n * 4, hipMemcpyDeviceToHost, L->stream));
     } else {
-        if ((r = L->b_out_off.ensure(((size_t)n + 1) * 8))) return r;
         hipLaunchKernelGGL(sqd::k_scan_lengths, dim3(1), dim3(1024), 0, L->stream, (const u32*)L->b_frame_len.p,
                            n, (u64*)L->b_out_off.p);
         HIPCHK(hipGetLastError());
@@ -586,13 +654,15 @@ static int compress_enqueue(sq_ctx* c, sq_lane* L, const u8* d_data, const u32* 
     u32* h_err = (u32*)L->h_pinned;
     HIPCHK(hipMemcpyAsync(h_err, (u32*)L->b_misc.p + 16, 4, hipMemcpyDeviceToHost, L->stream));
     HIPCHK(hipMemcpyAsync(h_err + 1, (u32*)L->b_misc.p + 33, 4, hipMemcpyDeviceToHost, L->stream));
-    L->job_max_len = max_len;
-    L->job_waves = waves;
-    L->job_fwaves = fwaves;
-    L->job_ws_each = ws_each;
-    L->job_etab_bytes = etab_bytes;
-    L->job_fast = fast;
     return SQ_OK;
+}
+
+static int compress_enqueue(sq_ctx* c, sq_lane* L, const u8* d_data, const u32* h_len, u32 n, const u8* d_select,
+                            u8* d_comp, u64 comp_cap, bool in_place) {
+    int r;
+    if ((r = compress_prepare(c, L, h_len, n, d_comp, comp_cap, in_place, false))) return r;
+    if ((r = compress_stage1(c, L, d_data, d_select, false))) return r;
+    return compress_stage2(c, L, d_data, d_select);
 }
 
 static int compress_finish(sq_ctx* c, sq_lane* L, u8* d_comp, u64 comp_cap, u64* h_comp_off, u32* h_comp_len, bool in_place) {
@@ -693,14 +763,14 @@ static int compress_finish(sq_ctx* c, sq_lane* L, u8* d_comp, u64 comp_cap, u64*
         fprintf(stderr, "\n");
     }
 #endif
-    if (getenv("SQ_DEBUG_STATS") && fast) { // certificate ends of the first chunks, as stage 1 left them
+    if (g_env.debug_stats && fast) { // certificate ends of the first chunks, as stage 1 left them
         std::vector<u32> ce(2 * (size_t)std::min(n, 24u));
         (void)hipMemcpy(ce.data(), L->b_cert.p, ce.size() * 4, hipMemcpyDeviceToHost);
         fprintf(stderr, "[squish_gpu stats] cert ends:");
         for (size_t i = 0; i < ce.size(); i += 2) fprintf(stderr, " %u/%u", ce[i], ce[i + 1] & 0x7FFFFFFFu);
         fprintf(stderr, "\n");
     }
-    if (getenv("SQ_DEBUG_STATS")) { // per-wave statistics words of the last chunk each wave compressed
+    if (g_env.debug_stats) { // per-wave statistics words of the last chunk each wave compressed
         const sqz::WsLayout WL = sqz::ws_layout(max_len);
         for (u32 w = 0; w < waves && w < 6; w++) {
             u32 tr[64];
@@ -710,7 +780,7 @@ static int compress_finish(sq_ctx* c, sq_lane* L, u8* d_comp, u64 comp_cap, u64*
                     tr[8 + 40], tr[8 + 41], tr[8 + 42], tr[8 + 43]);
         }
     }
-    if (*h_err && getenv("SQ_DEBUG")) {
+    if (*h_err && g_env.debug) {
         const sqz::WsLayout WL = sqz::ws_layout(max_len);
         int shown = 0;
         for (u32 w = 0; w < waves && shown < 8; w++) {
@@ -823,6 +893,51 @@ uint64_t sq_slots_bound(const uint32_t* h_len, uint32_t n) {
     return acc;
 }
 
+#ifndef SQ_NO_COMPRESS
+// hash -> dedup -> compress of one batch of device-resident chunks, ENQUEUED on lane L (off / len already uploaded).
+// Two forms, chosen per batch (DESIGN.md 4.2 "fused hash"):
+//   split: XXH3 kernel -> dedup -> stage 1 and stage 2 on the new chunks              (two reads of every new chunk)
+//   fused: stage 1 on EVERY chunk, hashing what it streams -> XXH3 kernel for the chunks stage 1 did not stream ->
+//          dedup -> duplicates' frames dropped -> stage 2 on the new chunks stage 1 left undecided (one read; the
+//          certificate and raw frame of a duplicate are wasted work, so this is for batches with few duplicates)
+// Everything that can fail for lack of memory or capacity is checked before the shared dedup set is touched;
+// *committed says whether it was (a caller that promises "nothing is committed on failure" rolls back then).
+// other: the context's other lane when batches may be in flight on it (its dedup kernels come first), else null.
+static int pack_enqueue(sq_ctx* c, sq_lane* L, sq_lane* other, const u8* d_data, const u32* h_len, u32 n, u8* d_hashes,
+                        u8* d_isnew, u8* d_comp, u64 comp_cap, bool in_place, u32 flags, bool* committed) {
+    int r;
+    *committed = false;
+    int const mode = (c->cfg.flags & SQ_CFG_ALWAYS_FUSE_HASH) ? 1 : (c->cfg.flags & SQ_CFG_NEVER_FUSE_HASH) ? 0 : g_env.fuse_hash;
+    bool const fused = mode == 1 || (mode < 0 && c->dup_ratio_last < 0.25f);
+    if ((r = compress_prepare(c, L, h_len, n, d_comp, comp_cap, in_place, fused))) return r;
+    u64 const seen0 = (flags & 1u) ? 0 : c->n_seen;
+    if (seen0 + n > c->key_capacity || seen0 + n >= 0xFFFFFFFFull) return SQ_E_CAP;
+    if (L->job_fused) {
+        if ((r = compress_stage1(c, L, d_data, nullptr, true))) return r;
+        if ((r = launch_hash(c, L, d_data, n, d_hashes, (const u8*)L->b_hashed.p, (const u8*)L->b_hpool.p))) return r;
+    } else if ((r = launch_hash(c, L, d_data, n, d_hashes))) // (does not depend on the batch before)
+        return r;
+    // the dedup set is shared: this batch's reset / insert must follow the previous batch's dedup kernels
+    if (other && other->busy) HIPCHK(hipStreamWaitEvent(L->stream, other->dedup_done, 0));
+    *committed = true;
+    if (flags & 1u) {
+        HIPCHK(hipMemsetAsync(c->d_table, 0, (c->table_mask + 1) * sizeof(u32), L->stream));
+        HIPCHK(hipMemsetAsync(c->d_unique, 0, 64, L->stream));
+        c->n_seen = 0;
+    }
+    if (!other) // (the synchronous form: what a roll-back restores)
+        HIPCHK(hipMemcpyAsync(c->d_unique + 1, c->d_unique, sizeof(unsigned long long), hipMemcpyDeviceToDevice, L->stream));
+    if ((r = dedup_async(c, L, d_hashes, n, 0, n, d_isnew))) return r;
+    HIPCHK(hipEventRecord(L->dedup_done, L->stream));
+    if (!L->job_fused && (r = compress_stage1(c, L, d_data, d_isnew, false))) return r;
+    return compress_stage2(c, L, d_data, d_isnew);
+}
+
+static void note_dup_ratio(sq_ctx* c, u32 n, u32 n_new) {
+    if (n) c->dup_ratio_last = 1.f - (float)n_new / (float)n;
+}
+#endif
+
 int sq_pack_batch(sq_ctx* c, const uint8_t* data, const uint64_t* off, const uint32_t* len, uint32_t n,
                   uint8_t* hashes, uint8_t* is_new, uint8_t* comp, uint64_t comp_cap,
                   uint64_t* comp_off) {
@@ -877,25 +992,33 @@ int sq_pack_batch(sq_ctx* c, const uint8_t* data, const uint64_t* off, const uin
         use_off = off2.data();
     }
     if ((r = upload_off_len(c, L, use_off, len, n))) return r;
-    if ((r = launch_hash(c, L, d_data, n, d_hashes))) return r;
     // The dedup commit is provisional until the frames are out: if the compress stage fails (SQ_E_CAP: the
-    // frames do not fit comp_cap; SQ_E_COMPRESS; an allocation), the set, its unique count and the global
+    // frames do not fit comp_cap; SQ_E_COMPRESS; a launch failure), the set, its unique count and the global
     // chunk index are put back, so the caller can retry the same batch (squish_gpu.h: "nothing is committed").
     const u64 seen_before = c->n_seen;
-    HIPCHK(hipMemcpyAsync(c->d_unique + 1, c->d_unique, sizeof(unsigned long long), hipMemcpyDeviceToDevice, L->stream));
-    if ((r = dedup_async(c, L, d_hashes, n, 0, n, d_isnew))) return r; // (fails before touching the set)
-    r = compress_async(c, L, d_data, use_off, len, n, d_isnew, d_comp, comp_cap, comp_off, nullptr);
+    bool committed = false;
+    c->last_lane = 0;
+    L->job_host = false;
+    r = pack_enqueue(c, L, nullptr, d_data, len, n, d_hashes, d_isnew, d_comp, comp_cap, false, 0, &committed);
+    if (!r) r = compress_finish(c, L, d_comp, comp_cap, comp_off, nullptr, false);
     if (r) {
-        const u64 nslots = c->table_mask + 1;
-        hipLaunchKernelGGL(sqd::k_dedup_rollback, dim3((unsigned)std::min<u64>((nslots + 255) / 256, 4096)), dim3(256), 0,
-                           L->stream, c->d_table, nslots, seen_before);
-        (void)hipMemcpyAsync(c->d_unique, c->d_unique + 1, sizeof(unsigned long long), hipMemcpyDeviceToDevice, L->stream);
+        if (committed) {
+            const u64 nslots = c->table_mask + 1;
+            hipLaunchKernelGGL(sqd::k_dedup_rollback, dim3((unsigned)std::min<u64>((nslots + 255) / 256, 4096)), dim3(256), 0,
+                               L->stream, c->d_table, nslots, seen_before);
+            (void)hipMemcpyAsync(c->d_unique, c->d_unique + 1, sizeof(unsigned long long), hipMemcpyDeviceToDevice, L->stream);
+        }
         (void)hipStreamSynchronize(L->stream);
         c->n_seen = seen_before;
         return r;
     }
     HIPCHK(hipEventElapsedTime(&L->last.hash_ms, L->ev[0], L->ev[1]));
     HIPCHK(hipEventElapsedTime(&L->last.dedup_ms, L->ev[2], L->ev[3]));
+    {
+        u32 n_new = 0;
+        for (u32 i = 0; i < n; i++) n_new += comp_off[i + 1] != comp_off[i];
+        note_dup_ratio(c, n, n_new);
+    }
     if (!dev) {
         HIPCHK(hipMemcpyAsync(hashes, d_hashes, (size_t)n * 16, hipMemcpyDeviceToHost, L->stream));
         HIPCHK(hipMemcpyAsync(is_new, d_isnew, n, hipMemcpyDeviceToHost, L->stream));
@@ -962,20 +1085,10 @@ int sq_pack_submit(sq_ctx* c, const uint8_t* data, const uint64_t* h_off, const 
         L->job_comp_cap = comp_cap;
     }
     if ((r = upload_off_len(c, L, use_off, h_len, n))) return r;
-    if ((r = launch_hash(c, L, d_data, n, d_hashes))) return r; // (does not depend on the batch before)
-    // the dedup set is shared: this batch's reset / insert must follow the previous batch's dedup kernels
-    if (other->busy) HIPCHK(hipStreamWaitEvent(L->stream, other->dedup_done, 0));
-    if (flags & 1u) {
-        HIPCHK(hipMemsetAsync(c->d_table, 0, (c->table_mask + 1) * sizeof(u32), L->stream));
-        HIPCHK(hipMemsetAsync(c->d_unique, 0, 64, L->stream));
-        c->n_seen = 0;
-    }
-    L->job_seen_before = c->n_seen;
-    if ((r = dedup_async(c, L, d_hashes, n, 0, n, d_isnew))) return r; // (fails before touching the set)
-    HIPCHK(hipEventRecord(L->dedup_done, L->stream));
-    if ((r = compress_enqueue(c, L, d_data, h_len, n, d_isnew, d_comp, dev ? comp_cap : ~0ull, dev))) {
+    bool committed = false;
+    if ((r = pack_enqueue(c, L, other, d_data, h_len, n, d_hashes, d_isnew, d_comp, dev ? comp_cap : ~0ull, dev, flags, &committed))) {
         (void)hipStreamSynchronize(L->stream);
-        return r;
+        return r; // (committed: squish_gpu.h -- sq_dedup_reset before the context is used again)
     }
     if (!dev && n) { // the packing pass, on the device: slots -> staging buffer, offsets from the scan
         HIPCHK(hipEventRecord(L->ev[6], L->stream));
@@ -1034,6 +1147,14 @@ int sq_shard_submit_rest(sq_ctx* c, const uint8_t* d_all_hashes, uint64_t n_tota
     if (sq_slots_bound(L->shard_len.data(), n) > comp_cap) return SQ_E_CAP;
     HIPCHK(hipSetDevice(c->device));
     int r;
+    c->shard_pending = false; // (whatever happens below, the hash step is consumed)
+    // every allocation and capacity check of the batch comes BEFORE the replicated dedup set is touched: a failure
+    // here leaves this rank's set as the other ranks' (squish_gpu.h)
+    {
+        u64 const seen0 = (flags & 1u) ? 0 : c->n_seen;
+        if (seen0 + n_total > c->key_capacity || seen0 + n_total >= 0xFFFFFFFFull) return SQ_E_CAP;
+    }
+    if ((r = compress_prepare(c, L, L->shard_len.data(), n, d_comp, comp_cap, true, false))) return r;
     // the dedup set is shared: this batch's reset / insert must follow the previous batch's dedup kernels
     if (other->busy) HIPCHK(hipStreamWaitEvent(L->stream, other->dedup_done, 0));
     if (flags & 1u) {
@@ -1041,11 +1162,9 @@ int sq_shard_submit_rest(sq_ctx* c, const uint8_t* d_all_hashes, uint64_t n_tota
         HIPCHK(hipMemsetAsync(c->d_unique, 0, 64, L->stream));
         c->n_seen = 0;
     }
-    L->job_seen_before = c->n_seen;
-    c->shard_pending = false; // (whatever happens below, the hash step is consumed)
-    if ((r = dedup_async(c, L, d_all_hashes, n_total, my_first, n, d_is_new))) return r; // (fails before touching the set)
+    if ((r = dedup_async(c, L, d_all_hashes, n_total, my_first, n, d_is_new))) return r; // (SQ_E_CAP: fails before touching the set)
     HIPCHK(hipEventRecord(L->dedup_done, L->stream));
-    if ((r = compress_enqueue(c, L, L->shard_data, L->shard_len.data(), n, d_is_new, d_comp, comp_cap, true))) {
+    if ((r = compress_stage1(c, L, L->shard_data, d_is_new, false)) || (r = compress_stage2(c, L, L->shard_data, d_is_new))) {
         (void)hipStreamSynchronize(L->stream);
         return r;
     }
@@ -1086,9 +1205,17 @@ int sq_pack_wait(sq_ctx* c, uint64_t* h_comp_off, uint32_t* h_comp_len) {
             }
         }
     }
+    // Also for an empty batch: the lane may still have dedup work queued for it (the sharded form commits every rank's
+    // hashes; a reset clears the table), and the next submit on the other lane only orders itself behind a BUSY lane.
+    if (hipStreamSynchronize(L->stream) != hipSuccess && !r) r = SQ_E_DEVICE;
     L->busy = false;
     c->collected++;
     if (r) return r;
+    if (n && !c->shard_pending) {
+        u32 n_new = 0;
+        for (u32 i = 0; i < n; i++) n_new += h_comp_len[i] != 0;
+        note_dup_ratio(c, n, n_new);
+    }
     if (n) {
         HIPCHK(hipEventElapsedTime(&L->last.hash_ms, L->ev[0], L->ev[1]));
         HIPCHK(hipEventElapsedTime(&L->last.dedup_ms, L->ev[2], L->ev[3]));

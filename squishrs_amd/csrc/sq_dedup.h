@@ -75,6 +75,22 @@ k_dedup_resolve(const u64* __restrict__ keys, u64 g_first, u32 n, const u32* __r
     }
 }
 
+// Fused form of the compress stage (sq_api.hip compress_stage2): stage 1 ran on every chunk BEFORE the dedup decision;
+// the frames it produced for chunks that turned out to be duplicates are dropped (ChunkStore::insert returns
+// compressed_data: None for them, /root/reference/src/util/chunk.rs:84-87), and stage 1's count of decided chunks is
+// corrected.
+__global__ void __launch_bounds__(256)
+k_drop_unselected(u32* __restrict__ frame_len, const u8* __restrict__ select, u32 n, u32* __restrict__ decided) {
+    u32 const i = blockIdx.x * blockDim.x + threadIdx.x;
+    bool drop = false;
+    if (i < n && select[i] == 0 && frame_len[i] != 0) {
+        frame_len[i] = 0;
+        drop = true;
+    }
+    const u64 b = __ballot(drop);
+    if ((threadIdx.x & 63) == 0 && b) atomicSub(decided, (u32)__popcll(b));
+}
+
 // Undo of one batch's k_dedup_insert (sq_pack_batch failing after the commit): empty every slot whose
 // representative index is >= g_first.  Entries of earlier batches were placed before any of these existed, so
 // their probe paths never run across the slots emptied here -- no tombstones are needed.

@@ -153,6 +153,49 @@ __device__ __forceinline__ uint4 ld16(const u8* p) {
 #endif
 }
 
+// The end of the long path for one wave: lane l holds the accumulator pair (acc[2j], acc[2j+1]), j = l & 3, as it
+// stands after the last FULL 1 KiB block (all 16 lanes of a class hold the same values).  Adds the stripes of the
+// last partial block and the final 64 bytes (secret offset 192-64-7), merges.  Every lane returns the hash.
+// Also the tail of the hash that compress stage 1 computes beside its scan (sq_zstd_fast.h, fast_hash_chain).
+__device__ inline H128 hash_finish_wave(const u8* __restrict__ p, u64 len, u32 lane, u64 a0, u64 a1) {
+    const u32 s = lane >> 2, i0 = 2 * (lane & 3);
+    const u64 sk0 = sec64(8 * s + 8 * i0), sk1 = sec64(8 * s + 8 * i0 + 8);
+    const u64 nbBlocks = (len - 1) >> 10;
+    const u8* q = p + lane * 16;
+    {   // last partial block: full stripes, then the final 64 bytes with secret offset 192-64-7
+        const u64 done = nbBlocks << 10;
+        const u32 nbStripes = (u32)(((len - 1) - done) >> 6);
+        u64 c0 = 0, c1 = 0;
+        if (s < nbStripes) {
+            uint4 v = ld16(q + done);
+            contrib(v, sk0, sk1, c0, c1);
+        }
+        if (lane < 4) {
+            uint4 v = ld16(p + len - 64 + lane * 16);
+            contrib(v, sec64(121 + 8 * i0), sec64(121 + 8 * i0 + 8), c0, c1);
+        }
+#pragma unroll
+        for (int m = 4; m < 64; m <<= 1) {
+            c0 += shfl_xor64(c0, m);
+            c1 += shfl_xor64(c1, m);
+        }
+        a0 += c0;
+        a1 += c1;
+    }
+    // mergeAccs: lanes with (lane&3)==i hold acc[2i], acc[2i+1]
+    const u32 i = lane & 3;
+    u64 lo = mul128_fold64(a0 ^ sec64(11 + 16 * i), a1 ^ sec64(11 + 16 * i + 8));
+    u64 hi = mul128_fold64(a0 ^ sec64(117 + 16 * i), a1 ^ sec64(117 + 16 * i + 8));
+    lo += shfl_xor64(lo, 1);
+    lo += shfl_xor64(lo, 2);
+    hi += shfl_xor64(hi, 1);
+    hi += shfl_xor64(hi, 2);
+    H128 r;
+    r.lo = avalanche3(lo + len * P64_1);
+    r.hi = avalanche3(hi + ~(len * P64_2));
+    return r;
+}
+
 // One wave, one chunk.  Every lane returns the full hash.
 __device__ inline H128 hash_long_wave(const u8* __restrict__ p, u64 len, u32 lane) {
     const u32 s = lane >> 2, i0 = 2 * (lane & 3);
@@ -202,32 +245,7 @@ __device__ inline H128 hash_long_wave(const u8* __restrict__ p, u64 len, u32 lan
         contrib(v, sk0, sk1, c0, c1);
         finish_block(c0, c1, true);
     }
-    {   // last partial block: full stripes, then the final 64 bytes with secret offset 192-64-7
-        const u64 done = nbBlocks << 10;
-        const u32 nbStripes = (u32)(((len - 1) - done) >> 6);
-        u64 c0 = 0, c1 = 0;
-        if (s < nbStripes) {
-            uint4 v = ld16(q + done);
-            contrib(v, sk0, sk1, c0, c1);
-        }
-        if (lane < 4) {
-            uint4 v = ld16(p + len - 64 + lane * 16);
-            contrib(v, sec64(121 + 8 * i0), sec64(121 + 8 * i0 + 8), c0, c1);
-        }
-        finish_block(c0, c1, false);
-    }
-    // mergeAccs: lanes with (lane&3)==i hold acc[2i], acc[2i+1]
-    const u32 i = lane & 3;
-    u64 lo = mul128_fold64(a0 ^ sec64(11 + 16 * i), a1 ^ sec64(11 + 16 * i + 8));
-    u64 hi = mul128_fold64(a0 ^ sec64(117 + 16 * i), a1 ^ sec64(117 + 16 * i + 8));
-    lo += shfl_xor64(lo, 1);
-    lo += shfl_xor64(lo, 2);
-    hi += shfl_xor64(hi, 1);
-    hi += shfl_xor64(hi, 2);
-    H128 r;
-    r.lo = avalanche3(lo + len * P64_1);
-    r.hi = avalanche3(hi + ~(len * P64_2));
-    return r;
+    return hash_finish_wave(p, len, lane, a0, a1);
 }
 
 // grid: ceil(n / wavesPerBlock) blocks of 64*wavesPerBlock threads
@@ -262,7 +280,10 @@ __device__ __forceinline__ u64 quad_xor64(u64 v, int m) { // value of lane ^ m i
 }
 
 // One 16-lane row, one chunk of `len` > 240 bytes.  Every lane of the row returns the hash.
-__device__ inline H128 hash_long_row(const u8* __restrict__ p, u64 len, u32 lane) {
+// sums (or null): the eight 64-bit sums of every FULL 1 KiB block of the chunk (what the stripes of a block add to the
+// accumulators: 64 B per block, accumulator order), left by the scan of compress stage 1 (sq_zstd_fast.h): the blocks
+// are then not read at all, only the scramble chain and the tail run here.
+__device__ inline H128 hash_long_row(const u8* __restrict__ p, u64 len, u32 lane, const u64* __restrict__ sums = nullptr) {
     const u32 rl = lane & 15, g = rl >> 2, j = rl & 3, i0 = 2 * j;
     const u64 sc0 = sec64(128 + 8 * i0), sc1 = sec64(128 + 8 * i0 + 8);
     // secret words of the four stripes this lane owns (stripe s uses secret offset 8*s)
@@ -290,6 +311,27 @@ __device__ inline H128 hash_long_row(const u8* __restrict__ p, u64 len, u32 lane
         }
     };
     u64 b = 0;
+    if (sums) { // lane (g, j) takes pair j of every block (the four g of a row load the same 16 bytes)
+        const u8* const sp = (const u8*)sums + 16 * j;
+        auto step = [&](const uint4& v) {
+            a0 += ((u64)v.y << 32) | v.x;
+            a1 += ((u64)v.w << 32) | v.z;
+            a0 = (a0 ^ (a0 >> 47) ^ sc0) * P32_1;
+            a1 = (a1 ^ (a1 >> 47) ^ sc1) * P32_1;
+        };
+        for (; b + 8 <= nbBlocks; b += 8) {
+            uint4 v[8];
+#pragma unroll
+            for (int t = 0; t < 8; t++) __builtin_memcpy(&v[t], sp + ((b + t) << 6), 16);
+#pragma unroll
+            for (int t = 0; t < 8; t++) step(v[t]);
+        }
+        for (; b < nbBlocks; b++) {
+            uint4 v;
+            __builtin_memcpy(&v, sp + (b << 6), 16);
+            step(v);
+        }
+    }
     // two blocks (8 loads per lane) in flight
     for (; b + 2 <= nbBlocks; b += 2) {
         uint4 v[8];
@@ -339,12 +381,14 @@ __device__ inline H128 hash_long_row(const u8* __restrict__ p, u64 len, u32 lane
 // grid = ceil(n / (4 * waves per workgroup)), one row of 16 lanes per chunk
 __global__ void __launch_bounds__(256)
 k_xxh3_128_rows(const u8* __restrict__ data, const u64* __restrict__ off, const u32* __restrict__ len, u32 n,
-                u8* __restrict__ hashes) {
+                u8* __restrict__ hashes, const u8* __restrict__ summed, const u8* __restrict__ sums, u64 sums_stride) {
     const u32 lane = threadIdx.x & 63;
     const u32 c = (blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * 4 + (lane >> 4);
     // Rows are independent: the DPP rotations / quad permutes of hash_long_row only read lanes of the same
     // row (quad), and a row's 16 lanes always take the same path, so rows may diverge freely (other
     // lengths, the short path, no chunk at all).
+    // summed / sums (or null): summed[c] != 0 says that compress stage 1 has streamed chunk c and left the sums of
+    // its full blocks at sums + c * sums_stride (the fused form of a pack batch): those chunks are not read again
     const bool live = c < n;
     H128 h = {0, 0};
     if (live) {
@@ -353,7 +397,7 @@ k_xxh3_128_rows(const u8* __restrict__ data, const u64* __restrict__ off, const 
         if (L <= 240)
             h = hash_short(p, L);
         else
-            h = hash_long_row(p, L, lane);
+            h = hash_long_row(p, L, lane, (summed != nullptr && summed[c] != 0) ? (const u64*)(sums + (u64)c * sums_stride) : nullptr);
     }
     if (live && (lane & 15) == 0) {
         u64* o = (u64*)(hashes + 16ull * c);

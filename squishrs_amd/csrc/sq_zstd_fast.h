@@ -18,6 +18,9 @@
 // tables per wave) and keeps the certificate's table in HBM.
 #pragma once
 #include "sq_zstd_match.h"
+#if SQ_ON_DEVICE
+#include "sq_xxh3.h" // the fused hash: stage 1 computes XXH3-128 beside its scan (one read of the chunk instead of two)
+#endif
 #include <type_traits>
 #if !SQ_ON_DEVICE
 #include <algorithm>
@@ -48,6 +51,9 @@ namespace sqz {
 #endif
 #ifndef SQZ_FAST_DEPTH
 #define SQZ_FAST_DEPTH 5u // rounds of the scan's stream in flight per wave
+#endif
+#ifndef SQZ_FAST_DEPTH_HS
+#define SQZ_FAST_DEPTH_HS 4u // ... in the fused-hash form of the scan (register pressure: one round's 5 registers less)
 #endif
 #ifndef SQZ_FAST_WAVES_PER_SIMD
 #define SQZ_FAST_WAVES_PER_SIMD 4
@@ -80,9 +86,44 @@ SQ_DEV bool fw_static_for(F&& f) {
 #define FW_SH_IDX 5u    // the chunk index the workgroup pulled from the queue
 #define FW_SH_FIN 8u    // [FW_NW] position each wave's scan ended at
 #define FW_SH_SAMPLE 12u // [4] largest count of each 4 KiB sample of the HUF pre-check
+// (FW_SH_FLAGS bit 2 (4): some wave did not stream its whole run -- the fused hash is not available)
 
-// LDS of one workgroup of k_incompressible_batch (28.9 KB at four waves: the 4 workgroups = 16 waves per CU that the
-// 128 registers per lane allow use 116 of the CU's 160 KB)
+// The fused hash ("fused hash").  With a 16-byte aligned chunk a round of the scan IS one 1 KiB block of
+// XXH3's long path (lane l holds stripe l >> 2, accumulator pair l & 3: the layout of sqx::hash_long_wave), and a
+// block's contribution to the accumulators does not depend on them (acc[i] += mul(data ^ secret), acc[i ^ 1] += data;
+// only the scramble BETWEEN blocks is a recurrence).  So each round also computes its block's eight 64-bit sums
+// (2 per lane, reduced over the row's four stripes with two DPP rotations, over the four rows through LDS) and
+// every few rounds the wave stores them (64 B per block) to the chunk's slice of a pool in global memory.  The serial
+// part -- 255 scrambles per 256 KiB chunk, a few microseconds of dependent arithmetic -- is NOT done here (run by one
+// wave at the end of a chunk it held the workgroup's slot for a fifth of the chunk's time: stage 1 13.9 -> 18.4 ms):
+// sqx::k_xxh3_128_rows, launched behind this kernel, runs it for all chunks at once, 16 lanes per chunk, and adds the
+// tail of the long path.  Cost here: ~20 VALU instructions per round and 64 B written per KiB read; saved: the hash
+// kernel's read of every chunk.
+#define SQZ_FAST_HPOOL_BLOCKS 260u                           // 256 blocks + a dump area for the idle lanes of a flush
+#define SQZ_FAST_HPOOL_BYTES (SQZ_FAST_HPOOL_BLOCKS * 64u)   // per chunk
+
+// (a, b) += row_ror:4 (a, b); (a, b) += row_ror:8 (a, b) for two 64-bit values a = a1:a0, b = b1:b0 -- each lane ends
+// with the sum over the four lanes of its row that share its (lane & 3).  64-bit adds whose first operand comes
+// through DPP, two instructions each, in place (a row rotation reads its 16 lanes before it writes them; as C++ the
+// compiler spends five instructions per add: two DPP moves, their zeroed destinations, one 64-bit add).  The two chains
+// alternate, so no DPP instruction reads a register written less than three instructions before it (DPP hazard: 2 wait
+// states); the s_nop covers whatever VALU instruction wrote the inputs.
+#define SQZ_ROW_SUM4(a0, a1, b0, b1)                                                                   \
+    asm("s_nop 1\n\t"                                                                                  \
+        "v_add_co_u32_dpp %0, vcc, %0, %0 row_ror:4 row_mask:0xf bank_mask:0xf\n\t"                    \
+        "v_addc_co_u32_dpp %1, vcc, %1, %1, vcc row_ror:4 row_mask:0xf bank_mask:0xf\n\t"              \
+        "v_add_co_u32_dpp %2, vcc, %2, %2 row_ror:4 row_mask:0xf bank_mask:0xf\n\t"                    \
+        "v_addc_co_u32_dpp %3, vcc, %3, %3, vcc row_ror:4 row_mask:0xf bank_mask:0xf\n\t"              \
+        "v_add_co_u32_dpp %0, vcc, %0, %0 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"                    \
+        "v_addc_co_u32_dpp %1, vcc, %1, %1, vcc row_ror:8 row_mask:0xf bank_mask:0xf\n\t"              \
+        "v_add_co_u32_dpp %2, vcc, %2, %2 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"                    \
+        "v_addc_co_u32_dpp %3, vcc, %3, %3, vcc row_ror:8 row_mask:0xf bank_mask:0xf"                    \
+        : "+v"(a0), "+v"(a1), "+v"(b0), "+v"(b1)                                                         \
+        :                                                                                                \
+        : "vcc")
+
+// LDS of one workgroup of k_incompressible_batch (34.1 KB at four waves: the 4 workgroups = 16 waves per CU that the
+// 128 registers per lane allow use 137 of the CU's 160 KB)
 struct FastLds {
     u32 bloom[SQZ_BLOOM_WORDS];      // certificate Bloom filter; afterwards the 256-bin sample histograms (256 words per wave)
     u16 vals[SQZ_FAST_VALS];         // per scheduled position: bits 6..21 of its 4-byte value, grouped by bits 22..31
@@ -92,6 +133,8 @@ struct FastLds {
     u32 hits[2 * SQZ_FAST_HITS];     // (position, bytes) of scanned positions whose bytes equal a scheduled position's;
                                      // position 0 = two scheduled positions with equal bytes
     u32 sh[16];                      // words shared by the waves (FW_SH_*)
+    u32 hsec[256];                   // fused hash: lane l's two secret words (4 dwords at 4 l), the same for every chunk
+    u32 hstage[FW_NW * SQZ_FAST_DEPTH_HS * 64]; // fused hash: per wave and round of a loop step, the four rows' sums (4 x 64 B)
 #ifdef SQ_PROF
     unsigned long long prof[8]; // 100 MHz ticks: 0 build, 1 scan loop, 2 look-ups (inside 1), 3 hit resolution, 4 pre-check + frame, 5 whole chunk
 #endif
@@ -279,6 +322,7 @@ SQ_DEV void vbloom_add3(SQ_L u32* const B, u32 v) {
 // straddle the chunk start or the block boundary.
 SQ_DEV void cert_lds_core(CertCtx& cx, FastLds* L, u8* rawOut) {
     cx.rawEnd = SQZ_WINDOW_START;
+    cx.hashDone = 0;
     const u8* const base = cx.base;
     u32 const nCert = cx.nCert;
     u32 const blk1 = (nCert > cx.certCnt0) ? cx.base1Pos : 0xFFFFFFFFu;
@@ -297,7 +341,8 @@ SQ_DEV void cert_lds_core(CertCtx& cx, FastLds* L, u8* rawOut) {
     constexpr u32 NW = FW_NW, NT = 64 * FW_NW;
     constexpr u32 ITS_ALL = SQZ_FAST_VALS / 512;      // batches of 512 scheduled positions
     constexpr u32 ITS = (ITS_ALL + NW - 1) / NW;      // ... of which this wave takes numbers wv, wv + NW, ...
-    u64 const below = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+    // set bits of m below this lane (v_mbcnt: no per-lane mask register to keep alive through the scan)
+    auto rankIn = [&](u64 m) -> u32 { return __builtin_amdgcn_mbcnt_hi((u32)(m >> 32), __builtin_amdgcn_mbcnt_lo((u32)m, 0u)); };
     SQ_L u32* const cand = (SQ_L u32*)L->cand + 256 * wv;
     SQ_L u32* const sh = (SQ_L u32*)L->sh;
     for (u32 i = tid; i < SQZ_BLOOM_WORDS; i += NT) bloom[i] = 0;
@@ -337,7 +382,7 @@ SQ_DEV void cert_lds_core(CertCtx& cx, FastLds* L, u8* rawOut) {
         u32 at = 0;
         if (lane == 0) at = __hip_atomic_fetch_add(&sh[FW_SH_NHITS], cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         at = wv_uni(at);
-        u32 const slot = at + (u32)__popcll(m & below);
+        u32 const slot = at + rankIn(m);
         if (have && slot < SQZ_FAST_HITS) {
             hits[2 * slot] = p;
             hits[2 * slot + 1] = vp;
@@ -544,13 +589,17 @@ SQ_DEV void cert_lds_core(CertCtx& cx, FastLds* L, u8* rawOut) {
     const u8* const lastByte = base + cx.chunkEndPos - 1;
     const u8* const aLast = lastByte - ((size_t)lastByte & 15);
     bool const rawCopy = rawOut != nullptr && src0 == a0;
+    // the fused hash needs the whole chunk streamed (a scan that would stop at an early certificate end goes on:
+    // what it finds beyond that end changes nothing) and rounds that are XXH3 blocks (aligned chunk)
+    bool const hashOn = cx.hashPool != nullptr && src0 == a0 && !(cx.dbg & 2);
     auto scanStop = [&]() -> u32 {
         u32 const ce = (blk1 != 0xFFFFFFFFu) ? certEnd1 : certEnd;
-        return ce < pEnd ? ce : pEnd;
+        return (ce < pEnd && !hashOn) ? ce : pEnd;
     };
     // the rounds of 1 KiB from p0 up to the stop are dealt out in contiguous runs, one per wave
     u32 const nRounds = p0 < (s32)scanStop() ? ((u32)((s32)scanStop() - p0) + 1023u) >> 10 : 0u;
-    u32 const perWave = (nRounds + NW - 1) / NW;
+    // (fused hash: runs of a multiple of four rounds, so that only the last wave's last loop step can be short)
+    u32 const perWave = hashOn ? ((nRounds + NW - 1) / NW + SQZ_FAST_DEPTH_HS - 1) / SQZ_FAST_DEPTH_HS * SQZ_FAST_DEPTH_HS : (nRounds + NW - 1) / NW;
     auto runStart = [&](u32 w) -> s32 { return p0 + (s32)(1024u * (perWave * w < nRounds ? perWave * w : nRounds)); };
     s32 pos = runStart(wv);
     s32 const myStop = (runStart(wv + 1) < (s32)scanStop()) ? runStart(wv + 1) : (s32)scanStop();
@@ -576,7 +625,10 @@ SQ_DEV void cert_lds_core(CertCtx& cx, FastLds* L, u8* rawOut) {
         if constexpr (decltype(AL)::value) {
             bool const second = (blk1 != 0xFFFFFFFFu) && rp >= (s32)blk1;
             u32 const wi = (((u32)rp - (second ? blk1 : SQZ_WINDOW_START)) >> 4) + lane;
-            wl = sq_grd16((const u8*)(schedBits + (second ? SQZ_SCHEDBITS_N : 0u) + (wi < SQZ_SCHEDBITS_N ? wi : SQZ_SCHEDBITS_N - 1)));
+            // (a 4-byte load of the 2-byte word: the upper half -- the next window's word -- never reaches the result,
+            // the masks it is combined with have 16 bits; as a 2-byte load the value's zero extension became an
+            // instruction of its own that hipcc placed at the loop's back edge, behind a wait for ALL loads in flight)
+            wl = sq_grd32((const u8*)(schedBits + (second ? SQZ_SCHEDBITS_N : 0u) + (wi < SQZ_SCHEDBITS_N ? wi : SQZ_SCHEDBITS_N - 1)));
             return;
         }
         bool const second = (blk1 != 0xFFFFFFFFu) && rp >= (s32)blk1;
@@ -656,7 +708,16 @@ SQ_DEV void cert_lds_core(CertCtx& cx, FastLds* L, u8* rawOut) {
         return ok;
     };
     // one round: Bloom tests, scheduled positions removed, positives collected; false = list of hits full
-    auto round = [&](auto AL, sq_v4u w, sq_v4u wn, u32 wl) -> bool {
+    // fused hash: this lane's slot of the wave's staging area (rows of 64 B: lanes 0..3 of each row write)
+    SQ_L u32* const hstWave = (SQ_L u32*)L->hstage + wv * (SQZ_FAST_DEPTH_HS * 64u);
+    const SQ_L u32* const hsecLane = (const SQ_L u32*)L->hsec + 4 * lane;
+    // fused hash: the loop always runs whole steps of SQZ_FAST_DEPTH_HS rounds with ONE exit test per step (exits
+    // after single rounds made hipcc merge them with the loop's latch in a block of register copies of the stream
+    // loads in flight, i.e. a wait for all of them in every step).  Rounds beyond the wave's run, and all rounds
+    // once the filter part has given up (hsDead: the list of hits is full), only hash and copy.
+    bool hsDead = false;
+    auto round = [&](auto AL, auto HS, auto IR, sq_v4u w, sq_v4u wn, u32 wl) -> bool {
+        bool const active = !decltype(HS)::value || (!hsDead && pos < myStop);
         u32 wa = 0, wb = 0;
         if constexpr (!decltype(AL)::value) pickLevels(pos, wl, wa, wb);
         u32 d4;
@@ -681,11 +742,11 @@ SQ_DEV void cert_lds_core(CertCtx& cx, FastLds* L, u8* rawOut) {
 #else
                 sq_gwr128(rawOut + ((u32)pos - SQZ_WINDOW_START) + ((u32)pos >= blk1 ? 6u : 3u) + 16 * lane, w);
 #endif
-            okMask = 0xFFFFu;
+            okMask = active ? 0xFFFFu : 0u;
             if ((u32)pos + 1024 > stop) {
                 s32 l = (s32)stop - lo;
                 l = l < 0 ? 0 : (l > 16 ? 16 : l);
-                okMask = (1u << l) - 1u;
+                okMask &= (1u << l) - 1u;
             }
         } else {
             s32 f = (s32)SQZ_WINDOW_START - lo, l = (s32)stop - lo;
@@ -749,7 +810,7 @@ SQ_DEV void cert_lds_core(CertCtx& cx, FastLds* L, u8* rawOut) {
         } else
             cm &= ~schedMaskFast(lo, wa, wb);
         bool ok = true;
-        if (nCand == 0) pendFrom = pos; // nothing older than this round is waiting for its look-up
+        if (nCand == 0 && active) pendFrom = pos; // nothing older than this round is waiting for its look-up
         // compaction (one positive per lane and turn) into the list that collects the positives of several
         // rounds: a look-up is a chain of dependent LDS reads, paid once per 64 positives instead of once
         // per round
@@ -763,7 +824,7 @@ SQ_DEV void cert_lds_core(CertCtx& cx, FastLds* L, u8* rawOut) {
             if (cm) {
                 u32 const j = (u32)__builtin_ctz(cm);
                 cm &= cm - 1;
-                u32 const slot = nCand + (u32)__popcll(m & below);
+                u32 const slot = nCand + rankIn(m);
                 if (slot < 128) {
                     cand[2 * slot] = (u32)(lo + (s32)j);
                     cand[2 * slot + 1] = valAt(w, d4, j);
@@ -772,6 +833,25 @@ SQ_DEV void cert_lds_core(CertCtx& cx, FastLds* L, u8* rawOut) {
             nCand += (u32)__popcll(m);
         }
         wv_fence();
+        if constexpr (decltype(HS)::value) { // (here, after the compaction loop: the filter's 54 temporaries are dead)
+            // XXH3: the eight sums of this 1 KiB block (XXH3_accumulate_512 over its 16 stripes, without the
+            // accumulators): two per lane, then over the four stripes of the row
+            sq_v4u const ks = *(const SQ_L sq_v4u*)hsecLane;
+            u64 const d0 = ((u64)w.y << 32) | w.x, d1 = ((u64)w.w << 32) | w.z;
+            u64 const k0 = d0 ^ (((u64)ks.y << 32) | ks.x), k1 = d1 ^ (((u64)ks.w << 32) | ks.z);
+            u64 c0 = (u64)(u32)k0 * (u64)(u32)(k0 >> 32) + d1;
+            u64 c1 = (u64)(u32)k1 * (u64)(u32)(k1 >> 32) + d0;
+            u32 a0 = (u32)c0, a1 = (u32)(c0 >> 32), b0 = (u32)c1, b1 = (u32)(c1 >> 32);
+            SQZ_ROW_SUM4(a0, a1, b0, b1);
+            // lanes 0..3 of each row write the row's four pairs of sums: 64 B per row.  (The predicate and the slot's
+            // offset are recomputed each round -- four instructions -- rather than kept in registers through the
+            // loop, which is at its limit of 128 vector and ~100 scalar registers: hence the laundered lane number.)
+            u32 l2 = lane;
+            asm volatile("" : "+v"(l2));
+            if ((l2 & 12) == 0) {
+                *(SQ_L sq_v4u*)(hstWave + 64 * decltype(IR)::value + (((l2 & 0x30u) >> 2) | (l2 & 3u)) * 4) = (sq_v4u){a0, a1, b0, b1};
+            }
+        }
         if (nCand > 128) { // not with a working filter on random data: treat like a full list of hits
             ok = false;
             cx.nOvf = 1u | (nCand << 8);
@@ -782,11 +862,29 @@ SQ_DEV void cert_lds_core(CertCtx& cx, FastLds* L, u8* rawOut) {
     };
     FPROF_T0(t_scan);
     bool full = false, scanned = false;
-    auto scan = [&](auto AL) {
+    // fused hash: the sums of the (four) rounds of one loop step, staged in LDS as [round][row][pair] x 16 B = 1 KiB
+    // -> the pool.  Lane 16 q + 4 row + j reads its 16 bytes, the four rows of a round are added up with the same two
+    // DPP rotations as the stripes of a row, and the lanes of row 0 store round q's 64 bytes.  The other lanes (and the
+    // rounds a short last step did not run) store into the pool's dump area instead: nothing here is conditional, so no
+    // store is pending on one path only (hipcc would guard the stream loads of the next rounds conservatively).
+    u64* const hpool = cx.hashPool;
+    auto hflush = [&](u32 r, u32 blk0) {
+        static_assert(SQZ_FAST_DEPTH_HS == 4, "one lane per (round, row, pair) of a step");
+        wv_fence();
+        sq_v4u const v = *(const SQ_L sq_v4u*)(hstWave + 4 * lane);
+        u32 a0 = v.x, a1 = v.y, b0 = v.z, b1 = v.w;
+        SQZ_ROW_SUM4(a0, a1, b0, b1);
+        u32 const q = lane >> 4, j = lane & 3;
+        bool const live = q < r && (lane & 12) == 0;
+        u32 const blk = live ? blk0 + q : 256u + ((lane >> 2) & 3);
+        sq_gwr128((u8*)(hpool + 8 * blk + 2 * j), (sq_v4u){a0, a1, b0, b1});
+        wv_fence();
+    };
+    auto scan = [&](auto AL, auto HS) {
         scanned = true;
         // SQZ_FAST_DEPTH rounds of 1 KiB in flight per wave: w[i] is used by one round of the unrolled body and
         // loaded again right after it
-        constexpr u32 D = SQZ_FAST_DEPTH;
+        constexpr u32 D = decltype(HS)::value ? SQZ_FAST_DEPTH_HS : SQZ_FAST_DEPTH;
         sq_v4u w[D];
         u32 lv[D];
 #pragma unroll
@@ -799,33 +897,55 @@ SQ_DEV void cert_lds_core(CertCtx& cx, FastLds* L, u8* rawOut) {
             loadLevels(AL, pos + (s32)(1024 * (D - 1)), lv[D - 1]);
             // ONE look-up site for the D rounds below (inlined into each of them, the look-up code made
             // the loop several times the size of the instruction cache's share of a wave)
-            if (nCand >= SQZ_FAST_LOOKUP_BATCH && !lookUp(1)) {
-                cx.nOvf = 2u | (sh[FW_SH_NHITS] << 8);
-                full = true;
-                break;
-            }
-            // (a compile-time loop: the rotation w[i] / w[(i + 1) % D] must be register names, not indices)
-            bool const done = !fw_static_for<0, D>([&](auto I) -> bool {
-                constexpr u32 i = decltype(I)::value;
-                if (!round(AL, w[i], w[(i + 1) % D], lv[i])) {
+            if constexpr (decltype(HS)::value) {
+                if (!hsDead && nCand >= SQZ_FAST_LOOKUP_BATCH && !lookUp(1)) {
+                    cx.nOvf = 2u | (sh[FW_SH_NHITS] << 8);
+                    hsDead = true;
+                }
+                // (a compile-time loop: the rotation w[i] / w[(i + 1) % D] must be register names, not indices)
+                (void)fw_static_for<0, D>([&](auto I) -> bool {
+                    constexpr u32 i = decltype(I)::value;
+                    if (!round(AL, HS, I, w[i], w[(i + 1) % D], lv[i])) hsDead = true;
+                    if constexpr (i + 1 < D) {
+                        w[i] = loadRound(pos + (s32)(1024 * (D - 1)));
+                        loadLevels(AL, pos + (s32)(1024 * (D - 1)), lv[i]);
+                    }
+                    return true;
+                });
+                hflush(D, ((u32)(pos - p0) >> 10) - D); // the step's block sums (pos has advanced by 1 KiB per round)
+                if (pos >= myStop) break;
+            } else {
+                if (nCand >= SQZ_FAST_LOOKUP_BATCH && !lookUp(1)) {
+                    cx.nOvf = 2u | (sh[FW_SH_NHITS] << 8);
                     full = true;
-                    return false;
+                    break;
                 }
-                if (pos >= myStop) return false;
-                if constexpr (i + 1 < D) {
-                    w[i] = loadRound(pos + (s32)(1024 * (D - 1)));
-                    loadLevels(AL, pos + (s32)(1024 * (D - 1)), lv[i]);
-                }
-                return true;
-            });
-            if (done) break;
+                bool const done = !fw_static_for<0, D>([&](auto I) -> bool {
+                    constexpr u32 i = decltype(I)::value;
+                    if (!round(AL, HS, I, w[i], w[(i + 1) % D], lv[i])) {
+                        full = true;
+                        return false;
+                    }
+                    if (pos >= myStop) return false;
+                    if constexpr (i + 1 < D) {
+                        w[i] = loadRound(pos + (s32)(1024 * (D - 1)));
+                        loadLevels(AL, pos + (s32)(1024 * (D - 1)), lv[i]);
+                    }
+                    return true;
+                });
+                if (done) break;
+            }
         }
+        if constexpr (decltype(HS)::value) full = hsDead;
     };
     if (pos < myStop && !(cx.dbg & 2)) {
-        if (src0 == a0)
-            scan(std::true_type{});
-        else
-            scan(std::false_type{});
+        if (src0 == a0) {
+            if (hashOn)
+                scan(std::true_type{}, std::true_type{});
+            else
+                scan(std::true_type{}, std::false_type{});
+        } else
+            scan(std::false_type{}, std::false_type{});
     }
     if (scanned) {
         if (!full && !lookUp(1)) full = true; // the positives still waiting
@@ -837,7 +957,13 @@ SQ_DEV void cert_lds_core(CertCtx& cx, FastLds* L, u8* rawOut) {
         }
     }
     if (lane == 0) sh[FW_SH_FIN + wv] = (u32)pos;
+    // a wave that gave up before the end of its run leaves holes in the pool: no fused hash for this chunk
+    if (hashOn && pos < myStop && lane == 0) __hip_atomic_fetch_or(&sh[FW_SH_FLAGS], 4u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     fw_sync();
+    if (hashOn && !(sh[FW_SH_FLAGS] & 4u)) {
+        cx.hashDone = 1; // every full block's sums are in the pool: sqx::k_xxh3_128_rows runs the scramble chain over them
+        if (tid == 0) sq_gwr8(cx.hashedFlag, 1u);
+    }
     if (rawCopy) { // the chunk's prefix that is in place: the runs of the waves, up to the first one that stopped early
         s32 at = runStart(0);
         bool any = false;
@@ -934,8 +1060,9 @@ SQ_DEV void cert_lds_core(CertCtx& cx, FastLds* L, u8* rawOut) {
 // Returns the frame length when the chunk is decided here, 0 when it is left to k_compress_batch.
 // certOut[0..1]: the certificate ends for k_compress_batch (certOut[1] carries SQZ_CERT_HINT_VALID),
 // or 0, 0 when no certificate was computed.
+// hashPool / hashedFlag (device build, or null): the fused hash -- see SQZ_FAST_HPOOL_BLOCKS.
 SQ_DEV u32 fastpath_frame_wave(const u8* src, u32 n, u8* dst, u32 cap, u32* E, u32 genBits, const u32* schedTab,
-                                 FastLds* L, u32* certOut, u32 dbg = 0) {
+                                 FastLds* L, u32* certOut, u32 dbg = 0, u64* hashPool = nullptr, u8* hashedFlag = nullptr) {
     CParams const cp = get_cparams(n);
     u32 c0 = 0, c1 = 0;
     u32 frame = 0;
@@ -962,6 +1089,8 @@ SQ_DEV u32 fastpath_frame_wave(const u8* src, u32 n, u8* dst, u32 cap, u32* E, u
         cx.lvl = nullptr;
         cx.certEnd = cx.certEnd1 = 0;
         cx.nOvf = 0;
+        cx.hashPool = hashPool;
+        cx.hashedFlag = hashedFlag;
         if (cx.nCert > 0 && cx.nCert <= SQZ_FAST_VALS) {
             cx.dbg = dbg;
             u32 const nBlocks = len1 ? 2u : 1u;
@@ -1033,7 +1162,11 @@ SQ_DEV u32 fastpath_frame_wave(const u8* src, u32 n, u8* dst, u32 cap, u32* E, u
 __global__ void __launch_bounds__(64 * SQZ_FAST_WG_WAVES, SQZ_FAST_WAVES_PER_SIMD)
 k_incompressible_batch(const u8* data, const u64* off, const u32* len, const u8* select, u32 n, u8* slots,
                        const u64* slot_off, u32* frame_len, u32* cert_out, u8* etab_pool, u64 etab_bytes,
-                       u32* queue, const u32* schedTab, u32 dbg, u32 persist, u32* work) {
+                       u32* queue, const u32* schedTab, u32 dbg, u32 persist, u32* work, u8* hashed, u8* hpool) {
+    // hashed / hpool (both or none): the fused form -- the kernel runs BEFORE the dedup decision on every chunk of the
+    // batch (select == null) and, for each chunk it streams, leaves the sums of XXH3's full blocks in the chunk's slice
+    // of hpool (SQZ_FAST_HPOOL_BYTES each) and hashed[idx] = 1 (hashed[] zeroed by the host); sqx::k_xxh3_128_rows
+    // finishes those hashes and computes the others from the chunk bytes.
     // queue[1]: number of chunks decided here.  work: the chunks left to k_compress_batch, as two index
     // lists: [0] / [1] their lengths, then n slots for the "heavy" ones (certified in neither block: the
     // whole exact path) and n slots for the others.
@@ -1046,6 +1179,14 @@ k_incompressible_batch(const u8* data, const u64* off, const u32* len, const u8*
     // 0: the table holds unknown words; `persist`: the host vouches that the pool is as the previous
     // launch left it, so the saved counter is still true and the tags go on counting
     u32 gen = persist ? gld32(saved) : 0u;
+    if (threadIdx.x < 64) { // the secret words of XXH3's stripe loop as the scan's lanes need them
+        u32 const l = threadIdx.x;
+        u64 const k0 = sqx::sec64(8 * (l >> 2) + 16 * (l & 3)), k1 = sqx::sec64(8 * (l >> 2) + 16 * (l & 3) + 8);
+        lds.hsec[4 * l] = (u32)k0;
+        lds.hsec[4 * l + 1] = (u32)(k0 >> 32);
+        lds.hsec[4 * l + 2] = (u32)k1;
+        lds.hsec[4 * l + 3] = (u32)(k1 >> 32);
+    }
 #ifdef SQ_PROF
     if (first)
         for (int k = 0; k < 8; k++) lds.prof[k] = 0;
@@ -1067,7 +1208,8 @@ k_incompressible_batch(const u8* data, const u64* off, const u32* len, const u8*
             wv_mem_sync_inv(); // no L1 line from the previous chunk's table / data survives
             FPROF_T0(t_chunk);
             r = fastpath_frame_wave(data + off[idx], len[idx], slots + slot_off[idx], cap, E, gen << SQZ_HT_GEN_SHIFT,
-                                    schedTab, &lds, cert_out + 2 * (size_t)idx, dbg);
+                                    schedTab, &lds, cert_out + 2 * (size_t)idx, dbg,
+                                    hpool ? (u64*)(hpool + (u64)idx * SQZ_FAST_HPOOL_BYTES) : nullptr, hashed ? hashed + idx : nullptr);
             FPROF_ADD(&lds, 5, t_chunk);
         } else if (first) {
             cert_out[2 * (size_t)idx] = 0;

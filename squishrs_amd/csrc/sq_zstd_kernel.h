@@ -627,7 +627,9 @@ k_compress_batch(const u8* data, const u64* off, const u32* len, const u8* selec
             iter++;
             if (q >= count) break;
             u32 const idx = list ? gld32(list + q) : q;
-            bool const take = list || (select == nullptr) || (select[idx] != 0);
+            // (the lists hold what stage 1 left undecided: of the selected chunks in the split form, of ALL chunks in the
+            // fused form, where stage 1 runs before the dedup decision -- duplicates are skipped here)
+            bool const take = (select == nullptr) || (select[idx] != 0);
             PROF_T0(t_all);
 #ifdef SQ_PROF
             if (wv_lane() == 0)

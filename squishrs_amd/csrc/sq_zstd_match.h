@@ -982,6 +982,9 @@ struct CertCtx {
                          // the scheduled positions themselves out (their mutual repeats are found
                          // while the table is built)
     u32 rawEnd;          // stage 1 only: position up to which the scan has written the raw blocks' payload
+    u64* hashPool;       // stage 1 only, or null: the fused XXH3 -- where the scan puts the sums of every full 1 KiB block
+    u8* hashedFlag;      //   ... the byte that says they are all there
+    u32 hashDone;        // result: the sums are complete
     u32 dbg;             // timing experiments (SQ_FAST_DBG): 1 = no build, 2 = no scan, 8 = build without the exchange
 };
 
