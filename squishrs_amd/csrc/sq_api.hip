@@ -23,6 +23,7 @@
 struct sq_env {
     bool debug = false, debug_stats = false, hash_wave_per_chunk = false, no_fastpath = false;
     int stage1_wgs_per_cu = 0, stage2_waves_per_cu = 0, fast_dbg = 0;
+    bool s1_after_s2 = true; // SQ_S1_AFTER_S2=0: experiment switch of the launch order in pack_enqueue
     int stage1_grid = -1; // SQ_STAGE1_GRID: 1 = one workgroup per chunk instead of persistent workgroups (experiment)
     int fuse_hash = -1; // SQ_FUSE_HASH: 0 never, 1 always, unset: chosen per batch from the previous batch's duplicate ratio
     bool allow_any_arch = false;
@@ -42,6 +43,7 @@ static void sq_env_read() {
     if (const char* e = getenv("SQ_FAST_DBG")) g_env.fast_dbg = atoi(e);
     if (const char* e = getenv("SQ_FUSE_HASH")) g_env.fuse_hash = atoi(e) ? 1 : 0;
     if (const char* e = getenv("SQ_STAGE1_GRID")) g_env.stage1_grid = atoi(e);
+    if (const char* e = getenv("SQ_S1_AFTER_S2")) g_env.s1_after_s2 = atoi(e) != 0;
 }
 
 #define HIPCHK(x)                                                                                  \
@@ -97,6 +99,7 @@ struct sq_lane {
     bool own_stream = false;
     hipEvent_t ev[10] = {};
     hipEvent_t dedup_done = nullptr; // recorded after this lane's dedup kernels: the other lane's dedup waits for it
+    hipEvent_t pre_s2 = nullptr;     // recorded right before this lane's stage 2 is launched (fused form, see pack_enqueue)
     DevBuf b_off, b_len, b_slot_off, b_frame_len, b_out_off, b_isnew, b_hashes, b_stage_in,
         b_stage_out, b_slots, b_ws, b_misc, b_cert, b_etab, b_work, b_hashed, b_hpool;
     // shapes of the two table pools at the last launch that completed (persistent generation tags)
@@ -226,6 +229,7 @@ int sq_ctx_create(const sq_config* cfg_in, sq_ctx** out) {
                 return SQ_E_DEVICE;
             }
         if (hipEventCreateWithFlags(&L->dedup_done, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&L->pre_s2, hipEventDisableTiming) != hipSuccess ||
             hipHostMalloc(&L->h_pinned, 4096, hipHostMallocDefault) != hipSuccess) {
             sq_ctx_destroy(c);
             return SQ_E_NOMEM;
@@ -279,6 +283,7 @@ void sq_ctx_destroy(sq_ctx* c) {
         for (auto& e : L->ev)
             if (e) (void)hipEventDestroy(e);
         if (L->dedup_done) (void)hipEventDestroy(L->dedup_done);
+        if (L->pre_s2) (void)hipEventDestroy(L->pre_s2);
         if (L->own_stream && L->stream) (void)hipStreamDestroy(L->stream);
     }
     if (c->d_table) (void)hipFree(c->d_table);
@@ -913,6 +918,11 @@ static int pack_enqueue(sq_ctx* c, sq_lane* L, sq_lane* other, const u8* d_data,
     u64 const seen0 = (flags & 1u) ? 0 : c->n_seen;
     if (seen0 + n > c->key_capacity || seen0 + n >= 0xFFFFFFFFull) return SQ_E_CAP;
     if (L->job_fused) {
+        // Stage 1's persistent workgroups take every wave slot of the GPU the moment the previous batch's stage 1
+        // retires -- before that batch's stage 2 has even been launched (its hashes and dedup come first), which then
+        // runs alone AFTER this kernel.  Holding this launch back until the other lane's stage 2 is on its way lets
+        // stage 2's waves become resident first and this kernel fill the slots as they retire.
+        if (other && other->busy && other->job_fused && g_env.s1_after_s2) HIPCHK(hipStreamWaitEvent(L->stream, other->pre_s2, 0));
         if ((r = compress_stage1(c, L, d_data, nullptr, true))) return r;
         if ((r = launch_hash(c, L, d_data, n, d_hashes, (const u8*)L->b_hashed.p, (const u8*)L->b_hpool.p))) return r;
     } else if ((r = launch_hash(c, L, d_data, n, d_hashes))) // (does not depend on the batch before)
@@ -930,6 +940,7 @@ static int pack_enqueue(sq_ctx* c, sq_lane* L, sq_lane* other, const u8* d_data,
     if ((r = dedup_async(c, L, d_hashes, n, 0, n, d_isnew))) return r;
     HIPCHK(hipEventRecord(L->dedup_done, L->stream));
     if (!L->job_fused && (r = compress_stage1(c, L, d_data, d_isnew, false))) return r;
+    if (L->job_fused) HIPCHK(hipEventRecord(L->pre_s2, L->stream));
     return compress_stage2(c, L, d_data, d_isnew);
 }
 

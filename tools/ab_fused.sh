@@ -15,3 +15,6 @@ print(f"{sys.argv[1]}: step {d['ms_per_step']:.2f} ms whole-step frac {r['whole_
 PY
 }
 one split SQ_FUSE_HASH=0 && one fused SQ_FUSE_HASH=1
+one fused_noorder SQ_FUSE_HASH=1 SQ_S1_AFTER_S2=0
+one fused_s2w6 SQ_FUSE_HASH=1 SQ_STAGE2_WAVES_PER_CU=6
+one fused_s2w4 SQ_FUSE_HASH=1 SQ_STAGE2_WAVES_PER_CU=4
