@@ -206,6 +206,8 @@ typedef struct sq_timings {
     float hash_ms, dedup_ms, compress_ms, compact_ms;
     float fast_ms; /* incompressible-chunk kernel (stage 1 of the compress stage); compress_ms = stage 2 */
     uint32_t fast_decided; /* chunks whose frame stage 1 produced in the most recent compress stage */
+    uint32_t fused;        /* 1: the batch took the fused form (stage 1 before the dedup decision, computing the hashes'
+                              block sums; hash_ms is then the kernel that finishes them), 0: the split form */
 } sq_timings;
 int sq_last_timings(sq_ctx* ctx, sq_timings* out);
 

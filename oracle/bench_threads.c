@@ -100,6 +100,10 @@ typedef struct {
 typedef struct {
     const uint8_t* data;
     size_t n_chunks, chunk_len;
+    const uint64_t* off; /* ragged form (sqo_bench_pipeline2): chunk i = data + off[i], len[i]; NULL = uniform chunk_len */
+    const uint32_t* len;
+    uint32_t* out_len;    /* per chunk of the FIRST pass over the buffer: its frame's length ... */
+    uint8_t* out_digest;  /* ... and XXH3-128 (16 bytes): what bench.py compares with the GPU's frames */
     double t_end;
     uint64_t next_file; /* atomic */
     bp_shard shards[BP_SHARDS];
@@ -142,14 +146,16 @@ static int bp_shard_insert(bp_shard* s, uint64_t k0, uint64_t k1) { /* 1 = vacan
 
 static void* bp_worker(void* p) {
     bp_state* st = (bp_state*)p;
-    size_t const cap = sqo_compress_bound(st->chunk_len) + 64;
+    size_t const cap = sqo_compress_bound(st->chunk_len) + 64; /* (chunk_len = the longest chunk) */
     while (bt_now() < st->t_end) {
         uint64_t const f = __atomic_fetch_add(&st->next_file, 1, __ATOMIC_RELAXED);
-        const uint8_t* c = st->data + (size_t)(f % st->n_chunks) * st->chunk_len;
+        size_t const ci = (size_t)(f % st->n_chunks);
+        const uint8_t* c = st->off ? st->data + st->off[ci] : st->data + ci * st->chunk_len;
+        size_t const clen = st->len ? st->len[ci] : st->chunk_len;
         uint64_t const pass = f / st->n_chunks;
         uint8_t h[16];
         uint64_t k0, k1;
-        sqo_hash_chunk(c, st->chunk_len, h);
+        sqo_hash_chunk(c, clen, h);
         memcpy(&k0, h, 8);
         memcpy(&k1, h + 8, 8);
         k0 ^= pass * 0x9E3779B97F4A7C15ull; /* a later pass over the buffer = other files */
@@ -162,8 +168,12 @@ static void* bp_worker(void* p) {
             m = (bp_msg*)malloc(sizeof(bp_msg));
             uint8_t* fr = (uint8_t*)malloc(cap);
             if (m && fr) {
-                m->clen = sqo_compress_chunk(c, st->chunk_len, fr, cap);
+                m->clen = sqo_compress_chunk(c, clen, fr, cap);
                 m->frame = fr;
+                if (pass == 0 && st->out_len) { /* (outside the reference's work: a 16-byte hash of the frame) */
+                    st->out_len[ci] = (uint32_t)m->clen;
+                    sqo_hash_chunk(fr, (size_t)m->clen, st->out_digest + 16 * ci);
+                }
                 m->orig = SQO_CHUNK_SIZE; /* writer.rs:255: always the buffer size */
                 memcpy(m->hash, h, 16);
                 m->next = NULL;
@@ -219,8 +229,31 @@ static void* bp_writer(void* p) {
     return NULL;
 }
 
+static int bp_run(const uint8_t* data, const uint64_t* off, const uint32_t* len, size_t n_chunks, size_t chunk_len, unsigned threads,
+                  double seconds, uint64_t stats[4], uint32_t* out_len, uint8_t* out_digest);
+
 int sqo_bench_pipeline(const uint8_t* data, size_t n_chunks, size_t chunk_len, unsigned threads, double seconds,
                        uint64_t stats[4]) {
+    return bp_run(data, NULL, NULL, n_chunks, chunk_len, threads, seconds, stats, NULL, NULL);
+}
+
+/* The same pipeline over chunks of different lengths (chunk i = data + off[i], len[i] bytes: the 2 MiB chunks of
+ * large files and their ragged tails), which also reports, for every chunk its first pass over the buffer reached,
+ * the frame's length (0 = not reached or a duplicate) and the XXH3-128 of the frame.  bench.py compares these with
+ * the GPU's frames: every chunk the CPU baseline compresses is a parity check. */
+int sqo_bench_pipeline2(const uint8_t* data, const uint64_t* off, const uint32_t* len, size_t n_chunks, unsigned threads,
+                        double seconds, uint64_t stats[4], uint32_t* out_len, uint8_t* out_digest) {
+    if (!off || !len || !out_len || !out_digest) return -1;
+    size_t mx = 0;
+    for (size_t i = 0; i < n_chunks; i++) {
+        if (len[i] > mx) mx = len[i];
+        out_len[i] = 0;
+    }
+    return bp_run(data, off, len, n_chunks, mx, threads, seconds, stats, out_len, out_digest);
+}
+
+static int bp_run(const uint8_t* data, const uint64_t* off, const uint32_t* len, size_t n_chunks, size_t chunk_len, unsigned threads,
+                  double seconds, uint64_t stats[4], uint32_t* out_len, uint8_t* out_digest) {
     if (!data || !n_chunks || !threads || !stats) return -1;
     bp_state* st = (bp_state*)calloc(1, sizeof(bp_state));
     pthread_t* th = (pthread_t*)calloc(threads, sizeof(pthread_t));
@@ -229,6 +262,10 @@ int sqo_bench_pipeline(const uint8_t* data, size_t n_chunks, size_t chunk_len, u
     st->data = data;
     st->n_chunks = n_chunks;
     st->chunk_len = chunk_len;
+    st->off = off;
+    st->len = len;
+    st->out_len = out_len;
+    st->out_digest = out_digest;
     st->sink_cap = (size_t)256 << 20;
     st->sink = (uint8_t*)malloc(st->sink_cap);
     if (!st->sink) return -1;
@@ -255,4 +292,56 @@ int sqo_bench_pipeline(const uint8_t* data, size_t n_chunks, size_t chunk_len, u
     free(st);
     free(th);
     return 0;
+}
+
+/* ---------------------------------------------------------------------------------------------------------
+ * bench.py, configs[3] leg: decode-and-verify of frames the GPU produced, on `threads` host threads for at most
+ * `seconds`: frame k = frames + foff[k], flen[k] bytes must decode (zstd_dec_oracle.c, an RFC 8878 decoder written
+ * independently of the encoder) to exactly want_len[k] bytes whose XXH3-128 is want_hash + 16 k.  *done = frames
+ * verified; returns the number of frames that failed (0 = all good), -1 on bad arguments. */
+typedef struct {
+    const uint8_t* frames;
+    const uint64_t* foff;
+    const uint32_t *flen, *want_len;
+    const uint8_t* want_hash;
+    size_t n;
+    double t_end;
+    uint64_t next, done, bad;
+} dv_state;
+
+static void* dv_worker(void* p) {
+    dv_state* st = (dv_state*)p;
+    size_t const cap = SQO_CHUNK_SIZE + 64;
+    uint8_t* out = (uint8_t*)malloc(cap);
+    if (!out) return NULL;
+    while (bt_now() < st->t_end) {
+        uint64_t const k = __atomic_fetch_add(&st->next, 1, __ATOMIC_RELAXED);
+        if (k >= st->n) break;
+        uint8_t h[16];
+        size_t const got = sqo_decompress_frame(st->frames + st->foff[k], st->flen[k], out, cap);
+        int ok = got == (size_t)st->want_len[k];
+        if (ok) {
+            sqo_hash_chunk(out, got, h);
+            ok = memcmp(h, st->want_hash + 16 * k, 16) == 0;
+        }
+        if (!ok) __atomic_fetch_add(&st->bad, 1, __ATOMIC_RELAXED);
+        __atomic_fetch_add(&st->done, 1, __ATOMIC_RELAXED);
+    }
+    free(out);
+    return NULL;
+}
+
+int64_t sqo_bench_decode_verify(const uint8_t* frames, const uint64_t* foff, const uint32_t* flen, const uint32_t* want_len,
+                                const uint8_t* want_hash, size_t n, unsigned threads, double seconds, uint64_t* done) {
+    if (!frames || !foff || !flen || !want_len || !want_hash || !threads || !done) return -1;
+    dv_state st = {frames, foff, flen, want_len, want_hash, n, bt_now() + seconds, 0, 0, 0};
+    pthread_t* th = (pthread_t*)calloc(threads, sizeof(pthread_t));
+    if (!th) return -1;
+    unsigned started = 0;
+    for (; started < threads; started++)
+        if (pthread_create(&th[started], NULL, dv_worker, &st) != 0) break;
+    for (unsigned t = 0; t < started; t++) pthread_join(th[t], NULL);
+    free(th);
+    *done = st.done;
+    return (int64_t)st.bad;
 }

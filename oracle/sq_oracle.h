@@ -93,6 +93,13 @@ uint64_t sqo_bench_insert_threads(const uint8_t* data, size_t n_chunks, size_t c
 int sqo_bench_pipeline(const uint8_t* data, size_t n_chunks, size_t chunk_len, unsigned threads, double seconds,
                        uint64_t stats[4]);
 
+/* the same over chunks of different lengths, reporting (frame length, XXH3-128 of the frame) per chunk of the first
+ * pass; and a threaded decode-and-verify of frames (bench.py's parity checks of the configs[3] leg) */
+int sqo_bench_pipeline2(const uint8_t* data, const uint64_t* off, const uint32_t* len, size_t n_chunks, unsigned threads,
+                        double seconds, uint64_t stats[4], uint32_t* out_len, uint8_t* out_digest);
+int64_t sqo_bench_decode_verify(const uint8_t* frames, const uint64_t* foff, const uint32_t* flen, const uint32_t* want_len,
+                                const uint8_t* want_hash, size_t n, unsigned threads, double seconds, uint64_t* done);
+
 #ifdef __cplusplus
 }
 #endif

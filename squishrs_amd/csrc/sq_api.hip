@@ -110,7 +110,7 @@ struct sq_lane {
     size_t etab_bytes_last = 0;
     u32 etab_waves_last = 0;
     void* h_pinned = nullptr; // small pinned host mirror (error words etc.)
-    sq_timings last = {0, 0, 0, 0, 0, 0};
+    sq_timings last = {0, 0, 0, 0, 0, 0, 0};
     u32 work_n = 0; // chunks of the launch whose stage-2 work lists b_work holds (0: none)
     // a batch enqueued by sq_pack_submit and not yet collected by sq_pack_wait
     bool busy = false;
@@ -693,6 +693,7 @@ static int compress_finish(sq_ctx* c, sq_lane* L, u8* d_comp, u64 comp_cap, u64*
     HIPCHK(hipEventElapsedTime(&L->last.compress_ms, L->ev[4], L->ev[5]));
     if (fast) HIPCHK(hipEventElapsedTime(&L->last.fast_ms, L->ev[8], L->ev[9]));
     L->last.fast_decided = fast ? h_err[1] : 0;
+    L->last.fused = L->job_fused ? 1u : 0u;
     L->work_n = fast ? n : 0;
     if (!*h_err) { // both kernels ran to completion: their saved table states are good for the next launch
         L->ws_ptr_last = L->b_ws.p;

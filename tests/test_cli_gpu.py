@@ -69,6 +69,37 @@ def test_pack_tree_byte_identical_to_oracle(tmp_path, oracle):
     assert r.returncode == 0 and f"number_of_files: {len(files)}" in r.stdout
 
 
+def test_config0_1000_files_of_64k_random(tmp_path, oracle):
+    """BASELINE configs[0]'s shape through the product's own driver: 1,000 files x 65,536 random bytes in one directory
+    -> `squishrs pack` -> the archive equals the oracle's .squish restatement of the same files in manifest order
+    (every byte but the timestamp: preamble, 1,000 chunk records of 32 + 65,546 bytes, manifest), `list --simple`
+    reports the 1,000 files (/root/reference/tests/cli_tests.rs:55-80 checks that line), unpack restores them."""
+    tree = tmp_path / "c0"
+    tree.mkdir()
+    files = {}
+    for i in range(1000):
+        files["f%06d.bin" % i] = corpus.random_bytes(0, i, 65536)
+        (tree / ("f%06d.bin" % i)).write_bytes(files["f%06d.bin" % i])
+    out = tmp_path / "c0.squish"
+    r = _run("pack", str(tree), "-o", str(out))
+    assert r.returncode == 0, r.stderr
+    arch = out.read_bytes()
+    order = _manifest_order(arch)
+    assert sorted(order) == sorted(files)
+    exp = oracle.pack_archive([(rel, files[rel]) for rel in order], timestamp=0)
+    assert int.from_bytes(arch[19:27], "little") == 1000
+    assert len(arch) == 27 + 1000 * (32 + 65546) + 4 + sum(24 + len(rel) + 16 for rel in order)   # SURVEY 8(d) C0
+    assert arch[:11] == b"squish1.2.0" and arch[19:] == exp[19:], "archive differs from the oracle restatement"
+    r = _run("list", str(out), "--simple")
+    assert r.returncode == 0 and "number_of_files: 1000" in r.stdout
+    back = tmp_path / "back"
+    r = _run("unpack", str(out), "-o", str(back))
+    assert r.returncode == 0, r.stderr
+    for rel in ("f000000.bin", "f000499.bin", "f000999.bin"):
+        assert (back / rel).read_bytes() == files[rel]
+    assert sum(len(fs) for _, _, fs in os.walk(back)) == 1000
+
+
 def test_roundtrip_fixture_of_reference(tmp_path):
     # tests/roundtrip.rs: one file "file.txt" = "hello squish" -> the 124-byte archive of App. A
     fx = json.load(open(os.path.join(ROOT, "tests", "golden", "roundtrip_hello_squish.json")))

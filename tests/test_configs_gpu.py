@@ -406,6 +406,37 @@ def test_rowbatch_every_kind_and_size_vs_oracle(gpu_store, oracle):
     assert not bad, bad[:10]
 
 
+def _stage1_decides(c: bytes) -> bool:
+    """Model of k_incompressible_batch's decision (sq_zstd_fast.h header): the no-match certificate over the whole
+    predicted schedule + HUF's sampled pre-check.  (Planted chunks whose plant makes a search succeed fail it here as
+    they do on the device; this is the statement of the certificate, not of what libzstd finds.)"""
+    n = len(c)
+    if not (16384 < n <= 262144):
+        return False
+    len0 = min(n, 131072)
+    len1 = n - len0
+    if len0 < 40960 or (len1 and len1 < 40960):
+        return False
+    a = np.frombuffer(c, dtype=np.uint8)
+    v = (a[:-3].astype(np.uint32) | (a[1:-2].astype(np.uint32) << 8) | (a[2:-1].astype(np.uint32) << 16) | (a[3:].astype(np.uint32) << 24))
+    _, first, inv = np.unique(v, return_index=True, return_inverse=True)
+    first_of = first[inv]                        # first position that holds position p's 4 bytes
+    for s_ in corpus.lazy_schedule(n):
+        if first_of[s_] < s_:                    # an earlier position with the same 4 bytes
+            return False
+        if v[s_] == v[s_ + 1]:                   # the repcode test (offset 1) of the search at s fires
+            return False
+    for b0, bl in ((0, len0), (len0, len1)):
+        if bl == 0:
+            continue
+        blk = a[b0:b0 + bl]
+        l1 = np.bincount(blk[:4096], minlength=256).max()
+        l2 = np.bincount(blk[-4096:], minlength=256).max()
+        if l1 + l2 > ((2 * 4096) >> 7) + 4:
+            return False
+    return True
+
+
 def test_stage1_workgroup_edges_sizes_and_alignments(gpu_store, oracle):
     """Stage 1 (one chunk per workgroup of four waves, sq_zstd_fast.h): every way the work is dealt out.  Sizes at the
     strategy's and the path's boundaries (16 KiB + 1, 40,960 = the smallest block HUF's sampled pre-check accepts, one
@@ -444,8 +475,17 @@ def test_stage1_workgroup_edges_sizes_and_alignments(gpu_store, oracle):
         bad = [(i, len(c), starts[i] % 16) for i, c in enumerate(chunks)
                if host[int(coff[i]):int(coff[i + 1])].tobytes() != oracle.compress_chunk(c)]
         assert not bad, bad[:10]
+    # How many of them stage 1 decides is not a guess: a chunk is decided there iff it is of this strategy with blocks of
+    # >= 40,960 bytes, no scheduled search has an earlier position with its 4 bytes (or the offset-1 repcode test at
+    # it fires) and HUF's sampled pre-check calls each block uncompressible -- computed here from the bytes.  The
+    # planted chunks are built to be handed over (the ones that plant BESIDE a searched position may still certify).
+    model = [_stage1_decides(c) for c in chunks]
+    is_random = [(kinds[i % len(kinds)] == "random") or (kinds[i % len(kinds)].startswith("planted") and lens[i] < 20000) for i in range(160)]
+    lo = sum(1 for m, r in zip(model, is_random) if m and r)
+    hi = sum(1 for m in model if m)
     decided = gpu_store.timings().fast_decided
-    assert decided >= 20, f"stage 1 decided only {decided} of the random chunks"
+    assert lo <= decided <= hi, f"stage 1 decided {decided} chunks; the model says {lo} random ones (at most {hi} with planted ones that certify)"
+    assert lo >= 25
 
 
 def test_shard_split_form_two_batches_in_flight(oracle):
