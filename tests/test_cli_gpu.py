@@ -88,7 +88,7 @@ def test_config0_1000_files_of_64k_random(tmp_path, oracle):
     assert sorted(order) == sorted(files)
     exp = oracle.pack_archive([(rel, files[rel]) for rel in order], timestamp=0)
     assert int.from_bytes(arch[19:27], "little") == 1000
-    assert len(arch) == 27 + 1000 * (32 + 65546) + 4 + sum(24 + len(rel) + 16 for rel in order)
+    assert len(arch) == 27 + 1000 * (32 + 65546) + 4 + sum(4 + len(rel) + 8 + 4 + 16 for rel in order)
     assert arch[:11] == b"squish1.2.0" and arch[19:] == exp[19:], "archive differs from the oracle restatement"
     r = _run("list", str(out), "--simple")
     assert r.returncode == 0 and "number_of_files: 1000" in r.stdout
