@@ -146,7 +146,10 @@ uint64_t sq_slots_bound(const uint32_t* h_len, uint32_t n);
  *     frames left in their slots of d_comp (see sq_compress_batch_slots; SQ_E_CAP unless comp_cap >=
  *     sq_slots_bound(h_len, n)).  flags bit 0: empty the dedup set first (== sq_dedup_reset, ordered correctly
  *     behind the batch before).  Every in-flight batch needs its OWN hashes / is_new / comp buffers.
- *     SQ_E_INVAL when two batches are already in flight.
+ *     SQ_E_INVAL when two batches are already in flight.  Failure: every allocation, capacity and argument check of
+ *     the batch (SQ_E_NOMEM, SQ_E_CAP, SQ_E_INVAL) runs BEFORE the shared dedup set is touched -- such a failure commits
+ *     nothing (not even the reset of flags bit 0) and the batch may be submitted again; SQ_E_DEVICE (a HIP call failed
+ *     after the commit) leaves the batch's hashes in the set: call sq_dedup_reset before reusing the context.
  *     data / hashes / is_new / comp may also be HOST pointers (all four on the same side): the batch is then staged
  *     through the lane's device buffers -- one H2D copy on the lane's stream, which overlaps the other lane's
  *     kernels -- the frames are packed back to back on the device and sq_pack_wait copies hashes, flags and
@@ -172,9 +175,11 @@ int sq_pack_wait(sq_ctx* ctx, uint64_t* h_comp_off, uint32_t* h_comp_len);
  *     is then in flight exactly as after sq_pack_submit and is collected by sq_pack_wait.  d_all_hashes, d_is_new and
  *     d_comp must stay valid until then.  The reference's counterpart of the exchange is the one DashMap all Rayon
  *     workers share (src/util/chunk.rs:52-56,83).
- * SQ_E_INVAL: no lane free, or the calls out of order.  A failing sq_shard_submit_rest (SQ_E_CAP: dedup capacity or
- * comp_cap too small, both detected before anything is enqueued) commits nothing to the dedup set and consumes the
- * hash step: start the batch again with sq_shard_submit_hash. */
+ * SQ_E_INVAL: no lane free, or the calls out of order.  A failing sq_shard_submit_rest consumes the hash step (start
+ * the batch again with sq_shard_submit_hash).  SQ_E_CAP (dedup capacity or comp_cap too small), SQ_E_NOMEM and
+ * SQ_E_INVAL are detected before anything is enqueued and commit nothing -- neither the hashes nor the reset of flags
+ * bit 0 -- so this rank's replicated set stays equal to the other ranks'; SQ_E_DEVICE (a HIP call failed after the
+ * commit) leaves the set in an undefined relation to theirs: every rank must sq_dedup_reset. */
 int sq_shard_submit_hash(sq_ctx* ctx, const uint8_t* d_data, const uint64_t* h_off, const uint32_t* h_len, uint32_t n,
                          uint8_t* d_hashes);
 int sq_shard_wait_hash(sq_ctx* ctx);

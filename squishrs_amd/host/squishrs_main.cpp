@@ -216,7 +216,22 @@ static uint64_t pack(const std::string& input, const std::string& output, int de
     // the compressor runs one wave per chunk, a compressible 2 MiB chunk takes a wave the better part of a second,
     // so a small input must reach the GPU in one or two batches for its chunks to be compressed side by side (small inputs should not pay
     // for page-locking gigabytes they never fill)
-    uint64_t const eff_batch = std::max<uint64_t>(std::min<uint64_t>(batch_bytes, std::max<uint64_t>(total_bytes / 8 + SQ_CHUNK_SIZE, 256ull << 20)), 8u << 20);
+    uint64_t eff_batch = std::max<uint64_t>(std::min<uint64_t>(batch_bytes, std::max<uint64_t>(total_bytes / 8 + SQ_CHUNK_SIZE, 256ull << 20)), 8u << 20);
+    {   // ... and the four batches' input + output buffers (2 x 4 x eff_batch) within half of the memory the host has
+        // available (MemAvailable): a small machine packs a large tree in more, smaller batches instead of being
+        // killed for lack of memory
+        uint64_t avail = 0;
+        if (FILE* mi = fopen("/proc/meminfo", "r")) {
+            char line[256];
+            while (fgets(line, sizeof line, mi)) {
+                unsigned long long kb = 0;
+                if (sscanf(line, "MemAvailable: %llu kB", &kb) == 1) avail = (uint64_t)kb << 10;
+            }
+            fclose(mi);
+        }
+        if (avail && !getenv("SQUISH_BATCH_BYTES"))
+            while (eff_batch > (64ull << 20) && 8 * eff_batch > avail / 2) eff_batch /= 2;
+    }
     int const NB = 4; // reader: 1, gpu: 2 in flight (sq_pack_submit / sq_pack_wait), writer: 1
     Batch bt[4];
     {   // Page-locking costs ~0.2 s per GiB here and only pays when the GPU stage (two PCIe crossings) is the
@@ -281,8 +296,15 @@ static uint64_t pack(const std::string& input, const std::string& output, int de
                 std::atomic<size_t> next{0};
                 std::string rerr;
                 std::mutex rmu;
+                // bytes actually read per planned chunk.  The plan comes from the sizes stat() reported before packing;
+                // the reference reads every file to its END (process_file, writer.rs:233-246) and records the chunks it
+                // got.  A file that has SHRUNK since is therefore packed as what is there: the chunk that runs into the
+                // end is shortened, chunks beyond it are dropped (the manifest keeps metadata.len() as the reference's
+                // does, writer.rs:231,270).  A file that has GROWN is packed up to its planned size (divergence: the
+                // reference would read on).
+                std::vector<uint32_t> actual(pc.size(), 0);
                 auto work = [&]() {
-                    int fd = -1;
+                    int fd = -1, fd_errno = 0;
                     size_t cur = (size_t)-1;
                     for (;;) {
                         size_t const i = next.fetch_add(1);
@@ -291,19 +313,24 @@ static uint64_t pack(const std::string& input, const std::string& output, int de
                         if (c.file != cur) {
                             if (fd >= 0) close(fd);
                             fd = open(files[c.file].c_str(), O_RDONLY);
+                            fd_errno = fd < 0 ? errno : 0; // (captured at the failing call: other threads may set errno's meaning aside by then)
                             cur = c.file;
                         }
                         ssize_t got = 0;
+                        int rd_errno = 0;
+                        size_t done = 0;
                         if (fd >= 0)
-                            for (size_t done = 0; done < c.len; done += (size_t)got) {
+                            for (; done < c.len; done += (size_t)got) {
                                 got = pread(fd, b.data.p + c.pos + done, c.len - done, (off_t)(c.foff + done));
+                                if (got < 0) rd_errno = errno;
                                 if (got <= 0) break;
                             }
-                        if (fd < 0 || got <= 0) {
+                        if (fd < 0 || got < 0) {
                             std::lock_guard<std::mutex> lk(rmu);
-                            if (rerr.empty()) rerr = std::string("I/O error: ") + (fd < 0 || got < 0 ? strerror(errno) : "file changed while packing");
+                            if (rerr.empty()) rerr = std::string("I/O error: ") + strerror(fd < 0 ? fd_errno : rd_errno) + " (" + files[c.file] + ")";
                             break;
                         }
+                        actual[i] = (uint32_t)done; // < c.len: the file ends here now (0: it ends before this chunk)
                     }
                     if (fd >= 0) close(fd);
                 };
@@ -313,10 +340,11 @@ static uint64_t pack(const std::string& input, const std::string& output, int de
                 work();
                 for (auto& t : pool) t.join();
                 if (!rerr.empty()) throw AppError{rerr};
-                for (auto const& c : pc) {
-                    b.off.push_back(c.pos);
-                    b.len.push_back(c.len);
-                    b.owner.push_back(c.file);
+                for (size_t i = 0; i < pc.size(); i++) {
+                    if (actual[i] == 0) continue; // (only for a file that shrank: an empty read is the loop's end, writer.rs:241-245)
+                    b.off.push_back(pc[i].pos);
+                    b.len.push_back(actual[i]);
+                    b.owner.push_back(pc[i].file);
                 }
                 b.used = pc.empty() ? 0 : pc.back().pos + pc.back().len;
                 t_read += now_s() - tr0;

@@ -533,3 +533,45 @@ def test_shard_split_form_two_batches_in_flight(oracle):
             fr = comp[int(off[i]):int(off[i]) + int(ln[i])].cpu().numpy().tobytes()
             assert fr == (oracle.compress_chunk(chunks[i]) if isn[i] else b"")
     st.close()
+
+
+def test_empty_shard_batch_still_orders_the_shared_dedup_set(oracle):
+    """A rank may hold 0 chunks of a super-batch while the other ranks' hashes (n_total > 0) must be committed to its
+    replicated set: sq_shard_submit_rest queues that copy + insert on the lane, and sq_pack_wait of such an EMPTY batch
+    must not return before they ran -- the next batch (other lane) orders its own dedup only behind a lane that is
+    still busy.  Then: a reset batch behind it.  Flags against the first-occurrence model throughout."""
+    import torch
+    import squishrs_amd
+    L = 65536
+    base = [corpus.random_bytes(81, i, L) for i in range(48)]
+    st = squishrs_amd.ChunkStore(device=0, max_chunk=L, dedup_capacity=4096)
+    try:
+        d = torch.frombuffer(bytearray(b"".join(base)), dtype=torch.uint8).cuda()
+        offs = np.arange(48, dtype=np.uint64) * np.uint64(L)
+        lens = np.full(48, L, dtype=np.uint32)
+        others = torch.zeros(48 * 16, dtype=torch.uint8, device="cuda")
+        st.hash_device(d, offs, lens, others)                       # "the other ranks'" hashes
+        e_u8 = torch.zeros(16, dtype=torch.uint8, device="cuda")    # (non-null pointers for the empty batch)
+        none_o, none_l = np.zeros(0, dtype=np.uint64), np.zeros(0, dtype=np.uint32)
+        for rep in range(3):
+            # empty batch of this rank, 48 hashes of the others; reset first
+            st.shard_submit_hash(e_u8, none_o, none_l, e_u8)
+            st.shard_wait_hash()
+            st.shard_submit_rest(others, 48, 0, e_u8, e_u8, reset=True)
+            co, cl = st.pack_wait(0)
+            assert len(co) == 0
+            # the same chunks as an ordinary batch on the OTHER lane: every one a duplicate of what was just committed
+            h = torch.zeros(48 * 16, dtype=torch.uint8, device="cuda")
+            f = torch.ones(48, dtype=torch.uint8, device="cuda")
+            c = torch.empty(st.slots_bound(lens), dtype=torch.uint8, device="cuda")
+            st.pack_submit(d, offs, lens, h, f, c)
+            co, cl = st.pack_wait(48)
+            assert f.cpu().tolist() == [0] * 48 and (cl == 0).all(), rep
+            assert torch.equal(h, others) and st.len() == 48
+            # a reset batch behind it: first occurrences only
+            st.pack_submit(d[:8 * L], offs[:8], lens[:8], h[:128], f[:8], c, reset=True)
+            co, cl = st.pack_wait(8)
+            assert f[:8].cpu().tolist() == [1] * 8 and st.len() == 8
+            assert c[int(co[3]):int(co[3]) + int(cl[3])].cpu().numpy().tobytes() == oracle.compress_chunk(base[3])
+    finally:
+        st.close()

@@ -12,6 +12,19 @@ import tempfile
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+MAX_SPAN = 120  # lines between a group's first read and its wait (18 reads + 18 bit indices + a few address moves today)
+
+
+def _vregs(text):
+    """Every vector register an instruction names: single operands (v17) and the members of ranges (v[8:11], as in
+    dwordx2 / dwordx4 memory operations, 64-bit moves, packed math, MFMA / accvgpr moves)."""
+    t = text.split(";")[0]
+    out = set(re.findall(r"\bv\d+\b", t))
+    for a, b in re.findall(r"\bv\[(\d+):(\d+)\]", t):
+        out.update(f"v{k}" for k in range(int(a), int(b) + 1))
+    return out
+
+
 def scan(asm_text):
     lines = asm_text.split("\n")
     groups, hazards, i = 0, [], 0
@@ -25,11 +38,11 @@ def scan(asm_text):
                 elif t and not t.startswith(";") and not t.startswith("."):
                     if t.endswith(":") or t.startswith("s_cbranch") or t.startswith("s_branch") or t.startswith("s_endpgm"):
                         hazards.append((j + 1, "control flow between the reads and their wait: " + t))
-                    if any(o in regs for o in re.findall(r"\bv\d+\b", t)):
+                    if _vregs(t) & regs:
                         hazards.append((j + 1, t))
                 j += 1
-                if j >= len(lines):
-                    hazards.append((i + 1, "reads without a wait"))
+                if j >= len(lines) or j - i > MAX_SPAN:
+                    hazards.append((i + 1, f"reads without their s_waitcnt within {MAX_SPAN} lines"))
                     break
             if len(regs) != 18:
                 hazards.append((i + 1, f"a group of {len(regs)} reads (18 expected)"))
