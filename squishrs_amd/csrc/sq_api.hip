@@ -101,7 +101,7 @@ struct sq_lane {
     hipEvent_t dedup_done = nullptr; // recorded after this lane's dedup kernels: the other lane's dedup waits for it
     hipEvent_t pre_s2 = nullptr;     // recorded right before this lane's stage 2 is launched (fused form, see pack_enqueue)
     DevBuf b_off, b_len, b_slot_off, b_frame_len, b_out_off, b_isnew, b_hashes, b_stage_in,
-        b_stage_out, b_slots, b_ws, b_misc, b_cert, b_etab, b_work, b_hashed, b_hpool;
+        b_stage_out, b_slots, b_ws, b_misc, b_cert, b_etab, b_work, b_hashed, b_hpool, b_jobs, b_pair;
     // shapes of the two table pools at the last launch that completed (persistent generation tags)
     void* ws_ptr_last = nullptr;
     size_t ws_each_last = 0;
@@ -123,6 +123,8 @@ struct sq_lane {
     size_t job_ws_each = 0, job_etab_bytes = 0;
     bool job_fast = false, job_in_place = false, job_fused = false;
     u8* job_slots = nullptr;
+    std::vector<u32> job_list; // stage 1's jobs when the batch holds chunks of more than two blocks (one job per pair of blocks)
+    u32 job_count = 0;
     u32 job_ws_persist = 0, job_etab_persist = 0;
     // host-pointer batch of sq_pack_submit: where the results go at sq_pack_wait
     bool job_host = false;
@@ -276,7 +278,7 @@ void sq_ctx_destroy(sq_ctx* c) {
         if (L->stream) (void)hipStreamSynchronize(L->stream);
         for (DevBuf* b : {&L->b_off, &L->b_len, &L->b_slot_off, &L->b_frame_len, &L->b_out_off, &L->b_isnew,
                           &L->b_hashes, &L->b_stage_in, &L->b_stage_out, &L->b_slots, &L->b_ws, &L->b_misc, &L->b_cert, &L->b_etab, &L->b_work,
-                          &L->b_hashed, &L->b_hpool})
+                          &L->b_hashed, &L->b_hpool, &L->b_jobs, &L->b_pair})
             b->release();
         if (L->h_pinned) (void)hipHostFree(L->h_pinned);
         if (L->h_len_pinned) (void)hipHostFree(L->h_len_pinned);
@@ -519,7 +521,20 @@ static int compress_prepare(sq_ctx* c, sq_lane* L, const u32* h_len, u32 n, u8* 
         if (occ < 1) occ = 4;
         if (g_env.stage1_wgs_per_cu >= 1 && g_env.stage1_wgs_per_cu < occ) occ = g_env.stage1_wgs_per_cu; // experiment: leave room for another lane's kernels
         fwaves = c->cfg.compress_waves ? c->cfg.compress_waves * 2 : (u32)c->num_cu * (u32)occ;
-        fwaves = std::min(fwaves, n);
+        // Stage 1's jobs: a chunk of at most two blocks is one; a larger one (lazy2 class: the reference's 2 MiB chunks)
+        // is one per pair of its 128 KiB blocks (sq_zstd_fast.h fastpath_blocks).  The list only exists when needed.
+        L->job_list.clear();
+        L->job_count = n;
+        if (max_len > (256u << 10) && n < (1u << 28)) {
+            for (u32 i = 0; i < n; i++) {
+                u32 const nb = (h_len[i] + (128u << 10) - 1) / (128u << 10), np = nb > 2 ? (nb + 1) / 2 : 1u;
+                for (u32 p = 0; p < np; p++) L->job_list.push_back(i | (p << 28));
+            }
+            L->job_count = (u32)L->job_list.size();
+            if ((r = L->b_jobs.ensure((size_t)L->job_count * 4))) return r;
+            if ((r = L->b_pair.ensure((size_t)n * 4))) return r;
+        }
+        fwaves = std::min(fwaves, L->job_count);
         if (g_env.stage1_grid == 1) fwaves = n;
         if ((r = L->b_cert.ensure((size_t)n * 8))) return r;
         if ((r = L->b_work.ensure(((size_t)2 * n + 2) * 4))) return r;
@@ -559,6 +574,10 @@ static int compress_prepare(sq_ctx* c, sq_lane* L, const u32* h_len, u32 n, u8* 
     HIPCHK(hipMemcpyAsync(L->b_slot_off.p, slot_off.data(), ((size_t)n + 1) * 8, hipMemcpyHostToDevice, L->stream));
     HIPCHK(hipMemsetAsync(L->b_frame_len.p, 0, (size_t)n * 4, L->stream));
     if (fast) HIPCHK(hipMemsetAsync(L->b_work.p, 0, 8, L->stream));
+    if (fast && !L->job_list.empty()) {
+        HIPCHK(hipMemcpyAsync(L->b_jobs.p, L->job_list.data(), (size_t)L->job_count * 4, hipMemcpyHostToDevice, L->stream));
+        HIPCHK(hipMemsetAsync(L->b_pair.p, 0, (size_t)n * 4, L->stream));
+    }
     if (L->job_fused) HIPCHK(hipMemsetAsync(L->b_hashed.p, 0, (size_t)n, L->stream));
     HIPCHK(hipMemsetAsync(L->b_misc.p, 0, 256, L->stream));
     if (g_env.debug) {
@@ -588,7 +607,9 @@ static int compress_stage1(sq_ctx* c, sq_lane* L, const u8* d_data, const u8* d_
                        (const u64*)L->b_slot_off.p, (u32*)L->b_frame_len.p, (u32*)L->b_cert.p, (u8*)L->b_etab.p,
                        (u64)L->job_etab_bytes, (u32*)L->b_misc.p + 32 /*queue*/, (const u32*)c->d_sched_tab,
                        (u32)g_env.fast_dbg, L->job_etab_persist, (u32*)L->b_work.p,
-                       fused ? (u8*)L->b_hashed.p : (u8*)nullptr, fused ? (u8*)L->b_hpool.p : (u8*)nullptr);
+                       fused ? (u8*)L->b_hashed.p : (u8*)nullptr, fused ? (u8*)L->b_hpool.p : (u8*)nullptr,
+                       L->job_list.empty() ? (const u32*)nullptr : (const u32*)L->b_jobs.p, L->job_count,
+                       L->job_list.empty() ? (u32*)nullptr : (u32*)L->b_pair.p);
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(L->ev[9], L->stream));
     return SQ_OK;

@@ -168,6 +168,12 @@ SQ_DEV u32 fast_frame_header(u8* dst, u32 n) {
     return 5 + (fcsCode == 0 ? 1 : (fcsCode == 1 ? 2 : 4));
 }
 
+// the same from a workgroup: its first wave writes, every wave gets the size
+SQ_DEV u32 fast_frame_header_all(u8* dst, u32 n) {
+    if (fw_wave() == 0) return fast_frame_header(dst, n);
+    return 5 + (n < 256 ? 1u : (n < 65536 + 256 ? 2u : 4u));
+}
+
 #if defined(SQ_PROF) && SQ_ON_DEVICE
 #define FPROF_T0(v) unsigned long long v = __builtin_amdgcn_s_memrealtime()
 #define FPROF_ADD(L, slot, v)                                              \
@@ -286,9 +292,9 @@ SQ_DEV void cert_pos8(const CertCtx& cx, u32 i, u32 nCert, u32 (&sp)[8]) {
     for (u32 g = 0; g < 8; g++) {
         u32 const j = (i + 64 * g < nCert) ? i + 64 * g : nCert - 1;
         bool const first = j < cx.certCnt0;
-        u32 const slot = first ? j : SQZ_SCHEDTAB_N + cx.tabOff1 + (j - cx.certCnt0);
+        u32 const slot = first ? (cx.tab0 ? SQZ_SCHEDTAB_N : 0u) + j : SQZ_SCHEDTAB_N + cx.tabOff1 + (j - cx.certCnt0);
         t[g] = sq_gld32(cx.schedTab + 2 + slot);
-        ad[g] = first ? SQZ_WINDOW_START : cx.base1Pos;
+        ad[g] = first ? cx.base0Pos : cx.base1Pos;
     }
     // all eight words pass through one empty asm: nothing that uses one of them can be scheduled before
     // the last load has been issued
@@ -623,12 +629,16 @@ SQ_DEV void cert_lds_core(CertCtx& cx, FastLds* L, u8* rawOut) {
     const u16* const schedBits = (const u16*)(cx.schedTab + SQZ_SCHEDBITS_OFF);
     auto loadLevels = [&](auto AL, s32 rp, u32& wl) {
         if constexpr (decltype(AL)::value) {
+            // (rounds in front of the first certified block -- the earlier blocks of a large chunk, base0Pos > the
+            // chunk's start -- hold no scheduled position of THIS certificate: their word is loaded like any other, from
+            // a clamped index, and dropped in round())
             bool const second = (blk1 != 0xFFFFFFFFu) && rp >= (s32)blk1;
-            u32 const wi = (((u32)rp - (second ? blk1 : SQZ_WINDOW_START)) >> 4) + lane;
+            u32 const tabSel = second ? SQZ_SCHEDBITS_N : (cx.tab0 ? SQZ_SCHEDBITS_N : 0u);
+            u32 const wi = (((u32)rp - (second ? blk1 : cx.base0Pos)) >> 4) + lane;
             // (a 4-byte load of the 2-byte word: the upper half -- the next window's word -- never reaches the result,
             // the masks it is combined with have 16 bits; as a 2-byte load the value's zero extension became an
             // instruction of its own that hipcc placed at the loop's back edge, behind a wait for ALL loads in flight)
-            wl = sq_grd32((const u8*)(schedBits + (second ? SQZ_SCHEDBITS_N : 0u) + (wi < SQZ_SCHEDBITS_N ? wi : SQZ_SCHEDBITS_N - 1)));
+            wl = sq_grd32((const u8*)(schedBits + tabSel + (wi < SQZ_SCHEDBITS_N ? wi : SQZ_SCHEDBITS_N - 1)));
             return;
         }
         bool const second = (blk1 != 0xFFFFFFFFu) && rp >= (s32)blk1;
@@ -736,11 +746,13 @@ SQ_DEV void cert_lds_core(CertCtx& cx, FastLds* L, u8* rawOut) {
         if constexpr (decltype(AL)::value) {
             // aligned chunk: the round starts at or after the chunk start and lies in one block, so the
             // destination of the raw copy is a wave-uniform base plus 16 bytes per lane
-            if (rawCopy && (u32)lo + 16 <= cx.chunkEndPos) // (clamped loads beyond the end fail this test)
+            // (block b's payload sits 3 (b + 1) bytes behind its place in the chunk: every block but the last is full;
+            // of a large chunk only the certified blocks are copied, the ones in front belong to other workgroups)
+            if (rawCopy && (u32)pos >= cx.base0Pos && (u32)lo + 16 <= cx.chunkEndPos) // (clamped loads beyond the end fail this test)
 #if SQZ_FAST_NT & 2
-                sq_gwr128_nt(rawOut + ((u32)pos - SQZ_WINDOW_START) + ((u32)pos >= blk1 ? 6u : 3u) + 16 * lane, w);
+                sq_gwr128_nt(rawOut + ((u32)pos - SQZ_WINDOW_START) + 3u * ((((u32)pos - SQZ_WINDOW_START) >> 17) + 1u) + 16 * lane, w);
 #else
-                sq_gwr128(rawOut + ((u32)pos - SQZ_WINDOW_START) + ((u32)pos >= blk1 ? 6u : 3u) + 16 * lane, w);
+                sq_gwr128(rawOut + ((u32)pos - SQZ_WINDOW_START) + 3u * ((((u32)pos - SQZ_WINDOW_START) >> 17) + 1u) + 16 * lane, w);
 #endif
             okMask = active ? 0xFFFFu : 0u;
             if ((u32)pos + 1024 > stop) {
@@ -799,8 +811,8 @@ SQ_DEV void cert_lds_core(CertCtx& cx, FastLds* L, u8* rawOut) {
             // the window's bitmap word; a block's searches stop 8 bytes before its end (a short last block
             // uses a prefix of the table)
             bool const second = (blk1 != 0xFFFFFFFFu) && pos >= (s32)blk1;
-            u32 const lim = ((!second && blk1 != 0xFFFFFFFFu) ? blk1 : cx.chunkEndPos) - 8;
-            u32 sm = wl;
+            u32 const lim = ((!second && blk1 != 0xFFFFFFFFu) ? blk1 : cx.chunkEndPos) - cx.tail;
+            u32 sm = (u32)pos >= cx.base0Pos ? wl : 0u;
             if ((u32)pos + 1024 > lim) {
                 s32 nb = (s32)lim - lo;
                 nb = nb < 0 ? 0 : (nb > 16 ? 16 : nb);
@@ -989,22 +1001,25 @@ SQ_DEV void cert_lds_core(CertCtx& cx, FastLds* L, u8* rawOut) {
         u32 const hp = have ? hits[2 * lane] : 0u, hv = have ? hits[2 * lane + 1] : 0u;
         u32 const k = hv >> 22, tag = (hv >> 6) & 0xFFFFu;
         u32 const lo = (have && k) ? fast_get16(ends, k - 1) : 0u, hi = have ? fast_get16(ends, k) : 0u;
-        auto posOf = [&](u32 i) -> u32 { // as cert_pos8
-            bool const first = i < cx.certCnt0;
-            u32 const slot = first ? i : SQZ_SCHEDTAB_N + cx.tabOff1 + (i - cx.certCnt0);
-            return sq_gld32(cx.schedTab + 2 + slot) + (first ? SQZ_WINDOW_START : cx.base1Pos);
+        auto posOf = [&](u32 i) -> u32 { return cert_pos_g(cx, i); }; // as cert_pos8
+        // does an earlier position p with the 4 bytes of the search at s let that search succeed?  btlazy2: always (the
+        // tree may reach it).  Row-hash finder (lazy2, minMatch 5): only from the row and with the tag of the search's
+        // 5-byte hash -- two positions that share 4 bytes but not the fifth meet there only by a hash collision
+        auto reaches = [&](u32 p, u32 s_) -> bool {
+            if (cx.hashBits == 0) return true;
+            return hash5(sq_grd64(base + p), cx.hashBits) == hash5(sq_grd64(base + s_), cx.hashBits);
         };
         u32 v0 = 0xFFFFFFFFu, v1 = 0xFFFFFFFFu;
         for (u32 a = lo; a < hi; a++) { // (a bucket holds 3.4 values on average, SQZ_FAST_BUCKET_MAX at most)
             if (vals[a] != tag) continue;
             u32 const sa = posOf(idxs[a]), va = sq_grd32(base + sa);
             if (hp != 0) { // a scanned position p with the bytes hv: every scheduled s > p with those bytes
-                if (va == hv && sa > hp) note(sa, v0, v1);
+                if (va == hv && sa > hp && reaches(hp, sa)) note(sa, v0, v1);
             } else { // two scheduled positions share bits 6..31: of two with equal bytes, the later search can succeed
                 for (u32 b = a + 1; b < hi; b++) {
                     if (vals[b] != tag) continue;
                     u32 const sb = posOf(idxs[b]), vb = sq_grd32(base + sb);
-                    if (va == vb) note(sa > sb ? sa : sb, v0, v1);
+                    if (va == vb && reaches(sa < sb ? sa : sb, sa > sb ? sa : sb)) note(sa > sb ? sa : sb, v0, v1);
                 }
             }
         }
@@ -1025,24 +1040,34 @@ SQ_DEV void cert_lds_core(CertCtx& cx, FastLds* L, u8* rawOut) {
         else
             certEnd1 = sviol < certEnd1 ? sviol : certEnd1;
     };
-    // scheduled positions as a bitmap, through the same arithmetic the device uses
-    static thread_local u8 isSched[(256u << 10) + 64];
-    memset(isSched, 0, sizeof(isSched));
-    for (s32 lo = 0; lo < (s32)cx.chunkEndPos; lo += 16) {
-        u32 const m = fast_sched_mask(lvlWords, lo, blk1, cx.chunkEndPos, 0, 0, false);
-        for (u32 j = 0; j < 16; j++)
-            if ((m >> j) & 1) isSched[lo + j] = 1;
-    }
+    // scheduled positions as a bitmap: for a chunk of at most two blocks through the same arithmetic the device uses,
+    // for the last two blocks of a larger one (base0Pos beyond the chunk's start: the device takes the schedule's
+    // bitmap table there) from the schedule tables themselves
+    static thread_local u8 isSched[(2048u << 10) + 64];
+    memset(isSched, 0, cx.chunkEndPos + 32);
+    bool const general = cx.base0Pos != SQZ_WINDOW_START || cx.tab0 != 0 || cx.tail != 8;
+    if (general)
+        for (u32 i = 0; i < nCert; i++) isSched[cert_pos_g(cx, i)] = 1;
+    else
+        for (s32 lo = 0; lo < (s32)cx.chunkEndPos; lo += 16) {
+            u32 const m = fast_sched_mask(lvlWords, lo, blk1, cx.chunkEndPos, 0, 0, false);
+            for (u32 j = 0; j < 16; j++)
+                if ((m >> j) & 1) isSched[lo + j] = 1;
+        }
+    auto reaches = [&](u32 p, u32 s_) -> bool { // (see the device twin)
+        return cx.hashBits == 0 || hash5(sq_rd64(base + p), cx.hashBits) == hash5(sq_rd64(base + s_), cx.hashBits);
+    };
     // (value, position) of every scheduled search, sorted by value then position
     std::vector<std::pair<u32, u32>> sv(nCert);
     for (u32 i = 0; i < nCert; i++) {
-        u32 const sp = cert_pos_c(cx, i);
+        u32 const sp = cert_pos_g(cx, i);
         sv[i] = std::make_pair(sq_rd32(base + sp), sp);
         if (cx.repOff && sq_rd32(base + sp + 1) == sq_rd32(base + sp + 1 - cx.repOff)) note(sp);
     }
     std::sort(sv.begin(), sv.end());
     for (u32 i = 1; i < nCert; i++) // an earlier scheduled position with the same bytes
-        if (sv[i].first == sv[i - 1].first) note(sv[i].second);
+        for (u32 j = i; j-- > 0 && sv[j].first == sv[i].first;)
+            if (reaches(sv[j].second, sv[i].second)) note(sv[i].second);
     // every scheduled position must be one the arithmetic knows (else the scan would skip a wrong set)
     for (u32 i = 0; i < nCert; i++)
         if (!isSched[sv[i].second]) certEnd = certEnd1 = SQZ_WINDOW_START;
@@ -1050,103 +1075,153 @@ SQ_DEV void cert_lds_core(CertCtx& cx, FastLds* L, u8* rawOut) {
         if (isSched[p]) continue;
         u32 const vp = sq_rd32(base + p);
         auto it = std::lower_bound(sv.begin(), sv.end(), std::make_pair(vp, p + 1));
-        for (; it != sv.end() && it->first == vp; ++it) note(it->second); // scheduled positions beyond p with these bytes
+        for (; it != sv.end() && it->first == vp; ++it) // scheduled positions beyond p with these bytes
+            if (reaches(p, it->second)) note(it->second);
     }
 #endif
     cx.certEnd = certEnd;
     cx.certEnd1 = (blk1 != 0xFFFFFFFFu) ? certEnd1 : 0u;
 }
 
+// Blocks bA (even) and bA + 1 of a chunk of n bytes: the no-match certificate over their searches, with every earlier
+// position of the chunk scanned; HUF's sampled pre-check of the two blocks; and, when both say "raw block", the two
+// blocks' headers and payload in their place of the frame at dst (the frame header is the caller's).  Returns 1 then,
+// 0 when at least one of the two blocks is not known to be raw.  *e0 / *e1: the certificate ends (positions).
+//   n <= 256 KiB (btlazy2): bA = 0, the whole chunk -- what this path was built for.
+//   n  > 256 KiB (lazy2 + row-hash finder, /root/reference/src/util/chunk.rs:11: the reference's own 2 MiB chunks):
+//     one call per pair of blocks (the set S of a pair fills the workgroup's LDS), each scanning the chunk from its start
+//     to the pair's end -- 4.5 passes over a 2 MiB chunk in total.  What differs from btlazy2: searches stop 16 bytes
+//     before a block's end (the finder's hash cache), and an earlier position with a search's 4 bytes only matters when
+//     it shares the search's row and tag, i.e. the (hashLog + 2)-bit hash of its FIVE bytes (minMatch 5): on random
+//     data that is what makes the certificate hold at all (a 2 MiB chunk has ~6 four-byte coincidences at searched
+//     positions, 0.03 five-byte ones).  Blocks: 128 KiB each while every block so far was emitted raw -- libzstd's
+//     pre-block splitter only acts once `savings >= 3`, and a raw block contributes -3 (ZSTD_optimalBlockSize).
+SQ_DEV u32 fastpath_blocks(const u8* src, u32 n, u8* dst, u32 cap, u32 bA, const CParams& cp, const u32* schedTab, FastLds* L,
+                           u32* e0, u32* e1, u32 dbg, u64* hashPool, u8* hashedFlag) {
+    constexpr u32 BS = SQZ_BLOCKSIZE_MAX;
+    bool const row = cp.strategy == STRAT_LAZY2;
+    u32 const nBlocksAll = (n + BS - 1) / BS;
+    u32 const vEnd = n < (bA + 2) * BS ? n : (bA + 2) * BS; // the part of the chunk this call looks at
+    u32 const offA = bA * BS;
+    u32 const lenA = vEnd - offA < BS ? vEnd - offA : BS, lenB = vEnd - offA - lenA;
+    u32 const tail = row ? 16u : 8u;
+    *e0 = *e1 = 0;
+    if (row && ((size_t)src & 15)) return 0; // (the general form of the scan takes the schedule's bitmap: aligned chunks)
+    CertCtx cx;
+    cx.base = src - SQZ_WINDOW_START;
+    cx.E = nullptr;
+    cx.eLog = cp.chainLog - 1;
+    cx.genBits = 0;
+    cx.schedTab = schedTab;
+    cx.base0Pos = SQZ_WINDOW_START + offA;
+    cx.tab0 = bA ? 1u : 0u;
+    cx.tail = tail;
+    cx.hashBits = row ? cp.hashLog + 2 : 0u; // rowHashLog + 8 tag bits = (hashLog - 6) + 8
+    u32 const full0 = gld32(schedTab), full1 = gld32(schedTab + 1);
+    const u32* const tabA = schedTab + 2 + (cx.tab0 ? SQZ_SCHEDTAB_N : 0u);
+    u32 const fullA = cx.tab0 ? full1 : full0;
+    cx.certCnt0 = (lenA <= tail) ? 0u : (lenA == BS && tail == 8) ? fullA : sched_count(tabA, fullA, lenA - tail);
+    u32 const cnt1 = (lenB <= tail) ? 0u : (lenB == BS && tail == 8) ? full1 : sched_count(schedTab + 2 + SQZ_SCHEDTAB_N, full1, lenB - tail);
+    cx.nCert = cx.certCnt0 + cnt1;
+    cx.base1Pos = cx.base0Pos + BS;
+    cx.tabOff1 = 0;
+    cx.repOff = 1;
+    cx.chunkEndPos = vEnd + SQZ_WINDOW_START;
+    cx.bloom = nullptr;
+    cx.cand = nullptr;
+    cx.ovf = nullptr;
+    cx.lvl = nullptr;
+    cx.certEnd = cx.certEnd1 = 0;
+    cx.nOvf = 0;
+    cx.hashPool = hashPool;
+    cx.hashedFlag = hashedFlag;
+    cx.hashDone = 0;
+    if (cx.nCert == 0 || cx.nCert > SQZ_FAST_VALS || lenA < 9) return 0;
+    cx.dbg = dbg;
+    u32 const nB = lenB ? 2u : 1u;
+    bool const sized = lenA >= SQZ_FAST_MIN_BLOCK && (lenB == 0 || lenB >= SQZ_FAST_MIN_BLOCK);
+    u32 const hdr = 5 + (n < 256 ? 1u : (n < 65536 + 256 ? 2u : 4u)); // = fast_frame_header()
+    bool const room = cap >= n + hdr + 3 * nBlocksAll;
+    cert_lds_core(cx, L, (sized && room && !(dbg & 4)) ? dst + hdr : nullptr);
+    FPROF_T0(t_frame);
+    *e0 = (dbg & 64) ? cx.nOvf : cx.certEnd; // (64: bring-up, why the scan gave up)
+    *e1 = cx.certEnd1;
+    // every search of the two blocks certainly fails?
+    bool whole = cx.certEnd >= cx.base0Pos + lenA - tail;
+    if (lenB) whole = whole && (cx.certEnd1 >= cx.base1Pos + lenB - tail);
+    if (dbg & 4) whole = false; // timing experiment: certificate only
+    u32 ok = 0;
+    if (whole && sized && room) {
+        // HUF's sampled pre-check: the 4 KiB samples (first and last of each block) are dealt out to the
+        // waves; largest1 + largest2 of a block are added up through LDS
+        u32 const wv = fw_wave();
+        u32 const nSamples = 2 * nB;
+        for (u32 j = wv; j < nSamples; j += FW_NW) {
+            u32 const b = j >> 1, bs = b ? lenB : lenA;
+            const u8* const at = src + offA + (b ? lenA : 0u) + ((j & 1) ? bs - 4096 : 0u);
+            u32 l = 0, dummy;
+            wv_zero_lds(L->bloom + 256 * wv, 256);
+            wv_hist_bytes(L->bloom + 256 * wv, at, 4096);
+            wv_max_and_last(L->bloom + 256 * wv, 256, &l, &dummy);
+            WV_SERIAL L->sh[FW_SH_SAMPLE + j] = l;
+        }
+        fw_sync();
+        ok = 1; // (every wave reads the same four words)
+        for (u32 b = 0; b < nB; b++)
+            if (L->sh[FW_SH_SAMPLE + 2 * b] + L->sh[FW_SH_SAMPLE + 2 * b + 1] > ((2 * 4096) >> 7) + 4) ok = 0;
+        if (ok) {
+            u32 const done = cx.rawEnd - SQZ_WINDOW_START; // chunk bytes the scan has already put in place
+            for (u32 b = 0; b < nB; b++) {
+                u32 const bs = b ? lenB : lenA, b0 = offA + (b ? lenA : 0u), blk = bA + b;
+                u8* const op = dst + hdr + (size_t)blk * (3u + BS);
+                if (b % FW_NW == wv) {
+                    u32 const h = ((blk + 1 == nBlocksAll) ? 1u : 0u) + (0u << 1) + (bs << 3); // ZSTD_noCompressBlock
+                    WV_SERIAL {
+                        op[0] = (u8)h;
+                        op[1] = (u8)(h >> 8);
+                        op[2] = (u8)(h >> 16);
+                    }
+                    u32 const have = done > b0 ? (done - b0 < bs ? done - b0 : bs) : 0u;
+                    if (have < bs) wv_memcpy(op + 3 + have, src + b0 + have, bs - have);
+                }
+            }
+        }
+    }
+    FPROF_ADD(L, 4, t_frame);
+    return ok;
+}
+
 // Returns the frame length when the chunk is decided here, 0 when it is left to k_compress_batch.
 // certOut[0..1]: the certificate ends for k_compress_batch (certOut[1] carries SQZ_CERT_HINT_VALID),
 // or 0, 0 when no certificate was computed.
 // hashPool / hashedFlag (device build, or null): the fused hash -- see SQZ_FAST_HPOOL_BLOCKS.
+// (One call does the whole chunk: all pairs of blocks of a chunk above 256 KiB one after the other -- the form of the
+// simulator build.  The kernel below deals the pairs out as jobs of their own and calls fastpath_blocks itself, at ONE
+// call site: the scan is three instantiations of a long loop, inlined twice it no longer fits the instruction cache.)
+#if !SQ_ON_DEVICE
 SQ_DEV u32 fastpath_frame_wave(const u8* src, u32 n, u8* dst, u32 cap, u32* E, u32 genBits, const u32* schedTab,
                                  FastLds* L, u32* certOut, u32 dbg = 0, u64* hashPool = nullptr, u8* hashedFlag = nullptr) {
+    (void)E; (void)genBits;
     CParams const cp = get_cparams(n);
     u32 c0 = 0, c1 = 0;
     u32 frame = 0;
+    u32 const nBlocks = (n + SQZ_BLOCKSIZE_MAX - 1) / SQZ_BLOCKSIZE_MAX;
     if (cp.strategy == STRAT_BTLAZY2 && n >= 9) {
-        u32 const len0 = n < SQZ_BLOCKSIZE_MAX ? n : SQZ_BLOCKSIZE_MAX;
-        u32 const len1 = n - len0;
-        CertCtx cx;
-        cx.base = src - SQZ_WINDOW_START;
-        cx.E = E;
-        cx.eLog = cp.chainLog - 1;
-        cx.genBits = genBits;
-        cx.schedTab = schedTab;
-        u32 const full0 = gld32(schedTab), full1 = gld32(schedTab + 1);
-        cx.certCnt0 = (len0 == SQZ_BLOCKSIZE_MAX) ? full0 : sched_count(schedTab + 2, full0, len0 - 8);
-        u32 const cnt1 = (len1 < 9) ? 0u : (len1 == SQZ_BLOCKSIZE_MAX) ? full1 : sched_count(schedTab + 2 + SQZ_SCHEDTAB_N, full1, len1 - 8);
-        cx.nCert = cx.certCnt0 + cnt1;
-        cx.base1Pos = SQZ_WINDOW_START + SQZ_BLOCKSIZE_MAX;
-        cx.tabOff1 = 0;
-        cx.repOff = 1;
-        cx.chunkEndPos = n + SQZ_WINDOW_START;
-        cx.bloom = nullptr;
-        cx.cand = nullptr;
-        cx.ovf = nullptr;
-        cx.lvl = nullptr;
-        cx.certEnd = cx.certEnd1 = 0;
-        cx.nOvf = 0;
-        cx.hashPool = hashPool;
-        cx.hashedFlag = hashedFlag;
-        if (cx.nCert > 0 && cx.nCert <= SQZ_FAST_VALS) {
-            cx.dbg = dbg;
-            u32 const nBlocks = len1 ? 2u : 1u;
-            bool const sized = len0 >= SQZ_FAST_MIN_BLOCK && (len1 == 0 || len1 >= SQZ_FAST_MIN_BLOCK);
-            bool const room = cap >= n + 9 + 3 * nBlocks;
-            u32 const hdr = 5 + (n < 256 ? 1u : (n < 65536 + 256 ? 2u : 4u)); // = fast_frame_header()
-            cert_lds_core(cx, L, (sized && room && !(dbg & 4)) ? dst + hdr : nullptr);
-            FPROF_T0(t_frame);
-            c0 = cx.certEnd;
-            c1 = cx.certEnd1 | SQZ_CERT_HINT_VALID;
-            if (dbg & 64) c0 = cx.nOvf; // bring-up: why the scan gave up
-            // every search of every block certainly fails?
-            bool whole = cx.certEnd >= SQZ_WINDOW_START + len0 - 8;
-            if (len1) whole = whole && (cx.certEnd1 >= SQZ_WINDOW_START + SQZ_BLOCKSIZE_MAX + len1 - 8);
-            if (dbg & 4) whole = false; // timing experiment: certificate only
-            if (whole && sized && room) {
-                // HUF's sampled pre-check: the 4 KiB samples (first and last of each block) are dealt out to the
-                // waves; largest1 + largest2 of a block are added up through LDS
-                u32 const wv = fw_wave();
-                u32 const nSamples = 2 * nBlocks;
-                for (u32 j = wv; j < nSamples; j += FW_NW) {
-                    u32 const b = j >> 1, bs = b ? len1 : len0;
-                    const u8* const at = src + (b ? len0 : 0u) + ((j & 1) ? bs - 4096 : 0u);
-                    u32 l = 0, dummy;
-                    wv_zero_lds(L->bloom + 256 * wv, 256);
-                    wv_hist_bytes(L->bloom + 256 * wv, at, 4096);
-                    wv_max_and_last(L->bloom + 256 * wv, 256, &l, &dummy);
-                    WV_SERIAL L->sh[FW_SH_SAMPLE + j] = l;
-                }
-                fw_sync();
-                u32 ok = 1; // (every wave reads the same four words)
-                for (u32 b = 0; b < nBlocks; b++)
-                    if (L->sh[FW_SH_SAMPLE + 2 * b] + L->sh[FW_SH_SAMPLE + 2 * b + 1] > ((2 * 4096) >> 7) + 4) ok = 0;
-                if (ok) {
-                    if (wv == 0) (void)fast_frame_header(dst, n);
-                    u8* op = dst + hdr;
-                    u32 const done = cx.rawEnd - SQZ_WINDOW_START; // chunk bytes the scan has already put in place
-                    for (u32 b = 0; b < nBlocks; b++) {
-                        u32 const bs = b ? len1 : len0, b0 = b ? len0 : 0u;
-                        if (b % FW_NW == wv) {
-                            u32 const h = ((b + 1 == nBlocks) ? 1u : 0u) + (0u << 1) + (bs << 3); // ZSTD_noCompressBlock
-                            WV_SERIAL {
-                                op[0] = (u8)h;
-                                op[1] = (u8)(h >> 8);
-                                op[2] = (u8)(h >> 16);
-                            }
-                            u32 const have = done > b0 ? (done - b0 < bs ? done - b0 : bs) : 0u;
-                            if (have < bs) wv_memcpy(op + 3 + have, src + b0 + have, bs - have);
-                        }
-                        op += 3 + bs;
-                    }
-                    frame = (u32)(op - dst);
-                }
-            }
-            FPROF_ADD(L, 4, t_frame);
+        u32 e0, e1;
+        u32 const ok = fastpath_blocks(src, n, dst, cap, 0, cp, schedTab, L, &e0, &e1, dbg, hashPool, hashedFlag);
+        if (e0 | e1) {
+            c0 = e0;
+            c1 = e1 | SQZ_CERT_HINT_VALID;
         }
+        if (ok) frame = fast_frame_header_all(dst, n) + n + 3 * nBlocks;
+    } else if (cp.strategy == STRAT_LAZY2 && !(dbg & 512)) { // (512: timing experiment, large chunks left to stage 2)
+        u32 ok = 1;
+        for (u32 bA = 0; bA < nBlocks && ok; bA += 2) {
+            u32 e0, e1;
+            ok = fastpath_blocks(src, n, dst, cap, bA, cp, schedTab, L, &e0, &e1, dbg, nullptr, nullptr);
+            fw_sync();
+        }
+        if (ok) frame = fast_frame_header_all(dst, n) + n + 3 * nBlocks;
     }
     if (fw_wave() == 0) WV_SERIAL {
         certOut[0] = c0;
@@ -1155,14 +1230,19 @@ SQ_DEV u32 fastpath_frame_wave(const u8* src, u32 n, u8* dst, u32 cap, u32* E, u
     wv_mem_sync();
     return frame;
 }
+#endif
 
 #if SQ_ON_DEVICE
-// Persistent workgroups of FW_NW waves; every workgroup pulls chunk indices from *queue until exhausted (every
-// workgroup reaches idx >= n).  frame_len[idx] = frame size, or 0 = not decided here.
+// Persistent workgroups of FW_NW waves; every workgroup pulls JOBS from *queue until exhausted (every workgroup reaches
+// j >= n_jobs).  A job is a chunk of at most two blocks, or one pair of blocks of a larger chunk (jobs[j] = chunk index |
+// pair number << 28; jobs == null: job j = chunk j).  frame_len[idx] = frame size, or 0 = not decided here.
+// pair_state[idx] (zeroed by the host; large chunks only): pairs finished so far (bits 0..7) and how many of them
+// failed (bits 8..); the workgroup that finishes a chunk's last pair writes its frame header and its verdict.
 __global__ void __launch_bounds__(64 * SQZ_FAST_WG_WAVES, SQZ_FAST_WAVES_PER_SIMD)
 k_incompressible_batch(const u8* data, const u64* off, const u32* len, const u8* select, u32 n, u8* slots,
                        const u64* slot_off, u32* frame_len, u32* cert_out, u8* etab_pool, u64 etab_bytes,
-                       u32* queue, const u32* schedTab, u32 dbg, u32 persist, u32* work, u8* hashed, u8* hpool) {
+                       u32* queue, const u32* schedTab, u32 dbg, u32 persist, u32* work, u8* hashed, u8* hpool,
+                       const u32* jobs, u32 n_jobs, u32* pair_state) {
     // hashed / hpool (both or none): the fused form -- the kernel runs BEFORE the dedup decision on every chunk of the
     // batch (select == null) and, for each chunk it streams, leaves the sums of XXH3's full blocks in the chunk's slice
     // of hpool (SQZ_FAST_HPOOL_BYTES each) and hashed[idx] = 1 (hashed[] zeroed by the host); sqx::k_xxh3_128_rows
@@ -1171,14 +1251,8 @@ k_incompressible_batch(const u8* data, const u64* off, const u32* len, const u8*
     // lists: [0] / [1] their lengths, then n slots for the "heavy" ones (certified in neither block: the
     // whole exact path) and n slots for the others.
     __shared__ FastLds lds;
-    // a workgroup's slice: its table (none in the LDS edition), then 256 bytes that keep its generation counter
-    // between launches
-    u32* const E = (u32*)(etab_pool + (u64)blockIdx.x * (etab_bytes + 256));
-    u32* const saved = (u32*)((u8*)E + etab_bytes);
+    (void)etab_pool; (void)etab_bytes; (void)persist; // (the certificate's set lives in LDS: no table, no generations)
     bool const first = threadIdx.x == 0;
-    // 0: the table holds unknown words; `persist`: the host vouches that the pool is as the previous
-    // launch left it, so the saved counter is still true and the tags go on counting
-    u32 gen = persist ? gld32(saved) : 0u;
     if (threadIdx.x < 64) { // the secret words of XXH3's stripe loop as the scan's lanes need them
         u32 const l = threadIdx.x;
         u64 const k0 = sqx::sec64(8 * (l >> 2) + 16 * (l & 3)), k1 = sqx::sec64(8 * (l >> 2) + 16 * (l & 3) + 8);
@@ -1191,36 +1265,72 @@ k_incompressible_batch(const u8* data, const u64* off, const u32* len, const u8*
     if (first)
         for (int k = 0; k < 8; k++) lds.prof[k] = 0;
 #endif
+    u32 const nj = jobs ? n_jobs : n;
     for (;;) {
         if (first) lds.sh[FW_SH_IDX] = atomicAdd(queue, 1u);
         fw_sync();
-        u32 const idx = wv_uni(lds.sh[FW_SH_IDX]);
+        u32 const j = wv_uni(lds.sh[FW_SH_IDX]);
         fw_sync(); // (the word is written again at the top of the next turn)
-        if (idx >= n) break;
+        if (j >= nj) break;
+        u32 const job = jobs ? gld32(jobs + j) : j;
+        u32 const idx = job & 0x0FFFFFFFu, pair = job >> 28;
+        bool const taken = select == nullptr || select[idx] != 0;
+        u32 const L = len[idx];
+        bool const large = L > 2 * SQZ_BLOCKSIZE_MAX; // more than two blocks: one job per pair of blocks
         u32 r = 0;
-        if (select == nullptr || select[idx] != 0) {
-            if (gen == 0 || gen >= SQZ_HT_GEN_MAX) {
-                if (fw_wave() == 0) wv_fill32(E, 0, etab_bytes / 4);
-                gen = 0;
-            }
-            gen++;
+        bool verdict = !large; // this job settles the chunk (the last pair of a large one does)
+        if (taken) {
             u32 const cap = (u32)(slot_off[idx + 1] - slot_off[idx]);
-            wv_mem_sync_inv(); // no L1 line from the previous chunk's table / data survives
+            u8* const dst = slots + slot_off[idx];
+            CParams const cp = get_cparams(L);
+            u32 const nBlocks = (L + SQZ_BLOCKSIZE_MAX - 1) / SQZ_BLOCKSIZE_MAX, nPairs = (nBlocks + 1) / 2;
+            wv_mem_sync_inv(); // no L1 line from the previous chunk's data survives
             FPROF_T0(t_chunk);
-            r = fastpath_frame_wave(data + off[idx], len[idx], slots + slot_off[idx], cap, E, gen << SQZ_HT_GEN_SHIFT,
-                                    schedTab, &lds, cert_out + 2 * (size_t)idx, dbg,
-                                    hpool ? (u64*)(hpool + (u64)idx * SQZ_FAST_HPOOL_BYTES) : nullptr, hashed ? hashed + idx : nullptr);
+            bool run = (cp.strategy == STRAT_BTLAZY2 && L >= 9) || (large && !(dbg & 512)); // (512: timing experiment, large chunks left to stage 2)
+            if (large) { // a pair of blocks of a large chunk is not worth its scan once another pair of the chunk has failed
+                if (first) lds.sh[FW_SH_IDX] = __hip_atomic_load(pair_state + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                fw_sync();
+                if (wv_uni(lds.sh[FW_SH_IDX]) >> 8) run = false;
+                fw_sync();
+            }
+            u32 ok = 0, e0 = 0, e1 = 0;
+            if (run) // (the ONE call site, see fastpath_frame_wave)
+                ok = fastpath_blocks(data + off[idx], L, dst, cap, large ? 2 * pair : 0u, cp, schedTab, &lds, &e0, &e1, dbg,
+                                     (hpool && !large) ? (u64*)(hpool + (u64)idx * SQZ_FAST_HPOOL_BYTES) : nullptr,
+                                     (hashed && !large) ? hashed + idx : nullptr);
+            if (!large) {
+                if (ok) r = fast_frame_header_all(dst, L) + L + 3 * nBlocks;
+                if (first) { // the certificate ends for k_compress_batch, or 0, 0 when no certificate was computed
+                    cert_out[2 * (size_t)idx] = e0;
+                    cert_out[2 * (size_t)idx + 1] = (e0 | e1) ? (e1 | SQZ_CERT_HINT_VALID) : 0u;
+                }
+            } else {
+                fw_sync();
+                if (first) lds.sh[FW_SH_IDX] = atomicAdd(pair_state + idx, 1u + (ok ? 0u : 0x100u)) + 1u + (ok ? 0u : 0x100u);
+                fw_sync();
+                u32 const now = wv_uni(lds.sh[FW_SH_IDX]);
+                fw_sync();
+                if ((now & 0xFFu) == nPairs) { // the chunk's last pair to finish
+                    verdict = true;
+                    if (!(now >> 8)) r = fast_frame_header_all(dst, L) + L + 3 * nBlocks;
+                    if (first) {
+                        cert_out[2 * (size_t)idx] = 0;
+                        cert_out[2 * (size_t)idx + 1] = 0;
+                    }
+                }
+            }
+            wv_mem_sync();
             FPROF_ADD(&lds, 5, t_chunk);
-        } else if (first) {
+        } else if (first && (!large || pair == 0)) {
             cert_out[2 * (size_t)idx] = 0;
             cert_out[2 * (size_t)idx + 1] = 0;
         }
-        if (first) {
+        if (first && verdict) {
             frame_len[idx] = r;
             if (r)
                 atomicAdd(queue + 1, 1u);
-            else if (select == nullptr || select[idx] != 0) {
-                u32 const L = len[idx], h0 = cert_out[2 * (size_t)idx], h1 = cert_out[2 * (size_t)idx + 1];
+            else if (taken) {
+                u32 const h0 = cert_out[2 * (size_t)idx], h1 = cert_out[2 * (size_t)idx + 1];
                 u32 const len0 = L < SQZ_BLOCKSIZE_MAX ? L : SQZ_BLOCKSIZE_MAX;
                 bool const heavy = (h1 & SQZ_CERT_HINT_VALID) && L > SQZ_BLOCKSIZE_MAX + 8 && len0 >= 9 &&
                                    h0 < SQZ_WINDOW_START + len0 - 8 && (h1 & ~SQZ_CERT_HINT_VALID) < SQZ_WINDOW_START + L - 8;
@@ -1229,11 +1339,10 @@ k_incompressible_batch(const u8* data, const u64* off, const u32* len, const u8*
             }
         }
     }
-    if (first) saved[0] = gen;
 #ifdef SQ_PROF
     fw_sync();
     if (first)
-        for (int k = 0; k < 8; k++) ((unsigned long long*)(saved + 8))[k] = lds.prof[k];
+        for (int k = 0; k < 8; k++) ((unsigned long long*)(etab_pool + (u64)blockIdx.x * (etab_bytes + 256) + etab_bytes + 32))[k] = lds.prof[k];
 #endif
 }
 #endif

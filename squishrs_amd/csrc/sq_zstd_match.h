@@ -970,6 +970,12 @@ struct CertCtx {
     u32 genBits;         // generation tag of this chunk's entries, in place (bits 19..29)
     const u32* schedTab; // constant no-match schedules
     u32 certCnt0, nCert; // scheduled searches in block 0 / in the chunk
+    u32 base0Pos;        // stage 1 (cert_lds_core) only: where the first certified block starts (SQZ_WINDOW_START for a chunk of
+                         // at most two blocks; a later block of a large chunk, whose earlier blocks are then only scanned)
+    u32 tab0;            //   ... which schedule table that block uses: 0 "first" (the frame's first block), 1 "later"
+    u32 tail;            //   ... searches stop this many bytes before a block's end: 8, row-hash finder 16
+    u32 hashBits;        //   ... 0: any earlier position with a search's 4 bytes breaks the certificate (btlazy2); else the
+                         //   row-hash finder's rule: only one whose 5-byte hash (this many bits: row + tag) is the search's too
     u32 base1Pos;        // position the "later" table is laid at (block 1's start; an anchor for a tail certificate)
     u32 tabOff1;         // first entry of the "later" table that is used
     u32 repOff;          // repcode offset of the searches' repcode test (1 at the start of a frame)
@@ -995,6 +1001,12 @@ SQ_DEV u32 cert_pos_c(const CertCtx& cx, u32 i) { // position of the i-th schedu
     bool const first = i < cx.certCnt0;
     u32 const slot = first ? i : SQZ_SCHEDTAB_N + cx.tabOff1 + (i - cx.certCnt0);
     return sq_gld32(cx.schedTab + 2 + slot) + (first ? SQZ_WINDOW_START : cx.base1Pos);
+}
+// the same for stage 1's generalised form (base0Pos / tab0)
+SQ_DEV u32 cert_pos_g(const CertCtx& cx, u32 i) {
+    bool const first = i < cx.certCnt0;
+    u32 const slot = first ? (cx.tab0 ? SQZ_SCHEDTAB_N : 0u) + i : SQZ_SCHEDTAB_N + cx.tabOff1 + (i - cx.certCnt0);
+    return sq_gld32(cx.schedTab + 2 + slot) + (first ? cx.base0Pos : cx.base1Pos);
 }
 
 SQ_DEVFN void cert_compute_core(CertCtx& cx) {

@@ -248,6 +248,84 @@ def planted(seed: int, nbytes: int, variant: int = 0) -> bytes:
     return bytes(b)
 
 
+def row_hash24(five: bytes, bits: int = 24) -> int:
+    """ZSTD_hash5 of the row-hash finder (salt 0): ((read64LE << 24) * prime5) >> (64 - bits); five = the 5 bytes."""
+    v = int.from_bytes(five[:5] + bytes(3), "little")
+    return (((v << 24) & ((1 << 64) - 1)) * 889523592379 & ((1 << 64) - 1)) >> (64 - bits)
+
+
+def planted_large(seed: int, nbytes: int, variant: int = 0) -> bytes:
+    """Incompressible bytes of the lazy2 / row-hash size class (> 256 KiB: the reference's 2 MiB chunks and the tails
+    above 256 KiB) with plants aimed at what is particular to that finder: candidates come from the row and tag of the
+    5-byte hash (a 4-byte coincidence whose fifth byte differs is harmless unless the hashes collide), searches stop
+    16 bytes before a block's end, the certificate of stage 1 works pair of blocks by pair of blocks."""
+    b = bytearray(random_bytes(78, seed * 16 + variant, nbytes))
+    block = 128 << 10
+    sched = []
+    start = 0
+    while start < nbytes:
+        end = min(start + block, nbytes)
+        p = start + (1 if start == 0 else 0)
+        while p < end - 16:
+            sched.append(p)
+            p += ((p - start) >> 8) + 1
+        start = end
+    rnd = xoshiro_bytes(seed * 104729 + variant, 64)
+    pick = lambda k, lo, hi: lo + int.from_bytes(rnd[4 * k:4 * k + 4], "little") % max(1, hi - lo)
+    nblk = (nbytes + block - 1) // block
+
+    def in_block(bi, frac=0.6):
+        xs = [x for x in sched if bi * block <= x < (bi + 1) * block]
+        return xs[int(len(xs) * frac)]
+
+    def copy(dst, src, ln):
+        b[dst:dst + ln] = b[src:src + ln]
+
+    mid_b = nblk // 2
+    if variant == 0:      # 4 equal bytes at a searched position, the fifth differs: no candidate (unless the hashes collide)
+        s = in_block(mid_b)
+        src = pick(0, 64, s - 64)
+        copy(s, src, 4)
+        if b[s + 4] == b[src + 4]:
+            b[s + 4] ^= 0x55
+    elif variant == 1:    # 5 equal bytes at a searched position of a middle block: a match of length >= 5
+        s = in_block(mid_b)
+        copy(s, pick(0, 64, s - 64), 5)
+    elif variant == 2:    # 40 bytes at a searched position of the last block
+        s = in_block(nblk - 1, 0.4)
+        copy(s, pick(0, 64, s - 64), 40)
+    elif variant == 3:    # 8 bytes in block 0 and 8 bytes in a late block
+        s0 = in_block(0, 0.8)
+        copy(s0, pick(0, 16, s0 - 16), 8)
+        s1 = in_block(min(nblk - 1, 5), 0.3)
+        copy(s1, pick(1, 64, s1 - 64), 8)
+    elif variant == 4:    # a repeat at a position the tree finders would search but the row-hash finder does not
+        e = (mid_b + 1) * block      # (the last positions before end - 8 of a block: it stops at end - 16)
+        copy(e - 12, pick(0, 64, e - 200), 9)
+    elif variant == 5:    # a run of equal bytes over a searched position: the repcode (offset 1) test fires
+        s = in_block(mid_b, 0.7)
+        b[s - 1:s + 7] = bytes([b[s]]) * 8
+    elif variant == 6:    # two searched positions of different pairs of blocks share 6 bytes
+        a = in_block(1, 0.5)
+        c = in_block(min(nblk - 1, 2 * ((nblk - 1) // 2)), 0.5)
+        copy(c, a, 6)
+    elif variant == 7:    # the earlier copy lies in the FIRST block, the search in the last pair of blocks
+        s = in_block(nblk - 1, 0.2)
+        copy(s, pick(0, 64, block - 64), 7)
+    elif variant == 8:    # 5 bytes in the dense start of a block (every position is searched there)
+        s = mid_b * block + 100
+        copy(s, pick(0, 64, s - 64), 5)
+    elif variant == 9:    # several: 5 bytes in a middle block, 7 bytes in the last pair with the copy in block 0
+        s = in_block(mid_b, 0.35)
+        copy(s, pick(0, 64, s - 64), 5)
+        s2 = in_block(nblk - 1, 0.55)
+        copy(s2, pick(1, 64, block - 64), 7)
+    # (A 4-byte coincidence with a different fifth byte can never meet its twin in the finder: of two 5-byte strings
+    # that share their first four bytes, (v << 24) * prime differs in the top 8 bits of the product by x * (prime & 0xFF),
+    # and that prime's low byte is odd -- the 256 fifth bytes give 256 different rows.)
+    return bytes(b)
+
+
 def cross_shard_plan(world: int, n: int, frac: float = 0.3, seed: int = 4):
     """BASELINE configs[4]: `world` contiguous shards of n chunks; int(frac * world * n) of ALL chunks are exact
     copies of an "original" (never itself a copy) that lives on ANOTHER shard.  Returns the content index of every
@@ -271,6 +349,8 @@ def cross_shard_plan(world: int, n: int, frac: float = 0.3, seed: int = 4):
 
 
 def make(kind: str, seed: int, nbytes: int) -> bytes:
+    if kind.startswith("plantedL"):
+        return planted_large(seed, nbytes, int(kind[8:] or 0))
     if kind.startswith("planted"):
         return planted(seed, nbytes, int(kind[7:] or 0))
     return GENERATORS[kind](seed, nbytes)
