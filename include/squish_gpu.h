@@ -185,6 +185,12 @@ int sq_shard_submit_hash(sq_ctx* ctx, const uint8_t* d_data, const uint64_t* h_o
 int sq_shard_wait_hash(sq_ctx* ctx);
 int sq_shard_submit_rest(sq_ctx* ctx, const uint8_t* d_all_hashes, uint64_t n_total, uint64_t my_first, uint8_t* d_is_new,
                          uint8_t* d_comp, uint64_t comp_cap, uint32_t flags);
+/* The same for ANY assignment of the chunks of the global order to ranks (block-cyclic stripes spread the first occurrences,
+ * i.e. the compression work, evenly -- with contiguous ranges the first rank holds first occurrences only): this rank's
+ * chunk i is entry d_my_idx[i] (device, n x u32, ascending) of d_all_hashes, which holds all ranks' hashes in GLOBAL
+ * chunk-index order (the caller permutes the rank-major result of its all-gather). */
+int sq_shard_submit_rest_idx(sq_ctx* ctx, const uint8_t* d_all_hashes, uint64_t n_total, const uint32_t* d_my_idx, uint8_t* d_is_new,
+                             uint8_t* d_comp, uint64_t comp_cap, uint32_t flags);
 
 /* Page-locked host buffers for the batch forms (hipHostMalloc).  The reference's packer reads every
  * chunk into a heap buffer (BufReader + chunk_buf, src/archive/writer.rs:233-246) and hands the frames on

@@ -21,7 +21,7 @@ EXPORTS = [
     "sq_pack_batch", "sq_unique_count", "sq_hash_batch", "sq_dedup_global", "sq_compress_batch",
     "sq_calibrate_read_bw", "sq_last_timings", "sq_dedup_reset", "sq_compress_batch_slots", "sq_slots_bound",
     "sq_host_alloc", "sq_host_free", "sq_debug_stage2_list", "sq_pack_submit", "sq_pack_wait", "sq_calibrate_gather",
-    "sq_shard_submit_hash", "sq_shard_wait_hash", "sq_shard_submit_rest",
+    "sq_shard_submit_hash", "sq_shard_wait_hash", "sq_shard_submit_rest", "sq_shard_submit_rest_idx",
 ]
 
 
@@ -94,6 +94,7 @@ def load():
     L.sq_shard_submit_hash.argtypes = [vp, u8p, vp, vp, ctypes.c_uint32, u8p]
     L.sq_shard_wait_hash.argtypes = [vp]
     L.sq_shard_submit_rest.argtypes = [vp, u8p, ctypes.c_uint64, ctypes.c_uint64, u8p, u8p, ctypes.c_uint64, ctypes.c_uint32]
+    L.sq_shard_submit_rest_idx.argtypes = [vp, u8p, ctypes.c_uint64, vp, u8p, u8p, ctypes.c_uint64, ctypes.c_uint32]
     L.sq_debug_stage2_list.argtypes = [vp, vp, ctypes.c_uint32, ctypes.POINTER(ctypes.c_uint32)]
     _lib = L
     return L

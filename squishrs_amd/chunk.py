@@ -193,6 +193,12 @@ class ChunkStore:
         check(self._L.sq_shard_submit_rest(self._h, all_hashes.data_ptr(), n_total, my_first, is_new.data_ptr(),
                                            comp.data_ptr(), comp.numel(), 1 if reset else 0))
 
+    def shard_submit_rest_idx(self, all_hashes, n_total: int, my_idx, is_new, comp, reset: bool = False):
+        """sq_shard_submit_rest_idx: as shard_submit_rest for any assignment of chunks to ranks -- all_hashes in GLOBAL
+        chunk-index order, my_idx (device int32/uint32 tensor) = the global index of each of this rank's chunks."""
+        check(self._L.sq_shard_submit_rest_idx(self._h, all_hashes.data_ptr(), n_total, my_idx.data_ptr(), is_new.data_ptr(),
+                                               comp.data_ptr(), comp.numel(), 1 if reset else 0))
+
     def stage2_list(self, cap: int = 1 << 20) -> np.ndarray:
         """Indices of the chunks the last compress launch's first stage left to the compressor proper."""
         out = np.zeros(cap, dtype=np.uint32)

@@ -1165,18 +1165,44 @@ int sq_shard_wait_hash(sq_ctx* c) {
     return SQ_OK;
 }
 
+#ifndef SQ_NO_COMPRESS
+static int shard_submit_rest(sq_ctx* c, const uint8_t* d_all_hashes, uint64_t n_total, uint64_t my_first, const uint32_t* d_my_idx,
+                             uint8_t* d_is_new, uint8_t* d_comp, uint64_t comp_cap, uint32_t flags);
+#endif
+
 int sq_shard_submit_rest(sq_ctx* c, const uint8_t* d_all_hashes, uint64_t n_total, uint64_t my_first, uint8_t* d_is_new,
                          uint8_t* d_comp, uint64_t comp_cap, uint32_t flags) {
 #ifdef SQ_NO_COMPRESS
     (void)c; (void)d_all_hashes; (void)n_total; (void)my_first; (void)d_is_new; (void)d_comp; (void)comp_cap; (void)flags;
     return SQ_E_COMPRESS;
 #else
+    return shard_submit_rest(c, d_all_hashes, n_total, my_first, nullptr, d_is_new, d_comp, comp_cap, flags);
+#endif
+}
+
+int sq_shard_submit_rest_idx(sq_ctx* c, const uint8_t* d_all_hashes, uint64_t n_total, const uint32_t* d_my_idx, uint8_t* d_is_new,
+                             uint8_t* d_comp, uint64_t comp_cap, uint32_t flags) {
+#ifdef SQ_NO_COMPRESS
+    (void)c; (void)d_all_hashes; (void)n_total; (void)d_my_idx; (void)d_is_new; (void)d_comp; (void)comp_cap; (void)flags;
+    return SQ_E_COMPRESS;
+#else
+    if (c && c->shard_pending && !c->ln[c->submitted & 1].shard_len.empty() && (!d_my_idx || !is_device_ptr(d_my_idx))) return SQ_E_INVAL;
+    return shard_submit_rest(c, d_all_hashes, n_total, 0, d_my_idx ? d_my_idx : (const uint32_t*)(uintptr_t)16, d_is_new, d_comp, comp_cap, flags);
+#endif
+}
+
+#ifndef SQ_NO_COMPRESS
+// d_my_idx == null: this rank's chunks are the contiguous range [my_first, my_first + n) of the global order; else
+// chunk i of this rank is entry d_my_idx[i] of it (any assignment of chunks to ranks, e.g. block-cyclic).
+static int shard_submit_rest(sq_ctx* c, const uint8_t* d_all_hashes, uint64_t n_total, uint64_t my_first, const uint32_t* d_my_idx,
+                             uint8_t* d_is_new, uint8_t* d_comp, uint64_t comp_cap, uint32_t flags) {
     if (!c || !c->shard_pending) return SQ_E_INVAL;
     sq_lane* const L = &c->ln[c->submitted & 1];
     sq_lane* const other = &c->ln[(c->submitted & 1) ^ 1];
     u32 const n = (u32)L->shard_len.size();
     if ((n_total && !d_all_hashes) || my_first + n > n_total || (n && (!d_is_new || !d_comp))) return SQ_E_INVAL;
     if (n && (!is_device_ptr(d_all_hashes) || !is_device_ptr(d_is_new) || !is_device_ptr(d_comp))) return SQ_E_INVAL;
+    if (d_my_idx && n_total >= 0xFFFFFFFFull) return SQ_E_INVAL;
     if (sq_slots_bound(L->shard_len.data(), n) > comp_cap) return SQ_E_CAP;
     HIPCHK(hipSetDevice(c->device));
     int r;
@@ -1188,6 +1214,7 @@ int sq_shard_submit_rest(sq_ctx* c, const uint8_t* d_all_hashes, uint64_t n_tota
         if (seen0 + n_total > c->key_capacity || seen0 + n_total >= 0xFFFFFFFFull) return SQ_E_CAP;
     }
     if ((r = compress_prepare(c, L, L->shard_len.data(), n, d_comp, comp_cap, true, false))) return r;
+    if (d_my_idx && (r = L->b_isnew.ensure((size_t)n_total + 16))) return r;
     // the dedup set is shared: this batch's reset / insert must follow the previous batch's dedup kernels
     if (other->busy) HIPCHK(hipStreamWaitEvent(L->stream, other->dedup_done, 0));
     if (flags & 1u) {
@@ -1195,7 +1222,15 @@ int sq_shard_submit_rest(sq_ctx* c, const uint8_t* d_all_hashes, uint64_t n_tota
         HIPCHK(hipMemsetAsync(c->d_unique, 0, 64, L->stream));
         c->n_seen = 0;
     }
-    if ((r = dedup_async(c, L, d_all_hashes, n_total, my_first, n, d_is_new))) return r; // (SQ_E_CAP: fails before touching the set)
+    if (d_my_idx) { // flags of ALL chunks of the global order, then this rank's picked out of them
+        if ((r = dedup_async(c, L, d_all_hashes, n_total, 0, (u32)n_total, (u8*)L->b_isnew.p))) return r;
+        if (n) {
+            hipLaunchKernelGGL(sqd::k_pick_flags, dim3((n + 255) / 256), dim3(256), 0, L->stream, (const u8*)L->b_isnew.p, d_my_idx, n,
+                               (u32)n_total, d_is_new);
+            HIPCHK(hipGetLastError());
+        }
+    } else if ((r = dedup_async(c, L, d_all_hashes, n_total, my_first, n, d_is_new))) // (SQ_E_CAP: fails before touching the set)
+        return r;
     HIPCHK(hipEventRecord(L->dedup_done, L->stream));
     if ((r = compress_stage1(c, L, L->shard_data, d_is_new, false)) || (r = compress_stage2(c, L, L->shard_data, d_is_new))) {
         (void)hipStreamSynchronize(L->stream);
@@ -1204,8 +1239,8 @@ int sq_shard_submit_rest(sq_ctx* c, const uint8_t* d_all_hashes, uint64_t n_tota
     L->busy = true;
     c->submitted++;
     return SQ_OK;
-#endif
 }
+#endif
 
 int sq_pack_wait(sq_ctx* c, uint64_t* h_comp_off, uint32_t* h_comp_len) {
 #ifdef SQ_NO_COMPRESS

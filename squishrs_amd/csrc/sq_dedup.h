@@ -91,6 +91,17 @@ k_drop_unselected(u32* __restrict__ frame_len, const u8* __restrict__ select, u3
     if ((threadIdx.x & 63) == 0 && b) atomicSub(decided, (u32)__popcll(b));
 }
 
+// Sharded form with any assignment of chunks to ranks (sq_shard_submit_rest_idx): the dedup stage has resolved the flags
+// of ALL chunks of the global order; this rank's chunk i is entry idx[i] of it.
+__global__ void __launch_bounds__(256)
+k_pick_flags(const u8* __restrict__ all_flags, const u32* __restrict__ idx, u32 n, u32 n_total, u8* __restrict__ out) {
+    u32 const i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) {
+        u32 const g = idx[i];
+        out[i] = g < n_total ? all_flags[g] : 0;
+    }
+}
+
 // Undo of one batch's k_dedup_insert (sq_pack_batch failing after the commit): empty every slot whose
 // representative index is >= g_first.  Entries of earlier batches were placed before any of these existed, so
 // their probe paths never run across the slots emptied here -- no tombstones are needed.

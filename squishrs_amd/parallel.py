@@ -22,6 +22,24 @@ def shard_range(n_total: int, rank: int, world: int):
     return first, base + (1 if rank < rem else 0)
 
 
+def stripe_assign(n_total: int, world: int, stripe: int):
+    """Block-cyclic assignment of the chunks of a super-batch to ranks: stripe t = chunks [t * stripe, (t + 1) * stripe) of
+    the global order belongs to rank t % world.  With contiguous ranges the first rank holds first occurrences only and
+    compresses all of its chunks while later ranks skip their duplicates of earlier ranks' chunks; stripes spread the
+    first occurrences -- the compression work -- evenly.  Returns (owner[g], counts[r], perm[g]): perm[g] = position of
+    chunk g in the rank-major concatenation an all-gather of the ranks' arrays produces."""
+    g = np.arange(n_total, dtype=np.int64)
+    owner = (g // max(1, stripe)) % world
+    counts = np.bincount(owner, minlength=world).astype(np.int64)
+    starts = np.zeros(world, dtype=np.int64)
+    starts[1:] = np.cumsum(counts)[:-1]
+    local = np.zeros(n_total, dtype=np.int64)
+    for r in range(world):
+        idx = np.nonzero(owner == r)[0]
+        local[idx] = np.arange(len(idx))
+    return owner, counts, starts[owner] + local
+
+
 class ShardedPacker:
     def __init__(self, stages, group: Optional[dist.ProcessGroup] = None):
         self.stages = stages
@@ -71,6 +89,19 @@ class ShardedPacker:
         parts = [recv[r * n_max * 16: r * n_max * 16 + int(counts_h[r]) * 16] for r in range(self.world)]
         return torch.cat(parts), n_total, my_first
 
+    def gather_ragged(self, t: torch.Tensor, n_max: int):
+        """All-gather of a 1-D tensor of at most n_max entries per rank (padded): returns the (world, n_max) result."""
+        if self.world == 1:
+            return t.reshape(1, -1)
+        if t.is_cuda and dist.get_backend(self.group) == "gloo":
+            torch.cuda.current_stream().synchronize()
+            return self.gather_ragged(t.cpu(), n_max).to(t.device)
+        send = torch.zeros(n_max, dtype=t.dtype, device=t.device)
+        send[: t.numel()] = t
+        recv = torch.empty(self.world * n_max, dtype=t.dtype, device=t.device)
+        dist.all_gather_into_tensor(recv, send, group=self.group)
+        return recv.view(self.world, n_max)
+
     def pack(self, data, offs: np.ndarray, lens: np.ndarray, hashes, is_new, comp, layout: str = "packed",
              uniform: bool = False):
         """hash -> all-gather -> global dedup -> compress own new chunks.
@@ -87,7 +118,7 @@ class ShardedPacker:
 
     # ---- pipelined form: two batches in flight, the exchange of batch k+1 under the compression of batch k ----------
     def submit(self, data, offs: np.ndarray, lens: np.ndarray, hashes, is_new, comp, reset: bool = False,
-               uniform: bool = False):
+               uniform: bool = False, perm=None, my_idx=None):
         """Enqueue one batch (slots layout): hash -> [host waits for the hashes] -> all-gather -> global dedup +
         compression of this rank's new chunks enqueued behind it.  Returns at once; collect with wait().  At most two
         batches in flight, each with its own hashes / is_new / comp buffers.  The collective runs on a stream of its
@@ -97,18 +128,32 @@ class ShardedPacker:
         st = self.stages
         st.shard_submit_hash(data, offs, lens, hashes)
         st.shard_wait_hash()
+
+        def exchange():
+            g, n_total, my_first = self.gather_hashes(hashes, n, uniform)
+            if perm is not None:
+                # any assignment of chunks to ranks (stripe_assign): the rank-major gather result is put into GLOBAL
+                # chunk-index order (perm: tensor on the hashes' device) -- on the exchange's stream, like the gather
+                g = g.view(-1, 16)[perm].reshape(-1).contiguous()
+            return g, n_total, my_first
+
         if self.world > 1 and torch.cuda.is_available() and hashes.is_cuda:
             if self._comm is None:
                 self._comm = torch.cuda.Stream()
             with torch.cuda.stream(self._comm):
-                all_hashes, n_total, my_first = self.gather_hashes(hashes, n, uniform)
+                all_hashes, n_total, my_first = exchange()
             self._comm.synchronize()
         else:
-            all_hashes, n_total, my_first = self.gather_hashes(hashes, n, uniform)
-        st.shard_submit_rest(all_hashes, n_total, my_first, is_new, comp, reset)
-        self._inflight.append((all_hashes, n))
+            all_hashes, n_total, my_first = exchange()
+            if hashes.is_cuda:
+                torch.cuda.current_stream().synchronize()   # (the permutation ran on torch's stream, the rest runs on the lane's)
+        if perm is not None:   # ... and this rank names its chunks by their global index (my_idx)
+            st.shard_submit_rest_idx(all_hashes, n_total, my_idx, is_new, comp, reset)
+        else:
+            st.shard_submit_rest(all_hashes, n_total, my_first, is_new, comp, reset)
+        self._inflight.append((all_hashes, n, my_idx))
 
     def wait(self):
         """(slot offsets[n], frame lengths[n]) of the oldest batch in flight."""
-        _keep, n = self._inflight.pop(0)
+        self.last_all_hashes, n, _idx = self._inflight.pop(0)   # (the batch's hashes in global order: the caller's manifest)
         return self.stages.pack_wait(n)

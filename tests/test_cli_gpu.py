@@ -250,10 +250,13 @@ def test_bench_config4_three_ranks_on_one_gpu_rehearsal():
     port = s.getsockname()[1]
     s.close()
     env = dict(os.environ, SQUISH_DEVICE="0", SQUISH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
-    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "3", "--master-addr", "127.0.0.1",
-                        "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "3", "--steps", "2", "--warmup", "1",
-                        "--chunks", "1500"], capture_output=True, text=True, env=env, cwd=ROOT, timeout=900)
-    assert r.returncode == 0, r.stderr[-3000:]
-    line = json.loads(r.stdout.strip().splitlines()[-1])
-    assert line["n_gpus"] == 3 and line["config"]["unique_chunks"] == 3150 and line["scaling"] == "weak"
-    assert line["config"]["parity"]["frames_compared_with_oracle"] > 0
+    # block-cyclic stripes of 16 chunks (the default), then contiguous ranges (--stripe 0)
+    for extra, chunks, unique in ((), "1600", 3360), (("--stripe", "0"), "1500", 3150):
+        r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "3", "--master-addr", "127.0.0.1",
+                            "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "3", "--steps", "2", "--warmup", "1",
+                            "--chunks", chunks, *extra], capture_output=True, text=True, env=env, cwd=ROOT, timeout=900)
+        assert r.returncode == 0, r.stderr[-3000:]
+        line = json.loads(r.stdout.strip().splitlines()[-1])
+        assert line["n_gpus"] == 3 and line["config"]["unique_chunks"] == unique and line["scaling"] == "weak"
+        assert line["config"]["parity"]["frames_compared_with_oracle"] > 0
+        assert ("block-cyclic" in line["config"]["workload"]) == (not extra)

@@ -87,6 +87,21 @@ class OracleStages:
         assert len(self._done) < 2, "more than two batches in flight"
         self._done.append(self.compress_device_slots(data, offs, lens, is_new, comp))
 
+    def shard_submit_rest_idx(self, all_hashes, n_total, my_idx, is_new, comp, reset=False):
+        """all_hashes in GLOBAL order; this rank's chunk i is entry my_idx[i] (sq_shard_submit_rest_idx)"""
+        data, offs, lens = self._pending
+        self._pending = None
+        if reset:
+            self.seen = set()
+        flags = torch.zeros(max(n_total, 1), dtype=torch.uint8)
+        self.dedup_device(all_hashes, n_total, 0, n_total, flags)
+        for i, g in enumerate(my_idx.tolist()):
+            is_new[i] = flags[g]
+        if not hasattr(self, "_done"):
+            self._done = []
+        assert len(self._done) < 2, "more than two batches in flight"
+        self._done.append(self.compress_device_slots(data, offs, lens, is_new, comp))
+
     def pack_wait(self, n):
         off, ln = self._done.pop(0)
         assert len(off) == n
@@ -146,6 +161,35 @@ def test_shard_range_contiguous():
             assert tot == n
 
 
+def test_stripe_assign_balances_first_occurrences():
+    """Block-cyclic stripes: every chunk has exactly one owner, perm maps the global order onto the rank-major
+    concatenation of an all-gather, and on BASELINE configs[4]'s plan (30 % copies) the chunks a rank has to compress
+    -- first occurrences in global order -- are spread evenly, where contiguous ranges leave rank 0 with all of its
+    chunks and the last rank with the fewest."""
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import corpus
+    from squishrs_amd.parallel import stripe_assign
+    for n_total, world, stripe in ((100, 4, 16), (37, 3, 1), (5, 4, 2), (64, 8, 8), (0, 2, 4)):
+        owner, counts, perm = stripe_assign(n_total, world, stripe)
+        assert len(owner) == n_total and counts.sum() == n_total and sorted(perm.tolist()) == list(range(n_total))
+        # rank-major concatenation: rank r's chunks in global order
+        rank_major = np.concatenate([np.nonzero(owner == r)[0] for r in range(world)]) if n_total else np.zeros(0, dtype=np.int64)
+        assert (rank_major[perm] == np.arange(n_total)).all()
+        if n_total >= world * stripe:
+            assert counts.max() - counts.min() <= stripe
+    world, n = 8, 4096
+    plan = corpus.cross_shard_plan(world, n)
+    _, first_idx = np.unique(plan, return_index=True)
+    new = np.zeros(world * n, dtype=bool)
+    new[first_idx] = True
+    owner, _, _ = stripe_assign(world * n, world, 16)
+    cyc = [int(new[owner == r].sum()) for r in range(world)]
+    con = [int(new[r * n:(r + 1) * n].sum()) for r in range(world)]
+    assert con[0] > 0.95 * n and con[-1] < 0.5 * n                 # contiguous: rank 0 compresses (nearly) everything it has
+    assert max(cyc) - min(cyc) < 0.05 * n and max(cyc) < 0.75 * n  # stripes: 70 % each, within a few percent
+
+
 def test_two_rank_global_first_occurrence():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -187,7 +231,7 @@ def _sharded_files():
     return files
 
 
-def _sharded_worker(rank, world, port, out_path, batch_chunks):
+def _sharded_worker(rank, world, port, out_path, batch_chunks, stripe=2):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -195,23 +239,25 @@ def _sharded_worker(rank, world, port, out_path, batch_chunks):
     from squishrs_amd.sharded_pack import pack_sharded
     files = _sharded_files()
     pack_sharded([(p, None) for p, _ in files], out_path, OracleStages(), device="cpu", timestamp=1234567,
-                 batch_chunks=batch_chunks, contents=[c for _, c in files])
+                 batch_chunks=batch_chunks, contents=[c for _, c in files], stripe=stripe)
     dist.barrier()
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,batch_chunks", [(2, 4096), (4, 3)])
-def test_sharded_pack_archive_equals_single_writer_archive(tmp_path, world, batch_chunks):
-    """gloo ranks with CPU stand-ins for the device stages: the archive rank 0 writes must be the oracle's
-    `.squish` restatement byte for byte (same timestamp) -- records in global chunk-index order, duplicates that
-    live on other ranks (and in other super-batches) dropped, count patched, manifest complete."""
+@pytest.mark.parametrize("world,batch_chunks,stripe", [(2, 4096, 2), (4, 3, 1), (2, 5, 16), (4, 6, 2), (3, 4096, 1)])
+def test_sharded_pack_archive_equals_single_writer_archive(tmp_path, world, batch_chunks, stripe):
+    """gloo ranks with CPU stand-ins for the device stages: the ONE archive the ranks write together (every rank
+    pwrite()s its own records at the offsets the exchanged record sizes give; block-cyclic stripes; two super-batches
+    in flight) must be the oracle's `.squish` restatement byte for byte (same timestamp) -- records in global
+    chunk-index order, duplicates that live on other ranks (and in other super-batches) dropped, count patched,
+    manifest complete.  Super-batches smaller than the world (ranks without a chunk), stripes larger than a batch."""
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
     out = str(tmp_path / f"w{world}.squish")
     ctx = mp.get_context("spawn")
-    procs = [ctx.Process(target=_sharded_worker, args=(r, world, port, out, batch_chunks)) for r in range(world)]
+    procs = [ctx.Process(target=_sharded_worker, args=(r, world, port, out, batch_chunks, stripe)) for r in range(world)]
     for p in procs:
         p.start()
     for p in procs:
