@@ -210,6 +210,10 @@ int sq_calibrate_read_bw(sq_ctx* ctx, const uint8_t* d_buf, uint64_t nbytes, flo
  * lanes... per CU): kernel time in ms and the number of loads issued.  The compressor's candidate evaluation on
  * compressible data is bound by this rate, not by streaming bandwidth; bench.py reports it beside configs[3]. */
 int sq_calibrate_gather(sq_ctx* ctx, const uint8_t* d_buf, uint64_t nbytes, uint32_t per_lane, float* ms, uint64_t* requests);
+/* The same with the shape of the requests chosen: req_bytes 16 / 32 / 64 per request, depth 1 / 2 / 4 / 8 / 16 requests in flight
+ * per lane, waves_per_cu 4 / 8 / 16 / 32 resident waves (0 = 16 bytes, 8 in flight, 32 waves).  tools/gather_sweep.py. */
+int sq_calibrate_gather2(sq_ctx* ctx, const uint8_t* d_buf, uint64_t nbytes, uint32_t per_lane, uint32_t req_bytes, uint32_t depth,
+                         uint32_t waves_per_cu, float* ms, uint64_t* requests);
 
 /* Timing of the most recent stage launches of this ctx, in milliseconds, measured with HIP
  * events on the ctx stream (0 if the stage did not run). */

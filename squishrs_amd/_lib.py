@@ -20,7 +20,7 @@ EXPORTS = [
     "sq_ctx_set_stream", "sq_ctx_synchronize", "sq_hash_chunk", "sq_compress_chunk",
     "sq_pack_batch", "sq_unique_count", "sq_hash_batch", "sq_dedup_global", "sq_compress_batch",
     "sq_calibrate_read_bw", "sq_last_timings", "sq_dedup_reset", "sq_compress_batch_slots", "sq_slots_bound",
-    "sq_host_alloc", "sq_host_free", "sq_debug_stage2_list", "sq_pack_submit", "sq_pack_wait", "sq_calibrate_gather",
+    "sq_host_alloc", "sq_host_free", "sq_debug_stage2_list", "sq_pack_submit", "sq_pack_wait", "sq_calibrate_gather", "sq_calibrate_gather2",
     "sq_shard_submit_hash", "sq_shard_wait_hash", "sq_shard_submit_rest", "sq_shard_submit_rest_idx",
 ]
 
@@ -87,6 +87,8 @@ def load():
     L.sq_slots_bound.argtypes = [vp, ctypes.c_uint32]
     L.sq_calibrate_read_bw.argtypes = [vp, u8p, ctypes.c_uint64, ctypes.POINTER(ctypes.c_float)]
     L.sq_calibrate_gather.argtypes = [vp, u8p, ctypes.c_uint64, ctypes.c_uint32, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_uint64)]
+    L.sq_calibrate_gather2.argtypes = [vp, u8p, ctypes.c_uint64, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32,
+                                       ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_uint64)]
     L.sq_last_timings.argtypes = [vp, ctypes.POINTER(SqTimings)]
     L.sq_dedup_reset.argtypes = [vp]
     L.sq_pack_submit.argtypes = [vp, u8p, vp, vp, ctypes.c_uint32, u8p, u8p, u8p, ctypes.c_uint64, ctypes.c_uint32]

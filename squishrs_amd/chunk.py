@@ -218,6 +218,13 @@ class ChunkStore:
         check(self._L.sq_calibrate_gather(self._h, buf.data_ptr(), buf.numel(), per_lane, ctypes.byref(ms), ctypes.byref(req)))
         return req.value / (ms.value / 1e3)
 
+    def gather_rate2(self, buf, nbytes: int, req_bytes: int = 16, depth: int = 8, waves_per_cu: int = 32, per_lane: int = 512) -> float:
+        """sq_calibrate_gather2: random requests of req_bytes per second over the first nbytes of `buf`."""
+        ms = ctypes.c_float(0)
+        req = ctypes.c_uint64(0)
+        check(self._L.sq_calibrate_gather2(self._h, buf.data_ptr(), nbytes, per_lane, req_bytes, depth, waves_per_cu, ctypes.byref(ms), ctypes.byref(req)))
+        return req.value / (ms.value / 1e3)
+
     def timings(self) -> SqTimings:
         t = SqTimings()
         check(self._L.sq_last_timings(self._h, ctypes.byref(t)))

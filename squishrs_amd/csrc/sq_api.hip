@@ -443,23 +443,53 @@ int sq_calibrate_read_bw(sq_ctx* c, const uint8_t* d_buf, uint64_t nbytes, float
     return SQ_OK;
 }
 
-int sq_calibrate_gather(sq_ctx* c, const uint8_t* d_buf, uint64_t nbytes, uint32_t per_lane, float* ms, uint64_t* requests) {
+// req_bytes: 16, 32 or 64 (one lane's piece: 1, 2 or 4 consecutive 16-byte loads); depth: 1, 2, 4, 8 or 16 pieces in flight per
+// lane; waves_per_cu: 4, 8, 16 or 32 resident waves per CU.  0 = the defaults (16 bytes, 8 in flight, 32 waves per CU).
+int sq_calibrate_gather2(sq_ctx* c, const uint8_t* d_buf, uint64_t nbytes, uint32_t per_lane, uint32_t req_bytes, uint32_t depth,
+                         uint32_t waves_per_cu, float* ms, uint64_t* requests) {
     if (!c || !d_buf || !ms || !requests || ((uintptr_t)d_buf & 15) || nbytes < 4096 || per_lane == 0) return SQ_E_INVAL;
     if (c->submitted != c->collected) return SQ_E_INVAL;
+    if (req_bytes == 0) req_bytes = 16;
+    if (depth == 0) depth = 8;
+    if (waves_per_cu == 0) waves_per_cu = 32;
     sq_lane* const L = &c->ln[0];
     HIPCHK(hipSetDevice(c->device));
     int r = L->b_misc.ensure(256);
     if (r) return r;
-    per_lane = (per_lane + 7) & ~7u;
-    dim3 block(256), grid((unsigned)(c->num_cu * 8)); // 8 waves per CU x 4: the occupancy of the compressor and more
+    per_lane = (per_lane + 15) & ~15u;
+    dim3 block(256), grid((unsigned)(c->num_cu * waves_per_cu / 4));
+    const uint4* const p = (const uint4*)d_buf;
+    u64 const n16 = nbytes / 16;
+    u32* const sink = (u32*)L->b_misc.p;
     HIPCHK(hipEventRecord(L->ev[6], L->stream));
-    hipLaunchKernelGGL(sqd::k_gather_bw, grid, block, 0, L->stream, (const uint4*)d_buf, nbytes / 16, per_lane, (u32*)L->b_misc.p);
+#define SQ_GB(R, D) hipLaunchKernelGGL((sqd::k_gather_bw<R, D>), grid, block, 0, L->stream, p, n16, per_lane, sink)
+#define SQ_GBD(R)                                                                        \
+    switch (depth) {                                                                     \
+    case 1: SQ_GB(R, 1); break;                                                          \
+    case 2: SQ_GB(R, 2); break;                                                          \
+    case 4: SQ_GB(R, 4); break;                                                          \
+    case 8: SQ_GB(R, 8); break;                                                          \
+    case 16: SQ_GB(R, 16); break;                                                        \
+    default: return SQ_E_INVAL;                                                          \
+    }
+    switch (req_bytes) {
+    case 16: SQ_GBD(1); break;
+    case 32: SQ_GBD(2); break;
+    case 64: SQ_GBD(4); break;
+    default: return SQ_E_INVAL;
+    }
+#undef SQ_GBD
+#undef SQ_GB
     HIPCHK(hipGetLastError());
     HIPCHK(hipEventRecord(L->ev[7], L->stream));
     HIPCHK(hipStreamSynchronize(L->stream));
     HIPCHK(hipEventElapsedTime(ms, L->ev[6], L->ev[7]));
     *requests = (uint64_t)grid.x * 256 * per_lane;
     return SQ_OK;
+}
+
+int sq_calibrate_gather(sq_ctx* c, const uint8_t* d_buf, uint64_t nbytes, uint32_t per_lane, float* ms, uint64_t* requests) {
+    return sq_calibrate_gather2(c, d_buf, nbytes, per_lane, 16, 8, 32, ms, requests);
 }
 
 #ifndef SQ_NO_COMPRESS

@@ -181,23 +181,32 @@ k_read_bw(const uint4* __restrict__ p, u64 n16, u32* __restrict__ sink) {
     if (acc == 0x12345678u) *sink = acc; // never true in practice; keeps the loads alive
 }
 
-// Random-access calibration: every lane reads `per_lane` 16-byte words at pseudo-random 16-byte aligned places of the
-// buffer (an LCG per lane; 8 independent loads in flight per lane, like the candidate evaluation of the row-hash
-// search batches).  The rate of such requests, not the streaming bandwidth, bounds the compressor on compressible
-// data; bench.py reports it beside the configs[3] leg.
+// Random-access calibration: every lane reads `per_lane` pieces of REQ x 16 bytes at pseudo-random REQ x 16-byte aligned
+// places of the buffer (an LCG per lane; DEPTH independent pieces in flight per lane, like the candidate evaluation of
+// the row-hash search batches).  The rate of such requests, not the streaming bandwidth, is what the compressor runs
+// against on compressible data; bench.py reports it beside the configs[3] leg, tools/gather_sweep.py
+// sweeps request size x depth x buffer size.  The index is a multiply-shift of the generator's upper bits -- NOT a
+// 64-bit modulo, which is a ~40-instruction software division per request and was what the first version of this
+// probe measured (the same 50 G/s whether or not the buffer fitted the Infinity Cache).
+template <int REQ, int DEPTH>
 __global__ void __launch_bounds__(256)
 k_gather_bw(const uint4* __restrict__ p, u64 n16, u32 per_lane, u32* __restrict__ sink) {
     u64 x = ((u64)blockIdx.x * blockDim.x + threadIdx.x) * 0x9E3779B97F4A7C15ull + 0x632BE59BD9B4E019ull;
+    u32 const nPieces = (u32)(n16 / REQ); // (< 2^32: buffers up to 64 GiB)
     u32 acc = 0;
-    for (u32 i = 0; i < per_lane; i += 8) {
-        uint4 v[8];
+    for (u32 i = 0; i < per_lane; i += DEPTH) {
+        uint4 v[DEPTH][REQ];
 #pragma unroll
-        for (int k = 0; k < 8; k++) {
+        for (int k = 0; k < DEPTH; k++) {
             x = x * 6364136223846793005ull + 1442695040888963407ull;
-            v[k] = p[(x >> 20) % n16];
+            u64 const at = (u64)__umulhi((u32)(x >> 32), nPieces) * REQ;
+#pragma unroll
+            for (int r = 0; r < REQ; r++) v[k][r] = p[at + r];
         }
 #pragma unroll
-        for (int k = 0; k < 8; k++) acc ^= v[k].x ^ v[k].y ^ v[k].z ^ v[k].w;
+        for (int k = 0; k < DEPTH; k++)
+#pragma unroll
+            for (int r = 0; r < REQ; r++) acc ^= v[k][r].x ^ v[k][r].y ^ v[k][r].z ^ v[k][r].w;
     }
     if (acc == 0x12345678u) *sink = acc; // never true in practice; keeps the loads alive
 }

@@ -283,8 +283,6 @@ SQ_DEVFN void rb_eval(MatchState& ms, RowBatch& bt, u32 i0, u32 iendPos) {
     SQ_L u32* const Lbest = (SQ_L u32*)g_lds.u.rb.best;
     SQ_L u32* const Lflag = (SQ_L u32*)g_lds.u.rb.flag;
     SQ_L u32* const Lown = (SQ_L u32*)g_lds.grp; // the 32 bytes at every lane's position
-    SQ_L u32* const Lprev = (SQ_L u32*)g_lds.u.rb.prev;
-    SQ_L u8* const Lbe = (SQ_L u8*)g_lds.u.rb.be;
     Lpb[lane] = pbase;
     Lstop[lane] = 0xFFFFFFFFu;
     Lbest[lane] = 0;
@@ -333,8 +331,10 @@ SQ_DEVFN void rb_eval(MatchState& ms, RowBatch& bt, u32 i0, u32 iendPos) {
             c[k] = B0 + (d & 63u);
             if (has[k] && !(d & 64u)) c[k] = sq_tld32(ms.hashTable + ((size_t)Lrow[own[k]] << 6) + (d & 63u));
         }
-        sq_v4u b0[4], b1[4];
-        u64 bp[4];
+        // Requests are what this kernel is short of: per pair only the FIRST 16 bytes of the candidate are
+        // fetched here; the second 16 only for the pairs whose first 16 all match (a second, sparse trip), and the 8 bytes
+        // in front of a candidate -- the backward extension -- only for each owner's winner (below).
+        sq_v4u b0[4];
         bool bad = false;
 #pragma unroll
         for (int k = 0; k < 4; k++) {
@@ -347,27 +347,42 @@ SQ_DEVFN void rb_eval(MatchState& ms, RowBatch& bt, u32 i0, u32 iendPos) {
             }
             u32 const cc = ok ? c[k] : SQZ_WINDOW_START;
             b0[k] = sq_grd128(base + cc);
-            b1[k] = sq_grd128(base + cc + 16);
-            bp[k] = sq_grd64(base + (cc >= 8 + SQZ_WINDOW_START ? cc - 8 : SQZ_WINDOW_START)); // the 8 bytes in front of the candidate
         }
         if (wv_ballot(bad)) ms.fault = 1;
+        bool more[4];
+        bool anyMore = false;
 #pragma unroll
         for (int k = 0; k < 4; k++) {
             len[k] = 0;
+            more[k] = false;
+            if (has[k]) {
+                sq_v4u const o0 = *(const SQ_L sq_v4u*)(Lown + 8 * own[k]);
+                len[k] = rb_prefix16(o0, b0[k]);
+                more[k] = len[k] == 16;
+                anyMore |= more[k];
+            }
+        }
+        if (wv_ballot(anyMore)) { // the sparse second trip
+            sq_v4u b1[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) b1[k] = more[k] ? sq_grd128(base + c[k] + 16) : (sq_v4u){0, 0, 0, 0};
+#pragma unroll
+            for (int k = 0; k < 4; k++)
+                if (more[k]) {
+                    sq_v4u const o1 = *(const SQ_L sq_v4u*)(Lown + 8 * own[k] + 4);
+                    len[k] = 16 + rb_prefix16(o1, b1[k]);
+                }
+        }
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
             if (has[k]) {
                 u32 const p = 64u * (u32)k + lane;
-                sq_v4u const o0 = *(const SQ_L sq_v4u*)(Lown + 8 * own[k]), o1 = *(const SQ_L sq_v4u*)(Lown + 8 * own[k] + 4);
-                u32 l = rb_prefix16(o0, b0[k]);
-                if (l == 16) l = 16 + rb_prefix16(o1, b1[k]);
+                u32 l = len[k];
                 u32 const lim = iendPos - (B0 + own[k]);
                 if (l >= 32 && lim > 32) l = 255; // long: the exact finder extends and decides
                 else if (l > lim) l = lim;
                 len[k] = l;
                 Lcand[p] = c[k];
-                // backward extension (catch-up) of this pair: equal bytes in front of both, at most 8; only
-                // meaningful (and only used) when both positions have 8 bytes in front of them
-                u64 const x = (((u64)Lprev[2 * own[k] + 1] << 32) | Lprev[2 * own[k]]) ^ bp[k];
-                Lbe[p] = (u8)((c[k] >= 8 + SQZ_WINDOW_START) ? (x ? ((u32)__builtin_clzll(x) >> 3) : SQZ_RB_BECAP) : 0u);
             }
         }
         wv_fence(); // (the stoppers are in before anybody reads them: LDS operations of a wave execute in order)
@@ -392,8 +407,16 @@ SQ_DEVFN void rb_eval(MatchState& ms, RowBatch& bt, u32 i0, u32 iendPos) {
                 u32 const t = 255u - (b & 255u);
                 ml = b >> 8;
                 bestC = Lcand[pbase + t];
-                be = (q >= 8 + SQZ_WINDOW_START) ? (u32)Lbe[pbase + t] : 0u;
             }
+        }
+    }
+    {   // backward extension (catch-up) of each owner's winner: equal bytes in front of both positions, at most 8; only
+        // meaningful (and only used) when both have 8 bytes in front of them -- one 8-byte load per owner with a match
+        bool const want = ml > 3 && bestC >= 8 + SQZ_WINDOW_START && q >= 8 + SQZ_WINDOW_START;
+        if (wv_ballot(want)) {
+            u64 const bp = want ? sq_grd64(base + bestC - 8) : 0ull;
+            u64 const x = bt.ownPrev ^ bp;
+            if (want) be = x ? ((u32)__builtin_clzll(x) >> 3) : SQZ_RB_BECAP;
         }
     }
     if (sel) {
