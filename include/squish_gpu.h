@@ -223,10 +223,6 @@ typedef struct sq_timings {
     uint32_t fast_decided; /* chunks whose frame stage 1 produced in the most recent compress stage */
     uint32_t fused;        /* 1: the batch took the fused form (stage 1 before the dedup decision, computing the hashes'
                               block sums; hash_ms is then the kernel that finishes them), 0: the split form */
-    uint32_t split_emitted; /* chunks above 256 KiB whose frame the two-kernel path produced (match-finding kernel +
-                               emitting kernel, inside compress_ms) in the most recent compress stage */
-    uint32_t split_left;    /* ... and those it handed back to the one-kernel compressor (an assumption of the
-                               match-finding kernel about the entropy stage's decisions did not hold) */
 } sq_timings;
 int sq_last_timings(sq_ctx* ctx, sq_timings* out);
 

@@ -35,8 +35,7 @@ class SqConfig(ctypes.Structure):
 class SqTimings(ctypes.Structure):
     _fields_ = [("hash_ms", ctypes.c_float), ("dedup_ms", ctypes.c_float),
                 ("compress_ms", ctypes.c_float), ("compact_ms", ctypes.c_float), ("fast_ms", ctypes.c_float),
-                ("fast_decided", ctypes.c_uint32), ("fused", ctypes.c_uint32),
-                ("split_emitted", ctypes.c_uint32), ("split_left", ctypes.c_uint32)]
+                ("fast_decided", ctypes.c_uint32), ("fused", ctypes.c_uint32)]
 
 
 class SquishError(RuntimeError):

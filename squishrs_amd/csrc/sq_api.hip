@@ -21,9 +21,7 @@
 
 // Experiment / bring-up switches of the environment: read ONCE (the first sq_ctx_create), never on the per-batch path.
 struct sq_env {
-    bool debug = false, debug_stats = false, hash_wave_per_chunk = false, no_fastpath = false, no_split = false;
-    int find_waves_per_cu = 0;
-    bool find_full_lds = false;
+    bool debug = false, debug_stats = false, hash_wave_per_chunk = false, no_fastpath = false;
     int stage1_wgs_per_cu = 0, stage2_waves_per_cu = 0, fast_dbg = 0;
     bool s1_after_s2 = true; // SQ_S1_AFTER_S2=0: experiment switch of the launch order in pack_enqueue
     int stage1_grid = -1; // SQ_STAGE1_GRID: 1 = one workgroup per chunk instead of persistent workgroups (experiment)
@@ -39,9 +37,6 @@ static void sq_env_read() {
     g_env.debug_stats = getenv("SQ_DEBUG_STATS") != nullptr;
     g_env.hash_wave_per_chunk = getenv("SQ_HASH_WAVE_PER_CHUNK") != nullptr;
     g_env.no_fastpath = getenv("SQ_NO_FASTPATH") != nullptr;
-    g_env.no_split = getenv("SQ_NO_SPLIT") != nullptr; // A/B: chunks above 256 KiB through k_compress_batch alone
-    if (const char* e = getenv("SQ_FIND_WAVES_PER_CU")) g_env.find_waves_per_cu = atoi(e);
-    g_env.find_full_lds = getenv("SQ_FIND_FULL_LDS") != nullptr; // bring-up: the match-finding kernel with the whole LdsState
     g_env.allow_any_arch = getenv("SQ_ALLOW_ANY_ARCH") != nullptr;
     if (const char* e = getenv("SQ_STAGE1_WAVES_PER_CU")) g_env.stage1_wgs_per_cu = atoi(e);
     if (const char* e = getenv("SQ_STAGE2_WAVES_PER_CU")) g_env.stage2_waves_per_cu = atoi(e);
@@ -106,7 +101,7 @@ struct sq_lane {
     hipEvent_t dedup_done = nullptr; // recorded after this lane's dedup kernels: the other lane's dedup waits for it
     hipEvent_t pre_s2 = nullptr;     // recorded right before this lane's stage 2 is launched (fused form, see pack_enqueue)
     DevBuf b_off, b_len, b_slot_off, b_frame_len, b_out_off, b_isnew, b_hashes, b_stage_in,
-        b_stage_out, b_slots, b_ws, b_misc, b_cert, b_etab, b_work, b_hashed, b_hpool, b_jobs, b_pair, b_find_off, b_find;
+        b_stage_out, b_slots, b_ws, b_misc, b_cert, b_etab, b_work, b_hashed, b_hpool, b_jobs, b_pair;
     // shapes of the two table pools at the last launch that completed (persistent generation tags)
     void* ws_ptr_last = nullptr;
     size_t ws_each_last = 0;
@@ -115,7 +110,7 @@ struct sq_lane {
     size_t etab_bytes_last = 0;
     u32 etab_waves_last = 0;
     void* h_pinned = nullptr; // small pinned host mirror (error words etc.)
-    sq_timings last = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    sq_timings last = {0, 0, 0, 0, 0, 0, 0};
     u32 work_n = 0; // chunks of the launch whose stage-2 work lists b_work holds (0: none)
     // a batch enqueued by sq_pack_submit and not yet collected by sq_pack_wait
     bool busy = false;
@@ -125,8 +120,6 @@ struct sq_lane {
     size_t h_len_cap = 0;
     u32 job_max_len = 0;
     u32 job_waves = 0, job_fwaves = 0;
-    u32 job_find_waves = 0, job_emit_waves = 0; // > 0: the batch's chunks above 256 KiB go through k_find_batch + k_emit_batch first
-    std::vector<u64> job_find_off;
     size_t job_ws_each = 0, job_etab_bytes = 0;
     bool job_fast = false, job_in_place = false, job_fused = false;
     u8* job_slots = nullptr;
@@ -285,7 +278,7 @@ void sq_ctx_destroy(sq_ctx* c) {
         if (L->stream) (void)hipStreamSynchronize(L->stream);
         for (DevBuf* b : {&L->b_off, &L->b_len, &L->b_slot_off, &L->b_frame_len, &L->b_out_off, &L->b_isnew,
                           &L->b_hashes, &L->b_stage_in, &L->b_stage_out, &L->b_slots, &L->b_ws, &L->b_misc, &L->b_cert, &L->b_etab, &L->b_work,
-                          &L->b_hashed, &L->b_hpool, &L->b_jobs, &L->b_pair, &L->b_find_off, &L->b_find})
+                          &L->b_hashed, &L->b_hpool, &L->b_jobs, &L->b_pair})
             b->release();
         if (L->h_pinned) (void)hipHostFree(L->h_pinned);
         if (L->h_len_pinned) (void)hipHostFree(L->h_len_pinned);
@@ -546,32 +539,6 @@ static int compress_prepare(sq_ctx* c, sq_lane* L, const u32* h_len, u32 n, u8* 
     const size_t ws_each = sqz::workspace_bytes(max_len);
     // keep the workspace pool within ~96 GiB
     while (waves > 64 && (u64)waves * ws_each > (96ull << 30)) waves /= 2;
-    // Chunks above 256 KiB (lazy2 + row hash): match finding and the entropy stage as kernels of their own
-    // (k_find_batch at 12 waves per CU, then k_emit_batch; sq_zstd_kernel.h).  Both use this lane's workspace pool
-    // before k_compress_batch does, which then finds no table state of its own in it (job_ws_persist = 0).
-    L->job_find_waves = L->job_emit_waves = 0;
-    u32 pool_waves = waves;
-    if (max_len > (256u << 10) && !g_env.no_split) {
-        std::vector<u64>& fo = L->job_find_off;
-        fo.assign(n, ~0ull);
-        u64 facc = 0;
-        u32 cnt = 0;
-        for (u32 i = 0; i < n; i++)
-            if (h_len[i] > (256u << 10)) {
-                fo[i] = facc;
-                facc += sqz::find_area_bytes(h_len[i]);
-                cnt++;
-            }
-        u32 per_cu = (g_env.find_waves_per_cu >= 1 && g_env.find_waves_per_cu <= 12) ? (u32)g_env.find_waves_per_cu : 12u;
-        u32 fw = c->cfg.compress_waves ? c->cfg.compress_waves : (u32)c->num_cu * per_cu;
-        fw = std::min(fw, cnt);
-        while (fw > 64 && (u64)fw * ws_each > (96ull << 30)) fw -= fw / 4;
-        if ((r = L->b_find_off.ensure((size_t)n * 8))) return r;
-        if ((r = L->b_find.ensure(facc + 256))) return r;
-        L->job_find_waves = fw;
-        L->job_emit_waves = std::min(waves, cnt);
-        pool_waves = std::max(waves, fw);
-    }
     // Stage 1, the incompressible-chunk kernel (sq_zstd_fast.h): as many workgroups as fit (its state is all
     // in LDS).  It only applies to chunks of 16 KiB < len <= 256 KiB.
     const bool fast = max_len > (16u << 10) && !g_env.no_fastpath;
@@ -606,7 +573,7 @@ static int compress_prepare(sq_ctx* c, sq_lane* L, const u32* h_len, u32 n, u8* 
             if ((r = L->b_hpool.ensure((size_t)n * SQZ_FAST_HPOOL_BYTES))) return r;
         }
     }
-    if ((r = L->b_ws.ensure((size_t)pool_waves * ws_each + 256))) return r;
+    if ((r = L->b_ws.ensure((size_t)waves * ws_each + 256))) return r;
     if (fast && (r = L->b_etab.ensure((size_t)fwaves * (etab_bytes + 256)))) return r;
     if ((r = L->b_misc.ensure(256))) return r;
     if (in_place && L->h_len_cap < (size_t)n * 4) {
@@ -621,7 +588,7 @@ static int compress_prepare(sq_ctx* c, sq_lane* L, const u32* h_len, u32 n, u8* 
         L->h_len_cap = want;
     }
     // the pools keep their generation tags from launch to launch as long as nothing about them changes
-    L->job_ws_persist = (L->b_ws.p == L->ws_ptr_last && ws_each == L->ws_each_last && waves == L->ws_waves_last && fast && !L->job_find_waves) ? 1u : 0u;
+    L->job_ws_persist = (L->b_ws.p == L->ws_ptr_last && ws_each == L->ws_each_last && waves == L->ws_waves_last && fast) ? 1u : 0u;
     L->job_etab_persist = (fast && L->b_etab.p == L->etab_ptr_last && etab_bytes == L->etab_bytes_last && fwaves == L->etab_waves_last) ? 1u : 0u;
     L->ws_ptr_last = nullptr; // becomes valid again when this launch has completed
     L->etab_ptr_last = nullptr;
@@ -642,11 +609,10 @@ static int compress_prepare(sq_ctx* c, sq_lane* L, const u32* h_len, u32 n, u8* 
         HIPCHK(hipMemsetAsync(L->b_pair.p, 0, (size_t)n * 4, L->stream));
     }
     if (L->job_fused) HIPCHK(hipMemsetAsync(L->b_hashed.p, 0, (size_t)n, L->stream));
-    if (L->job_find_waves) HIPCHK(hipMemcpyAsync(L->b_find_off.p, L->job_find_off.data(), (size_t)n * 8, hipMemcpyHostToDevice, L->stream));
     HIPCHK(hipMemsetAsync(L->b_misc.p, 0, 256, L->stream));
     if (g_env.debug) {
         int nb = 0;
-        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, sqz::k_compress_batch, 64, sizeof(sqz::LdsState));
+        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, sqz::k_compress_batch, 64, 0);
         hipFuncAttributes fa;
         (void)hipFuncGetAttributes(&fa, (const void*)sqz::k_compress_batch);
         fprintf(stderr, "[squish_gpu] compress kernel: occupancy %d blocks/CU, regs %d, lds %zu, scratch %zu; waves %u, ws_each %zu\n",
@@ -692,27 +658,14 @@ static int compress_stage2(sq_ctx* c, sq_lane* L, const u8* d_data, const u8* d_
         HIPCHK(hipGetLastError());
     }
     HIPCHK(hipEventRecord(L->ev[4], L->stream));
-    if (L->job_find_waves) {
-        const u32* const work = fast ? (const u32*)L->b_work.p : (const u32*)nullptr;
-        hipLaunchKernelGGL(sqz::k_find_batch, dim3(L->job_find_waves), dim3(64), g_env.find_full_lds ? (u32)sizeof(sqz::LdsState) : SQZ_LDS_FIND_BYTES, L->stream, d_data,
-                           (const u64*)L->b_off.p, (const u32*)L->b_len.p, d_select, n, (u8*)L->b_ws.p, (u64)L->job_ws_each,
-                           (u32*)L->b_misc.p + 4 /*queue*/, work, (const u64*)L->b_find_off.p, (u8*)L->b_find.p);
-        HIPCHK(hipGetLastError());
-        hipLaunchKernelGGL(sqz::k_emit_batch, dim3(L->job_emit_waves), dim3(64), sizeof(sqz::LdsState), L->stream, d_data,
-                           (const u64*)L->b_off.p, (const u32*)L->b_len.p, d_select, n, L->job_slots, (const u64*)L->b_slot_off.p,
-                           (u32*)L->b_frame_len.p, (u8*)L->b_ws.p, (u64)L->job_ws_each, (u32*)L->b_misc.p + 6 /*queue*/, work,
-                           (const u64*)L->b_find_off.p, (const u8*)L->b_find.p, (u32*)L->b_misc.p + 8 /*emitted, left*/);
-        HIPCHK(hipGetLastError());
-    }
     {
         dim3 block(64), grid(L->job_waves);
-        hipLaunchKernelGGL(sqz::k_compress_batch, grid, block, sizeof(sqz::LdsState), L->stream, d_data, (const u64*)L->b_off.p,
+        hipLaunchKernelGGL(sqz::k_compress_batch, grid, block, 0, L->stream, d_data, (const u64*)L->b_off.p,
                            (const u32*)L->b_len.p, d_select, n, L->job_slots,
                            (const u64*)L->b_slot_off.p, (u32*)L->b_frame_len.p, (u8*)L->b_ws.p,
                            (u64)L->job_ws_each, (u32*)L->b_misc.p /*queue*/, (u32*)L->b_misc.p + 16 /*err*/,
                            (const u32*)c->d_sched_tab, fast ? (const u32*)L->b_cert.p : (const u32*)nullptr, L->job_ws_persist,
-                           fast ? (const u32*)L->b_work.p : (const u32*)nullptr,
-                           L->job_find_waves ? (const u64*)L->b_find_off.p : (const u64*)nullptr);
+                           fast ? (const u32*)L->b_work.p : (const u32*)nullptr);
         HIPCHK(hipGetLastError());
     }
     HIPCHK(hipEventRecord(L->ev[5], L->stream));
@@ -730,13 +683,6 @@ static int compress_stage2(sq_ctx* c, sq_lane* L, const u8* d_data, const u8* d_
         if (hipStreamQuery(L->stream) == hipErrorNotReady) {
             hipStream_t s2;
             (void)hipStreamCreateWithFlags(&s2, hipStreamNonBlocking);
-            {
-                u32 mw[64];
-                (void)hipMemcpyAsync(mw, L->b_misc.p, sizeof(mw), hipMemcpyDeviceToHost, s2);
-                (void)hipStreamSynchronize(s2);
-                fprintf(stderr, "[squish_gpu watchdog] misc: queues %u %u | find q %u %u emit q %u %u stats %u %u | err %u | s1 %u %u | find in/out %u %u emit in/out %u %u compress in/out %u %u\n",
-                        mw[0], mw[1], mw[4], mw[5], mw[6], mw[7], mw[8], mw[9], mw[16], mw[32], mw[33], mw[40], mw[41], mw[42], mw[43], mw[44], mw[45]);
-            }
             const sqz::WsLayout WL = sqz::ws_layout(L->job_max_len);
             for (u32 w = 0; w < std::min(L->job_waves, 4u); w++) {
                 u32 tr[64];
@@ -764,7 +710,6 @@ static int compress_stage2(sq_ctx* c, sq_lane* L, const u8* d_data, const u8* d_
     u32* h_err = (u32*)L->h_pinned;
     HIPCHK(hipMemcpyAsync(h_err, (u32*)L->b_misc.p + 16, 4, hipMemcpyDeviceToHost, L->stream));
     HIPCHK(hipMemcpyAsync(h_err + 1, (u32*)L->b_misc.p + 33, 4, hipMemcpyDeviceToHost, L->stream));
-    HIPCHK(hipMemcpyAsync(h_err + 2, (u32*)L->b_misc.p + 8, 8, hipMemcpyDeviceToHost, L->stream));
     return SQ_OK;
 }
 
@@ -799,8 +744,6 @@ static int compress_finish(sq_ctx* c, sq_lane* L, u8* d_comp, u64 comp_cap, u64*
     HIPCHK(hipEventElapsedTime(&L->last.compress_ms, L->ev[4], L->ev[5]));
     if (fast) HIPCHK(hipEventElapsedTime(&L->last.fast_ms, L->ev[8], L->ev[9]));
     L->last.fast_decided = fast ? h_err[1] : 0;
-    L->last.split_emitted = L->job_find_waves ? h_err[2] : 0;
-    L->last.split_left = L->job_find_waves ? h_err[3] : 0;
     L->last.fused = L->job_fused ? 1u : 0u;
     L->work_n = fast ? n : 0;
     if (!*h_err) { // both kernels ran to completion: their saved table states are good for the next launch

@@ -74,11 +74,13 @@ struct RbLds {
     u32 prev[128];                    // per owner lane: the 8 bytes in front of its position
     u8 be[SQZ_RB_PAIRS];              // per pair: equal bytes in front of position and candidate (0..8)
 };
-// One wave's LDS.  The order matters: what the MATCH FINDERS need comes first (grp, ret, trace, the front of the union),
-// the entropy stage's tables last, so that a kernel that only finds matches (k_find_batch, sq_zstd_kernel.h) can be
-// launched with the first SQZ_LDS_FIND_BYTES of it and fit twice as many waves on a CU.  On the device the object
-// lives in dynamic LDS for that reason (the launch says how much of it exists).
 struct LdsState {
+    Entropy ent[2];
+    union {
+        EntropyScratch es;
+        u32 bloom[SQZ_BLOOM_WORDS];
+        RbLds rb; // row-hash search batches (match-finding phase of the lazy2 strategy)
+    } u;
     alignas(16) u8 grp[2048]; // wv_group scratch; the 64 x 32 source bytes of a row-hash search batch
     u32 ret[8];   // results handed from a serial region to the whole wave
     u32* trace;   // 56 debug words in the wave's workspace (read by the host watchdog)
@@ -86,20 +88,8 @@ struct LdsState {
     unsigned long long prof[32]; // per-phase 100 MHz tick sums (profiling build only)
     unsigned long long prof0[32], profLong[32]; // prof[] when the current chunk began; phase sums of the wave's longest chunk
 #endif
-    union {
-        RbLds rb; // row-hash search batches (match-finding phase of the lazy2 strategy)
-        EntropyScratch es;
-        u32 bloom[SQZ_BLOOM_WORDS];
-    } u;
-    Entropy ent[2];
 };
-#define SQZ_LDS_FIND_BYTES ((u32)(offsetof(sqz::LdsState, u) + sizeof(sqz::RbLds)))
-#if SQ_ON_DEVICE
-extern __shared__ __attribute__((aligned(16))) u8 sq_dyn_lds[];
-#define g_lds (*reinterpret_cast<LdsState*>(sq_dyn_lds))
-#else
 SQ_LDS LdsState g_lds;
-#endif
 
 // phase timers (profiling build only): s_memrealtime ticks (100 MHz) summed per phase
 #if defined(SQ_PROF) && SQ_ON_DEVICE
@@ -1463,8 +1453,6 @@ struct SeqStore {
     u16* stBits; // 4 x u16 per sequence: FSE state bits of the sequences bit stream (encodeSequences)
     u32 nseq, nlits;
     u32 longLengthType, longLengthPos;
-    u32 recordsOnly; // 1 in the match-finding kernel: sequence records only -- no literal position list, no literal copy
-                     // (the emitting kernel rebuilds both from the records: emit_prepare_block, sq_zstd_kernel.h)
 };
 
 SQ_DEV void entropy_reset(Entropy* e) { // serial

@@ -197,7 +197,7 @@ SQ_DEV void ps_merge(Fingerprint* acc, const Fingerprint* nw) {
 #endif
 }
 // ZSTD_splitBlock_byChunks(level 2) on a full 128 KiB block
-SQ_NOINLINE u32 splitBlock_byChunks(const u8* p, Fingerprint* fps) {
+SQ_DEVFN u32 splitBlock_byChunks(const u8* p, Fingerprint* fps) {
     Fingerprint* const past = fps;
     Fingerprint* const nw = fps + 1;
     int penalty = 3;
@@ -224,20 +224,21 @@ struct BlockState { // entropy tables are g_lds.ent[idx]
     u32 isFirstBlock;
 };
 
-// ZSTD_buildSeqStore: the match finder + parser of one block (at least 7 bytes); fills ss, leaves the block's
-// repcodes in bs.rep[bs.prevIdx ^ 1]; returns the size of the last literals.  LAZY2_ONLY: instantiated by the
-// match-finding kernel of the lazy2 size class (k_find_batch), which must not carry the other strategies' code.
-template <bool LAZY2_ONLY>
-SQ_DEV u32 cb_find(MatchState& ms, SeqStore& ss, BlockState& bs, void* optState, const u8* src, u32 srcSize) {
+// ZSTD_buildSeqStore + ZSTD_compressBlock_internal: returns body size; 0 => raw; 1 => RLE
+SQ_DEVFN u32 compressBlock_internal(MatchState& ms, SeqStore& ss, BlockState& bs, void* optState, u8* dst,
+                                    u32 dstCap, const u8* src, u32 srcSize) {
     u32 const p = bs.prevIdx, nx = p ^ 1;
-    ss.nseq = 0;
-    ss.nlits = 0;
-    ss.longLengthType = 0;
-    ss.longLengthPos = 0;
-    {
-        u32 const curr = (u32)(src - ms.base);
-        ms.blockEndPos = curr + srcSize;
-        if constexpr (!LAZY2_ONLY) {
+    u32 cSize;
+    if (srcSize < 1 + 1 + 3 + 1 + 1) { // ZSTDbss_noCompress
+        cSize = 0;
+    } else {
+        ss.nseq = 0;
+        ss.nlits = 0;
+        ss.longLengthType = 0;
+        ss.longLengthPos = 0;
+        {
+            u32 const curr = (u32)(src - ms.base);
+            ms.blockEndPos = curr + srcSize;
             if (ms.cp.strategy == STRAT_BTLAZY2) {
                 if (ms.nBlocks < SQZ_BLOCKTAB_CAP) {
                     gst32(ms.blockTab + 2 * ms.nBlocks, curr);
@@ -249,22 +250,20 @@ SQ_DEV u32 cb_find(MatchState& ms, SeqStore& ss, BlockState& bs, void* optState,
             }
             if (!ms.eager && !bs.isFirstBlock) bloom_rebuild(ms); // the entropy stage reused the LDS
             ms.sbMax = 256; // live buckets are dense right after a block start; grows back as they thin out
+            if (curr > ms.nextToUpdate + 384) {
+                u32 const d = curr - ms.nextToUpdate - 384;
+                u32 const n2u = curr - (192 < d ? 192 : d);
+                filter_add_skip(ms, ms.nextToUpdate, n2u);
+                ms.nextToUpdate = n2u;
+            }
         }
-        if (curr > ms.nextToUpdate + 384) {
-            u32 const d = curr - ms.nextToUpdate - 384;
-            u32 const n2u = curr - (192 < d ? 192 : d);
-            if constexpr (!LAZY2_ONLY) filter_add_skip(ms, ms.nextToUpdate, n2u);
-            ms.nextToUpdate = n2u;
-        }
-    }
-    ms.nxEnt = nx;
-    for (int i = 0; i < SQZ_REP_NUM; ++i) bs.rep[nx][i] = bs.rep[p][i];
-    u32 lastLLSize;
-    SQ_TRACE(0, 6);
-    if (LAZY2_ONLY || ms.cp.strategy == STRAT_LAZY2) {
-        lastLLSize = compressBlock_lazy_rowbatch(ms, ss, bs.rep[nx], src, srcSize);
-    } else if constexpr (!LAZY2_ONLY) {
-        if (ms.cp.strategy == STRAT_BTLAZY2) {
+        ms.nxEnt = nx;
+        for (int i = 0; i < SQZ_REP_NUM; ++i) bs.rep[nx][i] = bs.rep[p][i];
+        u32 lastLLSize;
+        SQ_TRACE(0, 6);
+        if (ms.cp.strategy == STRAT_LAZY2) {
+            lastLLSize = compressBlock_lazy_rowbatch(ms, ss, bs.rep[nx], src, srcSize);
+        } else if (ms.cp.strategy == STRAT_BTLAZY2) {
             lastLLSize = compressBlock_lazy<0>(ms, ss, bs.rep[nx], src, srcSize);
         } else {
             // btopt: the whole parse is one serial region on lane 0
@@ -308,51 +307,35 @@ SQ_DEV u32 cb_find(MatchState& ms, SeqStore& ss, BlockState& bs, void* optState,
             bs.rep[nx][2] = g_lds.ret[7];
             wv_fence();
         }
-    }
-    SQ_TRACE(0, 7);
-    SQ_TRACE(4, ss.nseq);
-    return lastLLSize;
-}
-
-// ZSTD_compressBlock_internal after the sequence store is built: the entropy stage.  Returns the body size; 0 => raw;
-// 1 => RLE; confirms the block's repcodes and entropy tables (bs.prevIdx) when it is emitted compressed.
-SQ_DEV u32 cb_emit(u32 strategy, SeqStore& ss, BlockState& bs, u8* dst, u32 dstCap, const u8* src, u32 srcSize, u32 lastLLSize) {
-    u32 const p = bs.prevIdx, nx = p ^ 1;
-    u32 cSize;
-    if (ss.nseq == 0 && ss.nlits == 0 && lastLLSize == srcSize) {
-        // no sequence at all: the literals ARE the block; the entropy stage reads them in place
-        SeqStore whole = ss;
-        whole.lits = const_cast<u8*>(src);
-        whole.nlits = srcSize;
-        ss.nlits = srcSize;
-        wv_mem_sync_inv();
-        cSize = entropy_compress_seqstore(whole, &g_lds.ent[p], &g_lds.ent[nx], strategy, dst, dstCap, srcSize);
-    } else {
-        PROF_T0(t_ll);
-        if (lastLLSize) wv_memcpy(ss.lits + ss.nlits, src + srcSize - lastLLSize, lastLLSize);
-        PROF_ADD(7, t_ll);
-        ss.nlits += lastLLSize;
-        wv_mem_sync_inv(); // sequence records / literals written by other lanes have landed
-        cSize = entropy_compress_seqstore(ss, &g_lds.ent[p], &g_lds.ent[nx], strategy, dst, dstCap, srcSize);
-    }
-    SQ_TRACE(0, 9);
-    SQ_TRACE(5, cSize);
-    if (is_err(cSize)) return cSize;
-    if (!bs.isFirstBlock && cSize < 25 && wv_is_rle(src, srcSize)) {
-        cSize = 1;
-        gst8(dst, srd8(src));
+        SQ_TRACE(0, 7);
+        SQ_TRACE(4, ss.nseq);
+        if (ss.nseq == 0 && ss.nlits == 0 && lastLLSize == srcSize) {
+            // no sequence at all: the literals ARE the block; the entropy stage reads them in place
+            SeqStore whole = ss;
+            whole.lits = const_cast<u8*>(src);
+            whole.nlits = srcSize;
+            ss.nlits = srcSize;
+            wv_mem_sync_inv();
+            cSize = entropy_compress_seqstore(whole, &g_lds.ent[p], &g_lds.ent[nx], ms.cp.strategy, dst, dstCap, srcSize);
+        } else {
+            PROF_T0(t_ll);
+            if (lastLLSize) wv_memcpy(ss.lits + ss.nlits, src + srcSize - lastLLSize, lastLLSize);
+            PROF_ADD(7, t_ll);
+            ss.nlits += lastLLSize;
+            wv_mem_sync_inv(); // sequence records / literals written by other lanes have landed
+            cSize = entropy_compress_seqstore(ss, &g_lds.ent[p], &g_lds.ent[nx], ms.cp.strategy, dst, dstCap, srcSize);
+        }
+        SQ_TRACE(0, 9);
+        SQ_TRACE(5, cSize);
+        if (is_err(cSize)) return cSize;
+        if (!bs.isFirstBlock && cSize < 25 && wv_is_rle(src, srcSize)) {
+            cSize = 1;
+            gst8(dst, srd8(src));
+        }
     }
     if (cSize > 1) bs.prevIdx ^= 1; // ZSTD_blockState_confirmRepcodesAndEntropyTables
     // offcode_repeatMode valid -> check: REP_VALID never occurs without a dictionary
     return cSize;
-}
-
-// ZSTD_buildSeqStore + ZSTD_compressBlock_internal: returns body size; 0 => raw; 1 => RLE
-SQ_DEVFN u32 compressBlock_internal(MatchState& ms, SeqStore& ss, BlockState& bs, void* optState, u8* dst,
-                                    u32 dstCap, const u8* src, u32 srcSize) {
-    if (srcSize < 1 + 1 + 3 + 1 + 1) return 0; // ZSTDbss_noCompress
-    u32 const lastLLSize = cb_find<false>(ms, ss, bs, optState, src, srcSize);
-    return cb_emit(ms.cp.strategy, ss, bs, dst, dstCap, src, srcSize, lastLLSize);
 }
 
 // State of a wave's hash-table area across the chunks of one launch.  gen == 0: the area holds
@@ -479,7 +462,6 @@ SQ_DEVFN u32 compress_frame_wave(const u8* src, u32 n, u8* dst, u32 cap, u8* ws,
     ss.stBits = (u16*)(ws + L.stBits);
     ss.nseq = ss.nlits = 0;
     ss.longLengthType = ss.longLengthPos = 0;
-    ss.recordsOnly = 0;
     WV_SERIAL {
         entropy_reset(&g_lds.ent[0]);
         entropy_reset(&g_lds.ent[1]);
@@ -587,304 +569,6 @@ SQ_DEVFN u32 compress_frame_wave(const u8* src, u32 n, u8* dst, u32 cap, u8* ws,
     return (u32)(op - dst);
 }
 
-// ---------------------------------------------------------------- the lazy2 size class cut in two kernels
-// Chunks above 256 KiB (lazy2 + row hash, sq_zstd_rowbatch.h) spend > 90 % of their time in the match finder, whose
-// throughput grows with the number of resident waves (it waits on dependent random reads); the entropy stage is what
-// pins k_compress_batch to 8 waves per CU (19.5 KB of LDS, 256 registers).  So the path is cut where the reference's
-// ZSTD_compressBlock_internal is cut (ZSTD_buildSeqStore | ZSTD_entropyCompressSeqStore):
-//   k_find_batch  (12 waves per CU: SQZ_LDS_FIND_BYTES of LDS, <= 168 registers) runs the parser over ALL blocks of a
-//                 chunk and leaves one record per block + the sequence records (8 B each) in the chunk's find area;
-//   k_emit_batch  (8 waves per CU) turns the records into the frame: literals gathered from the source, entropy
-//                 stage, block headers -- byte for byte what compress_frame_wave does after its finder call.
-// What the finder cannot know is what the entropy stage decides, and two of those decisions feed back into it:
-//   (1) a block emitted raw / RLE does not confirm its repcodes (ZSTD_blockState_confirmRepcodesAndEntropyTables):
-//       the finder assumes that a block of equal bytes (other than the first) is emitted RLE and every other block with
-//       sequences compressed;
-//   (2) the pre-block splitter only runs once the frame has saved 3 bytes (ZSTD_optimalBlockSize, `savings`): the
-//       finder estimates the savings from what it knows (sequences, literal bytes) and records what it assumed.
-// k_emit_batch knows the truth and checks both per block; a chunk where an assumption mattered and was wrong is left
-// without a frame (frame length 0) and k_compress_batch compresses it the one-kernel way afterwards.  Results are
-// therefore identical by construction; the assumptions only decide how often the work is done twice.
-#define SQZ_FIND_MAXBLOCKS 264u // 2 MiB / 8 KiB (the splitter's smallest cut) + slack
-#define SQZ_FIND_HDR_WORDS 8u
-#define SQZ_FIND_REC_WORDS 8u   // blockSize, nseq, lastLL, longType | longPos << 2, seqStart, flags, splitSize, -
-#define SQZ_FIND_F_SPLIT_ON 1u  // the block was sized by the splitter (savings >= 3 assumed)
-#define SQZ_FIND_F_RLE 2u       // all bytes equal, not the first block: assumed to be emitted as an RLE block
-SQ_HD size_t find_seq_cap(u32 n) { return (size_t)n / 4 + SQZ_FIND_MAXBLOCKS + 64; }
-SQ_HD size_t find_area_bytes(u32 n) {
-    return ws_align(((size_t)SQZ_FIND_HDR_WORDS + (size_t)SQZ_FIND_REC_WORDS * SQZ_FIND_MAXBLOCKS) * 4 + find_seq_cap(n) * 8);
-}
-SQ_DEV SeqDef* find_area_seqs(u32* area) { return (SeqDef*)(area + SQZ_FIND_HDR_WORDS + SQZ_FIND_REC_WORDS * SQZ_FIND_MAXBLOCKS); }
-
-// The finder half.  area[0] = 1 when every block of the chunk has its record, 2 when the chunk must take the
-// one-kernel path (too many blocks, a finder fault).
-SQ_DEVFN void find_frame_wave(const u8* src, u32 n, u8* ws, const WsLayout& L, u32* area) {
-    MatchState ms;
-    SeqStore ss;
-    BlockState bs;
-    CParams const cp = get_cparams(n);
-    WV_SERIAL { g_lds.trace = (u32*)(ws + L.dummy) + 8; }
-    wv_mem_sync_inv();
-    ms.cp = cp;
-    ms.base = src - SQZ_WINDOW_START;
-    ms.nextToUpdate = SQZ_WINDOW_START;
-    ms.lazySkipping = 0;
-    ms.fault = 0;
-    ms.hashTable = (u32*)(ws + L.hashTable);
-    ms.chainTable = (u32*)(ws + L.table2);
-    ms.tagTable = ws + L.table2;
-    ms.hashTable3 = nullptr;
-    ms.dummy = (u32*)(ws + L.dummy);
-    ms.hashLog3 = 0;
-    ms.rowHashLog = cp.hashLog - 6;
-    ms.eager = 1;
-    ms.nRepairs = 0;
-    ms.anchorPos = SQZ_WINDOW_START;
-    ms.chunkEndPos = n + SQZ_WINDOW_START;
-    ms.blockEndPos = SQZ_WINDOW_START + (n < SQZ_BLOCKSIZE_MAX ? n : SQZ_BLOCKSIZE_MAX);
-    ms.sched = nullptr;
-    ms.liveList = ms.skipList = ms.blockTab = nullptr;
-    ms.schedTab = nullptr;
-    ms.certCnt0 = 0;
-    ms.tailTab = nullptr;
-    ms.tailTabClean = nullptr;
-    ms.tailTried = ms.tailAt = ms.tailSeqs = 0;
-    ms.nCert = ms.nCertDone = ms.certEnd = ms.certEnd1 = 0;
-    ms.nLive = ms.nSkip = ms.nBlocks = 0;
-    ms.specOff = 0;
-    ms.sbMax = 256;
-    ms.nxEnt = 1;
-    ms.nEpoch = ms.nSpecFail = ms.nReplay = 0;
-    ms.genBits = 0;
-    wv_fill32(ms.hashTable, 0, (size_t)1 << cp.hashLog);
-    ss.seqs = find_area_seqs(area);
-    ss.lits = nullptr;
-    ss.llCode = ss.ofCode = ss.mlCode = nullptr;
-    ss.stBits = nullptr;
-    ss.nseq = ss.nlits = 0;
-    ss.longLengthType = ss.longLengthPos = 0;
-    ss.recordsOnly = 1;
-    for (int k = 0; k < 2; k++) {
-        bs.rep[k][0] = 1;
-        bs.rep[k][1] = 4;
-        bs.rep[k][2] = 8;
-    }
-    bs.prevIdx = 0;
-    bs.isFirstBlock = 1;
-    wv_mem_sync();
-    const u8* ip = src;
-    u32 remaining = n, nBlocks = 0, seqStart = 0, status = 1;
-    s64 estSavings = 0; // a lower bound in spirit: literals priced as incompressible, three bytes per sequence
-    // (every value that steers this loop is made wave-uniform explicitly -- wv_uni -- so that hipcc keeps the loop and
-    // its calls under scalar control: ms / ss / bs live in per-lane scratch across the out-of-line parser call)
-    while (remaining) {
-        if (nBlocks >= SQZ_FIND_MAXBLOCKS) {
-            status = 2;
-            break;
-        }
-        SQ_TRACE(0, 100 + nBlocks);
-        SQ_TRACE(2, (u32)(ip - src));
-        u32 blockSize = remaining < SQZ_BLOCKSIZE_MAX ? remaining : SQZ_BLOCKSIZE_MAX, flags = 0, splitSize = 0;
-        if (remaining >= SQZ_BLOCKSIZE_MAX && estSavings >= 3) {
-            splitSize = wv_uni(splitBlock_byChunks(ip, (Fingerprint*)(ws + L.fp)));
-            blockSize = splitSize;
-            flags |= SQZ_FIND_F_SPLIT_ON;
-        }
-        if (ms.nextToUpdate < SQZ_WINDOW_START) ms.nextToUpdate = SQZ_WINDOW_START;
-        u32 lastLL = blockSize, nseq = 0, lng = 0, nlits = 0;
-        if (blockSize >= 1 + 1 + 3 + 1 + 1) {
-            if (!bs.isFirstBlock && wv_uni(wv_is_rle(ip, blockSize))) flags |= SQZ_FIND_F_RLE;
-            ss.seqs = find_area_seqs(area) + seqStart;
-            lastLL = wv_uni(cb_find<true>(ms, ss, bs, nullptr, ip, blockSize));
-            SQ_TRACE(9, 1);
-            if (wv_uni(ms.fault)) {
-                status = 2;
-                break;
-            }
-            SQ_TRACE(9, 2);
-            nseq = wv_uni(ss.nseq);
-            nlits = wv_uni(ss.nlits);
-            lng = wv_uni(ss.longLengthType | (ss.longLengthPos << 2));
-            // assumption (1): emitted compressed -- the repcodes it leaves are confirmed -- unless it is a run of one byte
-            // (irrelevant when it has no sequence)
-            if (!(flags & SQZ_FIND_F_RLE)) bs.prevIdx ^= 1;
-        }
-        SQ_TRACE(9, 3);
-        u32* const rec = area + SQZ_FIND_HDR_WORDS + SQZ_FIND_REC_WORDS * nBlocks;
-        gst32(rec + 0, blockSize);
-        gst32(rec + 1, nseq);
-        gst32(rec + 2, lastLL);
-        gst32(rec + 3, lng);
-        gst32(rec + 4, seqStart);
-        gst32(rec + 5, flags);
-        gst32(rec + 6, splitSize);
-        gst32(rec + 7, 0);
-        estSavings += nseq ? (s64)blockSize - (s64)(nlits + lastLL) - 3 * (s64)nseq - 3 : -3;
-        seqStart += nseq;
-        nBlocks++;
-        ip += blockSize;
-        remaining -= blockSize;
-        bs.isFirstBlock = 0;
-        SQ_TRACE(9, 4);
-        SQ_TRACE(10, remaining);
-    }
-    SQ_TRACE(9, 5);
-    wv_mem_sync();
-    SQ_TRACE(9, 6);
-    gst32(area + 1, nBlocks);
-    gst32(area + 0, status);
-    wv_mem_sync();
-    SQ_TRACE(9, 7);
-}
-
-// One block's literal position list (ss.stBits) and literal buffer from its sequence records: what storeSeq_deferred
-// and gather_literals produce inside the parser in the one-kernel path.  blockPos: index of the block's first byte.
-SQ_DEVFN void emit_prepare_block(SeqStore& ss, const u8* base, u32 blockPos) {
-    u32* const posList = (u32*)ss.stBits;
-    u32 pos = blockPos, lit = 0;
-#if SQ_ON_DEVICE
-    u32 const lane = wv_lane();
-    for (u32 s0 = 0; s0 < ss.nseq; s0 += 64) {
-        u32 const s = s0 + lane;
-        u32 ll = 0, ml = 0;
-        if (s < ss.nseq) {
-            u32 const w = sq_gld32((const u32*)&ss.seqs[s] + 1);
-            ll = w & 0xFFFF;
-            ml = (w >> 16) + SQZ_MINMATCH;
-            if (ss.longLengthPos == s) {
-                if (ss.longLengthType == 1) ll += 0x10000;
-                if (ss.longLengthType == 2) ml += 0x10000;
-            }
-        }
-        u32 totL, totA;
-        u32 const exL = wv_excl_scan(ll, &totL), exA = wv_excl_scan(ll + ml, &totA);
-        if (s < ss.nseq) sq_gst64v(posList + 2 * (size_t)s, pos + exA, lit + exL);
-        pos += totA;
-        lit += totL;
-    }
-#else
-    for (u32 s = 0; s < ss.nseq; s++) {
-        u32 ll = ss.seqs[s].litLength, ml = (u32)ss.seqs[s].mlBase + SQZ_MINMATCH;
-        if (ss.longLengthPos == s) {
-            if (ss.longLengthType == 1) ll += 0x10000;
-            if (ss.longLengthType == 2) ml += 0x10000;
-        }
-        posList[2 * (size_t)s] = pos;
-        posList[2 * (size_t)s + 1] = lit;
-        pos += ll + ml;
-        lit += ll;
-    }
-#endif
-    ss.nlits = lit;
-    gather_literals(ss, base);
-}
-
-// The emitting half: the frame of a chunk whose blocks the finder left in `area`.  Returns the frame length; 0 when an
-// assumption of the finder did not hold (or on any error): the chunk then takes the one-kernel path.
-#if SQ_ON_DEVICE
-#define EMIT_FAIL(code) do { SQ_TRACE(40, code); return 0; } while (0)
-#else
-#define EMIT_FAIL(code) do { if (getenv("SQ_SIM_STATS")) fprintf(stderr, "[sim] emit refuses: reason %d at block %u of %u (savings %lld)\n", code, b_, nBlocks_, (long long)sav_); return 0; } while (0)
-#endif
-SQ_DEVFN u32 emit_frame_wave(const u8* src, u32 n, u8* dst, u32 cap, u8* ws, const WsLayout& L, const u32* area) {
-    SeqStore ss;
-    BlockState bs;
-    CParams const cp = get_cparams(n);
-    u8* op = dst;
-    u8* const oend = dst + cap;
-#if !SQ_ON_DEVICE
-    u32 b_ = ~0u, nBlocks_ = 0; // (for EMIT_FAIL's message)
-    s64 sav_ = 0;
-#endif
-    WV_SERIAL { g_lds.trace = (u32*)(ws + L.dummy) + 8; }
-    wv_mem_sync_inv();
-    if (cap < 18 || gld32(area) != 1) EMIT_FAIL(1);
-    u32 const nBlocks = gld32(area + 1);
-    u32 const hdr = fast_frame_header(dst, n);
-    op += hdr;
-    ss.lits = ws + L.lits;
-    ss.llCode = ws + L.llCode;
-    ss.ofCode = ws + L.ofCode;
-    ss.mlCode = ws + L.mlCode;
-    ss.stBits = (u16*)(ws + L.stBits);
-    ss.recordsOnly = 0;
-    WV_SERIAL {
-        entropy_reset(&g_lds.ent[0]);
-        entropy_reset(&g_lds.ent[1]);
-    }
-    bs.prevIdx = 0;
-    bs.isFirstBlock = 1;
-    wv_mem_sync();
-    const u8* ip = src;
-    u32 remaining = n;
-    s64 savings = 0;
-    for (u32 b = 0; b < nBlocks; b++) {
-        const u32* const rec = area + SQZ_FIND_HDR_WORDS + SQZ_FIND_REC_WORDS * b;
-        u32 const blockSize = gld32(rec), nseq = gld32(rec + 1), lastLL = gld32(rec + 2), lng = gld32(rec + 3),
-                  seqStart = gld32(rec + 4), flags = gld32(rec + 5);
-#if !SQ_ON_DEVICE
-        b_ = b, nBlocks_ = nBlocks, sav_ = savings;
-#endif
-        SQ_TRACE(0, 200 + b);
-        SQ_TRACE(2, (u32)(ip - src));
-        if (blockSize == 0 || blockSize > remaining) EMIT_FAIL(2);
-        // assumption (2): was the block sized the way ZSTD_optimalBlockSize sizes it with the true savings?
-        if (remaining >= SQZ_BLOCKSIZE_MAX) {
-            bool const splitOn = savings >= 3;
-            if (splitOn != ((flags & SQZ_FIND_F_SPLIT_ON) != 0)) {
-                // the finder took the other branch: fine when both give the same size
-                u32 const want = splitOn ? wv_uni(splitBlock_byChunks(ip, (Fingerprint*)(ws + L.fp))) : SQZ_BLOCKSIZE_MAX;
-                if (want != blockSize) EMIT_FAIL(3);
-            }
-        } else if (blockSize != remaining)
-            EMIT_FAIL(4);
-        u32 const lastBlock = (blockSize == remaining);
-        if ((u32)(oend - op) < 3 + 2 + 1) EMIT_FAIL(5);
-        u32 cSize = 0;
-        if (blockSize >= 1 + 1 + 3 + 1 + 1) {
-            ss.seqs = find_area_seqs(const_cast<u32*>(area)) + seqStart;
-            ss.nseq = nseq;
-            ss.nlits = 0;
-            ss.longLengthType = lng & 3;
-            ss.longLengthPos = lng >> 2;
-            if (nseq) emit_prepare_block(ss, src - SQZ_WINDOW_START, (u32)(ip - src) + SQZ_WINDOW_START);
-            cSize = wv_uni(cb_emit(cp.strategy, ss, bs, op + 3, (u32)(oend - op) - 3, ip, blockSize, lastLL));
-            if (is_err(cSize)) EMIT_FAIL(6);
-        }
-        // assumption (1): a block with sequences that is NOT emitted compressed leaves other repcodes to the next block
-        if (nseq && !lastBlock && (cSize > 1) != !(flags & SQZ_FIND_F_RLE)) EMIT_FAIL(7);
-        if (cSize == 0) { // ZSTD_noCompressBlock
-            u32 const h = lastBlock + (0u << 1) + (blockSize << 3);
-            if (blockSize + 3 > (u32)(oend - op)) EMIT_FAIL(8);
-            WV_SERIAL {
-                op[0] = (u8)h;
-                op[1] = (u8)(h >> 8);
-                op[2] = (u8)(h >> 16);
-            }
-            wv_memcpy(op + 3, ip, blockSize);
-            cSize = 3 + blockSize;
-        } else {
-            u32 const h = (cSize == 1) ? lastBlock + (1u << 1) + (blockSize << 3) : lastBlock + (2u << 1) + (cSize << 3);
-            WV_SERIAL {
-                op[0] = (u8)h;
-                op[1] = (u8)(h >> 8);
-                op[2] = (u8)(h >> 16);
-            }
-            cSize += 3;
-        }
-        savings += (s64)blockSize - (s64)cSize;
-        ip += blockSize;
-        remaining -= blockSize;
-        op += cSize;
-        bs.isFirstBlock = 0;
-        SQ_TRACE(7, 300 + b);
-    }
-    if (remaining) EMIT_FAIL(9);
-    SQ_TRACE(7, 400);
-    wv_fence();
-    return (u32)(op - dst);
-}
-
 #if SQ_ON_DEVICE
 // One chunk -> one frame in its output slot (kept out of line: keeps the queue loop simple).
 __device__ __noinline__ void compress_one(const u8* data, const u64* off, const u32* len, u32 idx, u8* slots,
@@ -905,7 +589,7 @@ __device__ __noinline__ void compress_one(const u8* data, const u64* off, const 
 __global__ void __launch_bounds__(64, 2) // 2 waves per SIMD: <= 256 registers, 8 waves per CU (LDS: 8 x 19 KiB)
 k_compress_batch(const u8* data, const u64* off, const u32* len, const u8* select, u32 n, u8* slots,
                  const u64* slot_off, u32* frame_len, u8* ws_pool, u64 ws_each, u32* queue, u32* err,
-                 const u32* schedTab, const u32* certHint, u32 persist, const u32* work, const u64* find_off) {
+                 const u32* schedTab, const u32* certHint, u32 persist, const u32* work) {
     u8* const ws = ws_pool + (u64)blockIdx.x * ws_each;
     u32* const dbg = (u32*)(ws + ws_each - 256) + 8; // wave-level progress words for the watchdog
     u32 iter = 0;
@@ -920,7 +604,6 @@ k_compress_batch(const u8* data, const u64* off, const u32* len, const u8* selec
         tg.tailTabClean = gld32(saved + 2);
     }
 #ifdef SQ_PROF
-    if (wv_lane() == 0) atomicAdd(queue + 44, 1u); // b_misc[44]
     unsigned long long const t_kernel0 = __builtin_amdgcn_s_memrealtime();
     if (wv_lane() == 0)
         for (int k = 0; k < 32; k++) g_lds.prof[k] = 0;
@@ -946,8 +629,7 @@ k_compress_batch(const u8* data, const u64* off, const u32* len, const u8* selec
             u32 const idx = list ? gld32(list + q) : q;
             // (the lists hold what stage 1 left undecided: of the selected chunks in the split form, of ALL chunks in the
             // fused form, where stage 1 runs before the dedup decision -- duplicates are skipped here)
-            bool take = (select == nullptr) || (select[idx] != 0);
-            if (find_off && take && find_off[idx] != ~0ull && frame_len[idx] != 0) take = false; // k_emit_batch made its frame
+            bool const take = (select == nullptr) || (select[idx] != 0);
             PROF_T0(t_all);
 #ifdef SQ_PROF
             if (wv_lane() == 0)
@@ -971,9 +653,6 @@ k_compress_batch(const u8* data, const u64* off, const u32* len, const u8* selec
         }
     }
     if (wv_lane() == 0) {
-#ifdef SQ_PROF
-        atomicAdd(queue + 45, 1u); // b_misc[45]
-#endif
         dbg[11] = 777;
         saved[0] = tg.gen;
         saved[1] = tg.windowLog;
@@ -987,81 +666,6 @@ k_compress_batch(const u8* data, const u64* off, const u32* len, const u8* selec
         o[32] = iter;
         for (int k = 0; k < 29; k++) o[42 + k] = g_lds.profLong[k];
     }
-#endif
-}
-
-// (out of line, like compress_one: the queue loops below stay small)
-__device__ __noinline__ void find_one(const u8* data, const u64* off, const u32* len, u32 idx, u8* ws, u8* area) {
-    u32 const L = len[idx];
-    WsLayout const lay = ws_layout(L);
-    find_frame_wave(data + off[idx], L, ws, lay, (u32*)area);
-}
-__device__ __noinline__ void emit_one(const u8* data, const u64* off, const u32* len, u32 idx, u8* slots, const u64* slot_off,
-                                      u32* frame_len, u8* ws, const u8* area, u32* stats) {
-    u32 const L = len[idx];
-    WsLayout const lay = ws_layout(L);
-    u64 const so = slot_off[idx];
-    u32 const cap = (u32)(slot_off[idx + 1] - so);
-    u32 const r = emit_frame_wave(data + off[idx], L, slots + so, cap, ws, lay, (const u32*)area);
-    if (wv_lane() == 0) {
-        frame_len[idx] = r; // 0: the chunk stays on k_compress_batch's plate
-        atomicAdd(stats + (r ? 0 : 1), 1u);
-    }
-}
-
-// The two kernels of the lazy2 size class (see "the lazy2 size class cut in two kernels" above).  Both walk the same
-// lists as k_compress_batch (stage 1's work lists, or every index) with counters of their own and touch only chunks
-// that have a find area (find_off[idx] != ~0: selected by the host for this path).
-__global__ void __launch_bounds__(64, 3) // 12 waves per CU: <= 168 registers, SQZ_LDS_FIND_BYTES of LDS each
-k_find_batch(const u8* data, const u64* off, const u32* len, const u8* select, u32 n, u8* ws_pool, u64 ws_each,
-             u32* queue, const u32* work, const u64* find_off, u8* find_pool) {
-    u8* const ws = ws_pool + (u64)blockIdx.x * ws_each;
-#ifdef SQ_PROF
-    if (wv_lane() == 0) atomicAdd(queue + 36, 1u); // b_misc[40]: waves that entered
-#endif
-    for (u32 pass = work ? 0u : 1u; pass < 2; pass++) {
-        u32 const count = work ? gld32(work + pass) : n;
-        const u32* const list = work ? work + 2 + (pass ? n : 0u) : nullptr;
-        for (;;) {
-            u32 q = 0;
-            if (wv_lane() == 0) q = atomicAdd(queue + pass, 1u);
-            q = wv_uni(q);
-            if (q >= count) break;
-            u32 const idx = list ? gld32(list + q) : q;
-            u64 const fo = find_off[idx];
-            if (fo == ~0ull || (select != nullptr && select[idx] == 0)) continue;
-            find_one(data, off, len, idx, ws, find_pool + fo);
-        }
-    }
-#ifdef SQ_PROF
-    if (wv_lane() == 0) atomicAdd(queue + 37, 1u); // b_misc[41]: waves that left
-#endif
-}
-
-__global__ void __launch_bounds__(64, 2)
-k_emit_batch(const u8* data, const u64* off, const u32* len, const u8* select, u32 n, u8* slots, const u64* slot_off,
-             u32* frame_len, u8* ws_pool, u64 ws_each, u32* queue, const u32* work, const u64* find_off,
-             const u8* find_pool, u32* stats) {
-    u8* const ws = ws_pool + (u64)blockIdx.x * ws_each;
-#ifdef SQ_PROF
-    if (wv_lane() == 0) atomicAdd(queue + 36, 1u); // b_misc[42]
-#endif
-    for (u32 pass = work ? 0u : 1u; pass < 2; pass++) {
-        u32 const count = work ? gld32(work + pass) : n;
-        const u32* const list = work ? work + 2 + (pass ? n : 0u) : nullptr;
-        for (;;) {
-            u32 q = 0;
-            if (wv_lane() == 0) q = atomicAdd(queue + pass, 1u);
-            q = wv_uni(q);
-            if (q >= count) break;
-            u32 const idx = list ? gld32(list + q) : q;
-            u64 const fo = find_off[idx];
-            if (fo == ~0ull || (select != nullptr && select[idx] == 0)) continue;
-            emit_one(data, off, len, idx, slots, slot_off, frame_len, ws, find_pool + fo, stats);
-        }
-    }
-#ifdef SQ_PROF
-    if (wv_lane() == 0) atomicAdd(queue + 37, 1u); // b_misc[43]
 #endif
 }
 #endif

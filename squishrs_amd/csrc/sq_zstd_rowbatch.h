@@ -530,16 +530,14 @@ SQ_DEV void storeSeq_deferred(SeqStore& ss, u32 litLength, u32 litPos, u32 offBa
 #if SQ_ON_DEVICE
     if (wv_lane() == 0) {
         sq_gst64v((u32*)&ss.seqs[ss.nseq], offBase, (litLength & 0xFFFF) | (mlBase << 16));
-        if (!ss.recordsOnly) sq_gst64v(posList + 2 * (size_t)ss.nseq, litPos, ss.nlits);
+        sq_gst64v(posList + 2 * (size_t)ss.nseq, litPos, ss.nlits);
     }
 #else
     ss.seqs[ss.nseq].offBase = offBase;
     ss.seqs[ss.nseq].litLength = (u16)litLength;
     ss.seqs[ss.nseq].mlBase = (u16)mlBase;
-    if (!ss.recordsOnly) {
-        posList[2 * (size_t)ss.nseq] = litPos;
-        posList[2 * (size_t)ss.nseq + 1] = ss.nlits;
-    }
+    posList[2 * (size_t)ss.nseq] = litPos;
+    posList[2 * (size_t)ss.nseq + 1] = ss.nlits;
 #endif
     ss.nlits += litLength;
     ss.nseq++;
@@ -818,12 +816,12 @@ SQ_DEV u32 compressBlock_lazy_rb_impl(MatchState& ms, SeqStore& ss, u32* rep, co
     rep[0] = offset_1 ? offset_1 : offsetSaved1;
     rep[1] = offset_2 ? offset_2 : offsetSaved2;
     PROF_T0(t_gl);
-    if (!ss.recordsOnly) gather_literals(ss, base);
+    gather_literals(ss, base);
     PROF_ADD(11, t_gl);
     return iendPos - anchor;
 }
 
-SQ_NOINLINE u32 compressBlock_lazy_rowbatch(MatchState& ms, SeqStore& ss, u32* rep, const u8* src, u32 srcSize) {
+SQ_DEVFN u32 compressBlock_lazy_rowbatch(MatchState& ms, SeqStore& ss, u32* rep, const u8* src, u32 srcSize) {
 #if SQ_ON_DEVICE
     MatchState lm = ms; // a private copy: its fields stay in registers (see compressBlock_lazy)
     u32 const r = compressBlock_lazy_rb_impl(lm, ss, rep, src, srcSize);

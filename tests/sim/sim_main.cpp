@@ -3,8 +3,6 @@
 // body, so the uniform control logic can be diffed against the oracle on a machine without a
 // GPU.  Never linked into libsquish_gpu.so; not a fallback for anything.
 #define SQ_SIM 1
-#include <stdio.h>
-#include <stdlib.h>
 #include "../../squishrs_amd/csrc/sq_zstd_kernel.h"
 #include <stdio.h>
 #include <stdlib.h>
@@ -85,35 +83,6 @@ extern "C" size_t sim_compress_two_stage(const uint8_t* src, size_t n, uint8_t* 
     sqz::TableGen tg = {0, 0, 0};
     r = sqz::compress_frame_wave(src, (u32)n, dst, (u32)cap, wsa, L, tg, sched_tab(), hint);
     free(ws);
-    return r;
-}
-// The lazy2 size class through its two kernels' bodies (find_frame_wave, then emit_frame_wave on separately poisoned
-// workspace and LDS, as two launches leave them), falling back to the one-kernel path when the emitting half refuses.
-// *emitted = 1 when the two-kernel path produced the frame; *blocks = number of block records.
-extern "C" size_t sim_compress_split(const uint8_t* src, size_t n, uint8_t* dst, size_t cap, int* emitted, int* blocks) {
-    sqz::WsLayout L = sqz::ws_layout((u32)n);
-    size_t const abytes = sqz::find_area_bytes((u32)n);
-    u8* area = (u8*)malloc(abytes + 256);
-    memset(area, 0xE7, abytes + 256);
-    u32* const a32 = (u32*)(((uintptr_t)area + 255) & ~(uintptr_t)255);
-    u8* ws = (u8*)malloc(L.total + 256 + 1024);
-    memset(ws, 0xA5, L.total + 256 + 1024);
-    memset(&sqz::g_lds, 0x5A, sizeof(sqz::g_lds));
-    u8* wsa = (u8*)(((uintptr_t)ws + 255) & ~(uintptr_t)255);
-    sqz::find_frame_wave(src, (u32)n, wsa, L, a32);
-    *blocks = (int)a32[1];
-    memset(ws, 0x3C, L.total + 256 + 1024); // another wave's workspace, another launch's LDS
-    memset(&sqz::g_lds, 0x69, sizeof(sqz::g_lds));
-    u32 r = sqz::emit_frame_wave(src, (u32)n, dst, (u32)cap, wsa, L, a32);
-    *emitted = r != 0;
-    if (!r) {
-        memset(ws, 0xA5, L.total + 256 + 1024);
-        memset(&sqz::g_lds, 0x5A, sizeof(sqz::g_lds));
-        sqz::TableGen tg = {0, 0, 0};
-        r = sqz::compress_frame_wave(src, (u32)n, dst, (u32)cap, wsa, L, tg, sched_tab(), nullptr);
-    }
-    free(ws);
-    free(area);
     return r;
 }
 // The arithmetic that tells the scan which positions are scheduled ones (fast_sched_mask) against the

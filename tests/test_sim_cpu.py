@@ -52,39 +52,6 @@ def test_sim_matches_oracle(sim, oracle, kind, seed, n):
     assert _sim_compress(sim, d) == oracle.compress_chunk(d)
 
 
-# The lazy2 size class cut in two kernels (k_find_batch + k_emit_batch): the finder's two assumptions about the entropy
-# stage, checked by the emitter, with the one-kernel path behind them.
-SPLIT_CASES = [("mixed", 5, 2097152), ("mixed", 2, 600000), ("text", 3, 1048577), ("random", 4, 2097152), ("records", 25, 1500000),
-               ("runs", 26, 2097152), ("skewed", 27, 700000), ("zeros", 23, 262145), ("text", 24, 262145), ("mixed", 28, 1000003),
-               ("planted4", 29, 300000), ("skewed", 30, 2097152), ("mixed", 31, 2097152), ("mixed", 32, 1500000),
-               ("rand_then_text", 0, 1048576), ("text_then_rand", 0, 1048576), ("skewed_then_text", 0, 1048576)]
-
-
-def _split_input(kind, seed, n):
-    if kind == "rand_then_text":      # raw blocks first (savings go negative), then compressible blocks the splitter would cut
-        return corpus.random_bytes(7, 7, n // 2) + corpus.make("mixed", 8, n - n // 2)
-    if kind == "text_then_rand":
-        return corpus.make("text", 9, n // 2) + corpus.random_bytes(7, 9, n - n // 2)
-    if kind == "skewed_then_text":    # blocks without sequences that still compress (Huffman): the finder's estimate is wrong
-        return corpus.make("skewed", 11, n // 2) + corpus.make("mixed", 12, n - n // 2)
-    return corpus.make(kind, seed, n)
-
-
-@pytest.mark.parametrize("kind,seed,n", SPLIT_CASES)
-def test_sim_split_path_matches_oracle(sim, oracle, kind, seed, n):
-    sim.sim_compress_split.restype = ctypes.c_size_t
-    sim.sim_compress_split.argtypes = [ctypes.c_char_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_size_t,
-                                       ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int)]
-    d = _split_input(kind, seed, n)
-    cap = len(d) + (len(d) >> 8) + 1024
-    dst = ctypes.create_string_buffer(cap)
-    emitted, blocks = ctypes.c_int(0), ctypes.c_int(0)
-    m = sim.sim_compress_split(d, len(d), dst, cap, ctypes.byref(emitted), ctypes.byref(blocks))
-    assert dst.raw[:m] == oracle.compress_chunk(d)
-    assert blocks.value >= (n + 131071) // 131072 or not emitted.value
-    print(f"{kind} {n}: emitted={emitted.value} blocks={blocks.value}")
-
-
 def test_lds_budget_allows_8_waves_per_cu(sim):
     # 160 KiB of LDS per CU, one wave per workgroup
     assert sim.sim_lds_bytes() * 8 <= 160 * 1024

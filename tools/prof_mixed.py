@@ -52,5 +52,5 @@ if __name__ == "__main__":
         assert fr == o.compress_chunk(chunks[i % k]), f"frame {i} differs from the oracle"
     ratio = float(ln.astype(np.uint64).sum()) / (n * L)
     print(f"{n} x {L} B {kind}: ratio {ratio:.3f}, {dt * 1e3:.1f} ms = {n * L / 2**20 / dt:.0f} MiB/s "
-          f"({n * L / 2**20 / dt / min(n, 2048):.2f} MiB/s per wave; stage 1 {t.fast_ms:.1f} ms, stage 2 {t.compress_ms:.1f} ms; two-kernel path: {t.split_emitted} emitted, {t.split_left} left to k_compress_batch); 4 frames bit-exact", flush=True)
+          f"({n * L / 2**20 / dt / min(n, 2048):.2f} MiB/s per wave; stage 1 {t.fast_ms:.1f} ms, stage 2 {t.compress_ms:.1f} ms); 4 frames bit-exact", flush=True)
     st.close()
