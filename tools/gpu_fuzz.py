@@ -18,7 +18,8 @@ import oracle_lib
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 1500
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 rng = np.random.default_rng(seed)
-kinds = ["text", "records", "runs", "skewed", "mixed", "random", "zeros", "planted0", "planted3", "planted6", "planted9"]
+kinds = ["text", "records", "runs", "skewed", "mixed", "random", "zeros", "planted0", "planted3", "planted6", "planted9",
+         "plantedL1", "plantedL4", "plantedL7", "random"]   # plantedL*: chunks above 256 KiB (stage 1's certificate per block pair)
 edges = [1, 2, 7, 8, 9, 255, 256, 257, 16383, 16384, 16385, 40960, 65535, 65536, 65537, 131071, 131072, 131073, 131080,
          262143, 262144, 262145, 262160, 393216, 524288, 524289, 1048575, 1048576, 2097151, 2097152]
 
@@ -43,9 +44,14 @@ def make(i):
             j += 1
         return b"".join(parts)[:size]
     k = kinds[int(r.integers(0, len(kinds)))]
-    if k.startswith("planted") and size < 20000:
+    if k.startswith("plantedL") and size <= 300000:
         k = "random"
-    return corpus.make(k, seed * 13 + i, size)
+    elif k.startswith("planted") and not k.startswith("plantedL") and (size < 20000 or size > 262144):
+        k = "random"
+    try:
+        return corpus.make(k, seed * 13 + i, size)
+    except IndexError:      # plantedL*: the last block is too short to hold the plant
+        return corpus.make("random", seed * 13 + i, size)
 
 
 t0 = time.time()
