@@ -57,6 +57,8 @@ struct RowBatch {
     u64 ownPrev;                // per lane: the 8 bytes in front of it
 #else
     u32 ml[64], off[64], rl[64], be[64], flags[64];
+    u64 imask[64], tmask[64];
+    u32 head[64], rowId[64], cnt[64];
 #endif
     u32 B0, n, valid, off1; // wave-uniform
     u32 ldsOk;              // wave-uniform: the lanes' source bytes are in LDS (g_lds.grp; clobbered by an insertion sweep)
@@ -440,7 +442,9 @@ SQ_DEV void rb_refresh(const MatchState& ms, RowBatch& bt, u32 off1, u32 iendPos
         bt.rl[i] = rl;
     }
 }
-SQ_DEV void rb_eval(MatchState&, RowBatch&, u32, u32) {} // (the simulator's rb_prepare evaluates every lane)
+// rb_prepare: per lane the candidate masks exactly as the device computes them (in-batch lanes with the same row and
+// tag; the row's tag matches by recency rank minus the r entries the batch itself will have overwritten) -- nothing is
+// evaluated here.
 SQ_DEVFN void rb_prepare(MatchState& ms, RowBatch& bt, u32 B0, u32 n, u32 off1, u32 iendPos) {
     const u8* const base = ms.base;
     bt.B0 = B0;
@@ -450,66 +454,153 @@ SQ_DEVFN void rb_prepare(MatchState& ms, RowBatch& bt, u32 B0, u32 n, u32 off1, 
     for (u32 i = 0; i < 64; i++) {
         bt.ml[i] = 3;
         bt.off[i] = bt.be[i] = 0;
-        bt.flags[i] = SQZ_RB_DONE;
+        bt.flags[i] = 0;
+        bt.imask[i] = bt.tmask[i] = 0;
+        bt.head[i] = bt.rowId[i] = bt.cnt[i] = 0;
         hashes[i] = 0;
     }
     rb_refresh(ms, bt, off1, iendPos);
     for (u32 i = 0; i < n; i++) hashes[i] = hash5(sq_rd64(base + B0 + i), ms.rowHashLog + 8);
     for (u32 i = 0; i < n; i++) {
         u32 const q = B0 + i;
-        if (q + 32 > ms.chunkEndPos) {
-            bt.flags[i] |= SQZ_RB_EXACT;
+        if (q + 32 > ms.chunkEndPos) { // positions whose 32-byte windows would reach beyond the chunk go to the exact finder
+            bt.flags[i] = SQZ_RB_EXACT;
             continue;
         }
         u32 const hash = hashes[i], rowId = hash >> 8, tag = hash & 0xFF;
-        u32 cands[64], nc = 0, r = 0;
-        for (u32 j = i; j-- > 0;) {
+        u32 r = 0;
+        u64 imask = 0;
+        for (u32 j = 0; j < i; j++)
             if ((hashes[j] >> 8) == rowId) {
                 r++;
-                if ((hashes[j] & 0xFF) == tag) cands[nc++] = B0 + j;
+                if ((hashes[j] & 0xFF) == tag) imask |= 1ull << j;
             }
-        }
-        const u32* const row = ms.hashTable + ((size_t)rowId << 6);
         const u8* const tagRow = ms.tagTable + ((size_t)rowId << 6);
         u32 const head = tagRow[0] & 63u;
-        for (u32 rank = 0; rank + r < 63; rank++) {
+        u64 tmask = 0;
+        for (u32 rank = 0; rank + r < 63; rank++) { // the r oldest entries are overwritten by then
             u32 const slot = rb_slot_of(head, rank);
-            if (slot == 0 || tagRow[slot] != (u8)tag) continue;
-            u32 const idx = row[slot];
-            if (idx < SQZ_WINDOW_START) break;
-            if (idx >= q) {
-                ms.fault = 1;
-                break;
-            }
-            cands[nc++] = idx;
+            if (slot != 0 && tagRow[slot] == (u8)tag) tmask |= 1ull << rank;
         }
-        u32 const limitLen = iendPos - q;
-        u32 ml = 3, bestC = 0;
-        bool exact = false;
-        for (u32 k = 0; k < nc; k++) {
-            u32 len = 0;
-            while (len < 32 && len < limitLen && base[q + len] == base[cands[k] + len]) len++;
-            if (len >= 32 && limitLen > 32) {
-                exact = true;
-                break;
+        bt.imask[i] = imask;
+        bt.tmask[i] = tmask;
+        bt.head[i] = head;
+        bt.rowId[i] = rowId;
+        bt.cnt[i] = (u32)__builtin_popcountll(imask) + (u32)__builtin_popcountll(tmask);
+    }
+}
+
+// rb_eval: the device routine statement by statement over the SAME arrays (g_lds.u.rb: descriptors, candidate
+// positions, per-owner pair bases / first stoppers / best / "long candidate" flags), scalar loops in place of the lanes:
+// the window of owners one round of SQZ_RB_ROUND pairs allows, the descriptor listing (in-batch candidates most recent
+// first, then the row's by recency rank), the pairs' lengths from at most 32 bytes, first stopper = minimum order,
+// winner = maximum of (length, -order) in front of it, backward extension of the winner only.  The bounds the device
+// relies on are asserted here, so a sanitizer build of the simulator sees an out-of-range descriptor.
+#define SQZ_SIM_CHECK(c)                                                                                    \
+    do {                                                                                                    \
+        if (!(c)) {                                                                                         \
+            ms.fault = 1;                                                                                   \
+            __builtin_trap();                                                                               \
+        }                                                                                                   \
+    } while (0)
+SQ_DEVFN void rb_eval(MatchState& ms, RowBatch& bt, u32 i0, u32 iendPos) {
+    const u8* const base = ms.base;
+    u32 const B0 = bt.B0;
+    RbLds& R = g_lds.u.rb;
+    u32 pbase[64], cnt[64];
+    bool sel[64];
+    u32 run = 0;
+    for (u32 lane = 0; lane < 64; lane++) {
+        bool const cand_lane = lane >= i0 && lane < bt.n && !(bt.flags[lane] & SQZ_RB_EXACT);
+        u32 const mycnt = cand_lane ? bt.cnt[lane] : 0u;
+        pbase[lane] = run;
+        sel[lane] = lane >= i0 && lane < bt.n && run + mycnt <= SQZ_RB_ROUND && (lane < i0 + 3 || run + mycnt <= SQZ_RB_SPEC);
+        cnt[lane] = (sel[lane] && cand_lane) ? mycnt : 0u;
+        run += mycnt;
+        R.pbase[lane] = pbase[lane];
+        R.stop[lane] = 0xFFFFFFFFu;
+        R.best[lane] = 0;
+        R.flag[lane] = 0;
+        R.rowId[lane] = bt.rowId[lane];
+    }
+    u32 P = 0;
+    for (u32 o = 0; o < 64; o++) { // one pass per owner
+        if (!cnt[o]) continue;
+        u64 const im = bt.imask[o], tm = bt.tmask[o];
+        u32 const pb = pbase[o], nIn = (u32)__builtin_popcountll(im);
+        for (u32 lane = 0; lane < 64; lane++) {
+            u64 const above = (lane == 63) ? 0ull : (~0ull << (lane + 1));
+            u64 const below = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+            if ((im >> lane) & 1) {
+                u32 const at = pb + (u32)__builtin_popcountll(im & above);
+                SQZ_SIM_CHECK(at < SQZ_RB_PAIRS);
+                R.desc[at] = (u16)((o << 7) | 64u | lane);
             }
-            if (len > ml) {
-                ml = len;
-                bestC = cands[k];
-                if (len == limitLen) break;
+            if ((tm >> lane) & 1) {
+                u32 const at = pb + nIn + (u32)__builtin_popcountll(tm & below);
+                SQZ_SIM_CHECK(at < SQZ_RB_PAIRS);
+                R.desc[at] = (u16)((o << 7) | rb_slot_of(bt.head[o], lane));
             }
         }
-        if (exact) {
-            bt.flags[i] |= SQZ_RB_EXACT;
+        P = pb + nIn + (u32)__builtin_popcountll(tm);
+    }
+    SQZ_SIM_CHECK(P <= SQZ_RB_ROUND);
+    u32 len[SQZ_RB_PAIRS], ord[SQZ_RB_PAIRS], own[SQZ_RB_PAIRS];
+    bool has[SQZ_RB_PAIRS];
+    for (u32 p = 0; p < P; p++) { // the pairs: positions, stoppers, lengths
+        u32 const d = R.desc[p];
+        own[p] = (d >> 7) & 63u;
+        SQZ_SIM_CHECK(p >= R.pbase[own[p]]);
+        ord[p] = p - R.pbase[own[p]];
+        u32 c = B0 + (d & 63u);
+        if (!(d & 64u)) c = ms.hashTable[((size_t)R.rowId[own[p]] << 6) + (d & 63u)];
+        bool const ok = c >= SQZ_WINDOW_START && c < B0 + own[p];
+        has[p] = ok;
+        len[p] = 0;
+        if (!ok) { // an unwritten slot (reads 0) ends its owner's scan, as does an impossible index
+            if (ord[p] < R.stop[own[p]]) R.stop[own[p]] = ord[p];
+            if (c >= B0 + own[p]) ms.fault = 1;
             continue;
         }
-        bt.ml[i] = ml;
-        bt.off[i] = OFFSET_TO_OFFBASE(q - bestC);
-        if (ml > 3 && bestC >= 8 + SQZ_WINDOW_START && q >= 8 + SQZ_WINDOW_START) {
-            u32 be = 0;
-            while (be < SQZ_RB_BECAP && base[q - 1 - be] == base[bestC - 1 - be]) be++;
-            bt.be[i] = be;
+        u32 const q = B0 + own[p];
+        u32 l = 0;
+        while (l < 32 && base[q + l] == base[c + l]) l++; // (q + 32 <= chunk end for every owner: rb_prepare)
+        u32 const lim = iendPos - q;
+        if (l >= 32 && lim > 32) l = 255; // long: the exact finder extends and decides
+        else if (l > lim) l = lim;
+        len[p] = l;
+        R.cand[p] = c;
+    }
+    for (u32 p = 0; p < P; p++)
+        if (has[p] && ord[p] < R.stop[own[p]]) {
+            if (len[p] == 255) R.flag[own[p]] |= 1u;
+            else {
+                u32 const v = (len[p] << 8) | (255u - ord[p]);
+                if (v > R.best[own[p]]) R.best[own[p]] = v;
+            }
         }
+    for (u32 lane = 0; lane < 64; lane++) {
+        if (!sel[lane]) continue;
+        u32 const q = B0 + lane;
+        u32 ml = 3, bestC = 0, be = 0, flags = bt.flags[lane];
+        if (cnt[lane]) {
+            if (R.flag[lane]) flags |= SQZ_RB_EXACT;
+            else {
+                u32 const b = R.best[lane];
+                if ((b >> 8) > 3) {
+                    u32 const t = 255u - (b & 255u);
+                    SQZ_SIM_CHECK(pbase[lane] + t < P);
+                    ml = b >> 8;
+                    bestC = R.cand[pbase[lane] + t];
+                }
+            }
+        }
+        if (ml > 3 && bestC >= 8 + SQZ_WINDOW_START && q >= 8 + SQZ_WINDOW_START)
+            while (be < SQZ_RB_BECAP && base[q - 1 - be] == base[bestC - 1 - be]) be++;
+        bt.ml[lane] = ml;
+        bt.off[lane] = OFFSET_TO_OFFBASE(q - bestC);
+        bt.be[lane] = be;
+        bt.flags[lane] = flags | SQZ_RB_DONE;
     }
 }
 #endif

@@ -52,6 +52,24 @@ def test_sim_matches_oracle(sim, oracle, kind, seed, n):
     assert _sim_compress(sim, d) == oracle.compress_chunk(d)
 
 
+def test_sim_row_batches_clean_under_asan_ubsan(oracle, tmp_path):
+    """The row-hash search batches (sq_zstd_rowbatch.h) under AddressSanitizer + UBSan: the simulator's rb_eval walks the
+    same descriptor / candidate / per-owner arrays as the device routine, with the bounds the device relies on asserted, so
+    an out-of-range descriptor (the round-2 fault on all-equal data: every lane in one row) would show here.  Cases: the
+    inputs that fill a row with candidates (zeros, runs), text, and a mixed chunk with exact-finder stretches."""
+    exe = tmp_path / "sim_asan"
+    subprocess.check_call(["g++", "-O1", "-g", "-std=c++17", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined",
+                           "-o", str(exe), os.path.join(ROOT, "tests", "sim", "sim_cli.cpp")])
+    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=0", UBSAN_OPTIONS="print_stacktrace=1")
+    for kind, seed, n in (("zeros", 23, 262145), ("runs", 21, 400001), ("zeros", 0, 700000), ("text", 24, 300000), ("mixed", 2, 600000)):
+        d = corpus.make(kind, seed, n)
+        src, dst = tmp_path / "in.bin", tmp_path / "out.bin"
+        src.write_bytes(d)
+        r = subprocess.run([str(exe), str(src), str(dst)], capture_output=True, text=True, env=env, timeout=900)
+        assert r.returncode == 0 and "Sanitizer" not in r.stderr and "runtime error" not in r.stderr, (kind, n, r.stderr[-2000:])
+        assert dst.read_bytes() == oracle.compress_chunk(d), (kind, n)
+
+
 def test_lds_budget_allows_8_waves_per_cu(sim):
     # 160 KiB of LDS per CU, one wave per workgroup
     assert sim.sim_lds_bytes() * 8 <= 160 * 1024
