@@ -133,8 +133,8 @@ struct FastLds {
     u32 hits[2 * SQZ_FAST_HITS];     // (position, bytes) of scanned positions whose bytes equal a scheduled position's;
                                      // position 0 = two scheduled positions with equal bytes
     u32 sh[16];                      // words shared by the waves (FW_SH_*)
-    u32 hsec[256];                   // fused hash: lane l's two secret words (4 dwords at 4 l), the same for every chunk
-    u32 hstage[FW_NW * SQZ_FAST_DEPTH_HS * 64]; // fused hash: per wave and round of a loop step, the four rows' sums (4 x 64 B)
+    u32 hsec[256];                   // fused hash: lane l's two secret words (dword k at 64 k + l), the same for every chunk
+    u32 hstage[FW_NW * SQZ_FAST_DEPTH_HS * 64]; // fused hash: per wave, the (round, row, pair) sums of a loop step, dword k at 64 k + 16 round + 4 row + pair
 #ifdef SQ_PROF
     unsigned long long prof[8]; // 100 MHz ticks: 0 build, 1 scan loop, 2 look-ups (inside 1), 3 hit resolution, 4 pre-check + frame, 5 whole chunk
 #endif
@@ -720,7 +720,8 @@ SQ_DEV void cert_lds_core(CertCtx& cx, FastLds* L, u8* rawOut) {
     // one round: Bloom tests, scheduled positions removed, positives collected; false = list of hits full
     // fused hash: this lane's slot of the wave's staging area (rows of 64 B: lanes 0..3 of each row write)
     SQ_L u32* const hstWave = (SQ_L u32*)L->hstage + wv * (SQZ_FAST_DEPTH_HS * 64u);
-    const SQ_L u32* const hsecLane = (const SQ_L u32*)L->hsec + 4 * lane;
+    const SQ_L u32* const hsecLane = (const SQ_L u32*)L->hsec + lane; // word k of the lane's secret at [64 k + lane]: four
+                                                                      // conflict-free 4-byte reads (a 16-byte read per lane costs ~40 LDS cycles)
     // fused hash: the loop always runs whole steps of SQZ_FAST_DEPTH_HS rounds with ONE exit test per step (exits
     // after single rounds made hipcc merge them with the loop's latch in a block of register copies of the stream
     // loads in flight, i.e. a wait for all of them in every step).  Rounds beyond the wave's run, and all rounds
@@ -848,7 +849,7 @@ SQ_DEV void cert_lds_core(CertCtx& cx, FastLds* L, u8* rawOut) {
         if constexpr (decltype(HS)::value) { // (here, after the compaction loop: the filter's 54 temporaries are dead)
             // XXH3: the eight sums of this 1 KiB block (XXH3_accumulate_512 over its 16 stripes, without the
             // accumulators): two per lane, then over the four stripes of the row
-            sq_v4u const ks = *(const SQ_L sq_v4u*)hsecLane;
+            sq_v4u const ks = (sq_v4u){hsecLane[0], hsecLane[64], hsecLane[128], hsecLane[192]};
             u64 const d0 = ((u64)w.y << 32) | w.x, d1 = ((u64)w.w << 32) | w.z;
             u64 const k0 = d0 ^ (((u64)ks.y << 32) | ks.x), k1 = d1 ^ (((u64)ks.w << 32) | ks.z);
             u64 c0 = (u64)(u32)k0 * (u64)(u32)(k0 >> 32) + d1;
@@ -860,8 +861,12 @@ SQ_DEV void cert_lds_core(CertCtx& cx, FastLds* L, u8* rawOut) {
             // loop, which is at its limit of 128 vector and ~100 scalar registers: hence the laundered lane number.)
             u32 l2 = lane;
             asm volatile("" : "+v"(l2));
-            if ((l2 & 12) == 0) {
-                *(SQ_L sq_v4u*)(hstWave + 64 * decltype(IR)::value + (((l2 & 0x30u) >> 2) | (l2 & 3u)) * 4) = (sq_v4u){a0, a1, b0, b1};
+            if ((l2 & 12) == 0) { // word k of (round, slot) at [64 k + 16 round + slot]: the flush reads [64 k + lane]
+                SQ_L u32* const hw = hstWave + 16 * decltype(IR)::value + (((l2 & 0x30u) >> 2) | (l2 & 3u));
+                hw[0] = a0;
+                hw[64] = a1;
+                hw[128] = b0;
+                hw[192] = b1;
             }
         }
         if (nCand > 128) { // not with a working filter on random data: treat like a full list of hits
@@ -883,8 +888,7 @@ SQ_DEV void cert_lds_core(CertCtx& cx, FastLds* L, u8* rawOut) {
     auto hflush = [&](u32 r, u32 blk0) {
         static_assert(SQZ_FAST_DEPTH_HS == 4, "one lane per (round, row, pair) of a step");
         wv_fence();
-        sq_v4u const v = *(const SQ_L sq_v4u*)(hstWave + 4 * lane);
-        u32 a0 = v.x, a1 = v.y, b0 = v.z, b1 = v.w;
+        u32 a0 = hstWave[lane], a1 = hstWave[64 + lane], b0 = hstWave[128 + lane], b1 = hstWave[192 + lane];
         SQZ_ROW_SUM4(a0, a1, b0, b1);
         u32 const q = lane >> 4, j = lane & 3;
         bool const live = q < r && (lane & 12) == 0;
@@ -1256,10 +1260,10 @@ k_incompressible_batch(const u8* data, const u64* off, const u32* len, const u8*
     if (threadIdx.x < 64) { // the secret words of XXH3's stripe loop as the scan's lanes need them
         u32 const l = threadIdx.x;
         u64 const k0 = sqx::sec64(8 * (l >> 2) + 16 * (l & 3)), k1 = sqx::sec64(8 * (l >> 2) + 16 * (l & 3) + 8);
-        lds.hsec[4 * l] = (u32)k0;
-        lds.hsec[4 * l + 1] = (u32)(k0 >> 32);
-        lds.hsec[4 * l + 2] = (u32)k1;
-        lds.hsec[4 * l + 3] = (u32)(k1 >> 32);
+        lds.hsec[l] = (u32)k0;
+        lds.hsec[64 + l] = (u32)(k0 >> 32);
+        lds.hsec[128 + l] = (u32)k1;
+        lds.hsec[192 + l] = (u32)(k1 >> 32);
     }
 #ifdef SQ_PROF
     if (first)
