@@ -790,7 +790,7 @@ static int compress_finish(sq_ctx* c, sq_lane* L, u8* d_comp, u64 comp_cap, u64*
             if (fast) { // where stage 1's certificates ended (positions; 2 = chunk start, 131074 = block 1)
                 u32 ce[2] = {0, 0};
                 (void)hipMemcpy(ce, (u32*)L->b_cert.p + 2 * (size_t)(u32)e.second, 8, hipMemcpyDeviceToHost);
-                fprintf(stderr, " cert %u/%u", ce[0], ce[1] & 0x7FFFFFFFu);
+                fprintf(stderr, " cert %u/%u", ce[0] & SQZ_CERT_HINT_POS_MASK, ce[1] & 0x7FFFFFFFu);
             }
             fprintf(stderr, ")");
         }
@@ -824,7 +824,7 @@ static int compress_finish(sq_ctx* c, sq_lane* L, u8* d_comp, u64 comp_cap, u64*
         std::vector<u32> ce(2 * (size_t)std::min(n, 24u));
         (void)hipMemcpy(ce.data(), L->b_cert.p, ce.size() * 4, hipMemcpyDeviceToHost);
         fprintf(stderr, "[squish_gpu stats] cert ends:");
-        for (size_t i = 0; i < ce.size(); i += 2) fprintf(stderr, " %u/%u", ce[i], ce[i + 1] & 0x7FFFFFFFu);
+        for (size_t i = 0; i < ce.size(); i += 2) fprintf(stderr, " %u/%u", ce[i] & SQZ_CERT_HINT_POS_MASK, ce[i + 1] & 0x7FFFFFFFu);
         fprintf(stderr, "\n");
     }
     if (g_env.debug_stats) { // per-wave statistics words of the last chunk each wave compressed

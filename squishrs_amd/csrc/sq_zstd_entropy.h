@@ -1045,6 +1045,7 @@ SQ_DEVFN u32 compressLiterals(u8* dst, u32 dstCap, const u8* src, u32 srcSize, c
     WV_SERIAL {
         next->huf = prev->huf;
         next->huf_repeat = prev->huf_repeat;
+        g_lds.ret[6] = 0; // becomes 1 when anything is written to dst before the literals' mode is decided
     }
     wv_mem_sync();
     {
@@ -1089,6 +1090,7 @@ SQ_DEVFN u32 compressLiterals(u8* dst, u32 dstCap, const u8* src, u32 srcSize, c
                 break;
             }
             if (largest == srcSize) {
+                g_lds.ret[6] = 1;
                 *ostart = src[0];
                 cLitSize = 1;
                 break;
@@ -1116,6 +1118,7 @@ SQ_DEVFN u32 compressLiterals(u8* dst, u32 dstCap, const u8* src, u32 srcSize, c
             }
             {
                 // scratch FSE table for the weights: next->ll is rebuilt later in this block
+                g_lds.ret[6] = 1;
                 u32 hSize = huf_writeCTable(op, hcap, maxSym, huffLog, &next->ll);
                 if (is_err(hSize)) {
                     cLitSize = SQZ_ERR;
@@ -1513,14 +1516,28 @@ SQ_DEVFN u32 entropy_compress_seqstore(const SeqStore& ss, const Entropy* prev, 
     PROF_T0(t_ent);
     u32 const nbSeq = ss.nseq;
     u32 litSectionSize;
+    WV_SERIAL { g_lds.ret[7] = 1; } // "dst may have been written to" (0 only on the early way out below)
     {
         u32 const litSize = ss.nlits;
         u32 const suspect = (nbSeq == 0) || (litSize / nbSeq >= 20);
-        // without sequences the literals are the whole block: stored raw they cannot beat a raw block
-        // (section = litSize + 3, + 1 for the sequence count > blockSize - minGain), so skip the copy
-        u32 const discardRaw = (nbSeq == 0) && (litSize == blockSize) && (litSize > 4095);
-        litSectionSize = compressLiterals(dst, dstCap, ss.lits, litSize, prev, next, strategy, suspect, discardRaw);
+        // A raw literals section of litSize + 3 bytes, the sequence count (1 byte) and -- when there are sequences -- at
+        // least the modes byte and one byte of bit stream: if that much is not below blockSize - minGain the block is
+        // emitted raw whatever the rest costs (ZSTD_entropyCompressSeqStore: cSize >= maxCSize -> 0).  Then the raw
+        // literals are not copied and nothing else is written either (discardRaw): incompressible chunks with a few
+        // short matches -- what stage 1 hands over on random data -- stop here, and stage 1's raw payload, if it is in
+        // place in dst, stays intact (ret[7] = 0 tells the caller).
+        u32 const certainRaw = (litSize > 4095) && (litSize + 3 + (nbSeq ? 3u : 1u) >= blockSize - min_gain(blockSize, strategy));
+        litSectionSize = compressLiterals(dst, dstCap, ss.lits, litSize, prev, next, strategy, suspect, certainRaw);
         if (is_err(litSectionSize)) return (blockSize <= dstCap) ? 0 : SQZ_ERR;
+        if (certainRaw && litSectionSize == litSize + 3) { // the literals' mode came out raw
+            wv_mem_sync();
+            u32 const touched = g_lds.ret[6];
+            wv_fence();
+            WV_SERIAL { g_lds.ret[7] = touched; }
+            wv_mem_sync();
+            PROF_ADD(6, t_ent);
+            return 0;
+        }
     }
     SQ_TRACE(0, 81);
     SQ_TRACE(6, litSectionSize);

@@ -142,6 +142,13 @@ struct FastLds {
 
 #define SQZ_FAST_MIN_BLOCK (4096u * 10u) // HUF's sampled pre-check needs srcSize >= 10 samples
 #define SQZ_CERT_HINT_VALID 0x80000000u   // flag in certOut[1]: the two words are a certificate
+// certOut[0]: the certificate end of block 0 (a position: < 2^19) in the low bits; above it, in units of 64 bytes, how many
+// bytes of the chunk the scan has ALREADY written as raw-block payload at their place in a frame of full raw blocks
+// (dst + header + 3 (b + 1) + offset): the compressor skips its own copy of a raw block that is in place.
+#define SQZ_CERT_HINT_POS_BITS 19u
+#define SQZ_CERT_HINT_POS_MASK ((1u << SQZ_CERT_HINT_POS_BITS) - 1u)
+#define SQZ_CERT_HINT_RAW_LOG 6u
+#define SQZ_CERT_HINT_RAW_MAX ((1u << (32u - SQZ_CERT_HINT_POS_BITS)) - 1u)
 
 // ZSTD_writeFrameHeader for a single-segment frame with content size n; returns the header size.
 SQ_DEV u32 fast_frame_header(u8* dst, u32 n) {
@@ -1101,7 +1108,7 @@ SQ_DEV void cert_lds_core(CertCtx& cx, FastLds* L, u8* rawOut) {
 //     positions, 0.03 five-byte ones).  Blocks: 128 KiB each while every block so far was emitted raw -- libzstd's
 //     pre-block splitter only acts once `savings >= 3`, and a raw block contributes -3 (ZSTD_optimalBlockSize).
 SQ_DEV u32 fastpath_blocks(const u8* src, u32 n, u8* dst, u32 cap, u32 bA, const CParams& cp, const u32* schedTab, FastLds* L,
-                           u32* e0, u32* e1, u32 dbg, u64* hashPool, u8* hashedFlag) {
+                           u32* e0, u32* e1, u32 dbg, u64* hashPool, u8* hashedFlag, u32* rawDone = nullptr) {
     constexpr u32 BS = SQZ_BLOCKSIZE_MAX;
     bool const row = cp.strategy == STRAT_LAZY2;
     u32 const nBlocksAll = (n + BS - 1) / BS;
@@ -1150,6 +1157,7 @@ SQ_DEV u32 fastpath_blocks(const u8* src, u32 n, u8* dst, u32 cap, u32 bA, const
     FPROF_T0(t_frame);
     *e0 = (dbg & 64) ? cx.nOvf : cx.certEnd; // (64: bring-up, why the scan gave up)
     *e1 = cx.certEnd1;
+    if (rawDone) *rawDone = cx.rawEnd - SQZ_WINDOW_START; // chunk bytes whose raw-block payload the scan has put in place
     // every search of the two blocks certainly fails?
     bool whole = cx.certEnd >= cx.base0Pos + lenA - tail;
     if (lenB) whole = whole && (cx.certEnd1 >= cx.base1Pos + lenB - tail);
@@ -1297,15 +1305,17 @@ k_incompressible_batch(const u8* data, const u64* off, const u32* len, const u8*
                 if (wv_uni(lds.sh[FW_SH_IDX]) >> 8) run = false;
                 fw_sync();
             }
-            u32 ok = 0, e0 = 0, e1 = 0;
+            u32 ok = 0, e0 = 0, e1 = 0, rawDone = 0;
             if (run) // (the ONE call site, see fastpath_frame_wave)
                 ok = fastpath_blocks(data + off[idx], L, dst, cap, large ? 2 * pair : 0u, cp, schedTab, &lds, &e0, &e1, dbg,
                                      (hpool && !large) ? (u64*)(hpool + (u64)idx * SQZ_FAST_HPOOL_BYTES) : nullptr,
-                                     (hashed && !large) ? hashed + idx : nullptr);
+                                     (hashed && !large) ? hashed + idx : nullptr, &rawDone);
             if (!large) {
                 if (ok) r = fast_frame_header_all(dst, L) + L + 3 * nBlocks;
-                if (first) { // the certificate ends for k_compress_batch, or 0, 0 when no certificate was computed
-                    cert_out[2 * (size_t)idx] = e0;
+                if (first) { // the certificate ends for k_compress_batch, or 0, 0 when no certificate was computed; beside
+                             // the first, how much raw-block payload is in place already (SQZ_CERT_HINT_RAW_*)
+                    u32 const units = (rawDone >> SQZ_CERT_HINT_RAW_LOG) < SQZ_CERT_HINT_RAW_MAX ? (rawDone >> SQZ_CERT_HINT_RAW_LOG) : SQZ_CERT_HINT_RAW_MAX;
+                    cert_out[2 * (size_t)idx] = e0 | (units << SQZ_CERT_HINT_POS_BITS);
                     cert_out[2 * (size_t)idx + 1] = (e0 | e1) ? (e1 | SQZ_CERT_HINT_VALID) : 0u;
                 }
             } else {
@@ -1334,7 +1344,7 @@ k_incompressible_batch(const u8* data, const u64* off, const u32* len, const u8*
             if (r)
                 atomicAdd(queue + 1, 1u);
             else if (taken) {
-                u32 const h0 = cert_out[2 * (size_t)idx], h1 = cert_out[2 * (size_t)idx + 1];
+                u32 const h0 = cert_out[2 * (size_t)idx] & SQZ_CERT_HINT_POS_MASK, h1 = cert_out[2 * (size_t)idx + 1];
                 u32 const len0 = L < SQZ_BLOCKSIZE_MAX ? L : SQZ_BLOCKSIZE_MAX;
                 bool const heavy = (h1 & SQZ_CERT_HINT_VALID) && L > SQZ_BLOCKSIZE_MAX + 8 && len0 >= 9 &&
                                    h0 < SQZ_WINDOW_START + len0 - 8 && (h1 & ~SQZ_CERT_HINT_VALID) < SQZ_WINDOW_START + L - 8;

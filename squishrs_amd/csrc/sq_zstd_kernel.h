@@ -489,7 +489,7 @@ SQ_DEVFN u32 compress_frame_wave(const u8* src, u32 n, u8* dst, u32 cap, u8* ws,
         PROF_ADD(24, t_pr);
         u32 const hint1 = certHint ? gld32(certHint + 1) : 0u;
         if (hint1 & SQZ_CERT_HINT_VALID) { // already computed by the incompressible-chunk kernel
-            ms.certEnd = gld32(certHint);
+            ms.certEnd = gld32(certHint) & SQZ_CERT_HINT_POS_MASK;
             ms.certEnd1 = hint1 & ~SQZ_CERT_HINT_VALID;
         } else if (ms.nCert > 0 && !certHint) {
             cert_compute(ms);
@@ -514,6 +514,9 @@ SQ_DEVFN u32 compress_frame_wave(const u8* src, u32 n, u8* dst, u32 cap, u8* ws,
     const u8* ip = src;
     u32 remaining = n;
     s64 savings = 0;
+    // chunk bytes that stage 1's scan has already written as raw-block payload where a frame of full raw blocks has them
+    // (block b at dst + hdr + 3 (b + 1) + 128 KiB b): a raw block found there is not copied again
+    u32 const rawHave = (certHint && cp.strategy == STRAT_BTLAZY2) ? (gld32(certHint) >> SQZ_CERT_HINT_POS_BITS) << SQZ_CERT_HINT_RAW_LOG : 0u;
     while (remaining) {
         SQ_TRACE(0, 4);
         SQ_TRACE(2, (u32)(ip - src));
@@ -536,7 +539,14 @@ SQ_DEVFN u32 compress_frame_wave(const u8* src, u32 n, u8* dst, u32 cap, u8* ws,
                 op[2] = (u8)(h >> 16);
             }
             PROF_T0(t_raw);
-            wv_memcpy(op + 3, ip, blockSize);
+            {
+                u32 const o = (u32)(ip - src);
+                // in place already?  (this block and all before it full raw blocks, stage 1 got that far, and the entropy
+                // stage's attempt wrote nothing over it: g_lds.ret[7], set by compressLiterals / entropy_compress_seqstore)
+                bool const inPlace = blockSize >= 7 && o + blockSize <= rawHave && op == dst + hdr + 3 * (o >> 17) + o &&
+                                     (o & (SQZ_BLOCKSIZE_MAX - 1)) == 0 && g_lds.ret[7] == 0;
+                if (!inPlace) wv_memcpy(op + 3, ip, blockSize);
+            }
             PROF_ADD(7, t_raw);
             cSize = 3 + blockSize;
         } else {
