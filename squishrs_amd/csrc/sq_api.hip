@@ -665,7 +665,8 @@ static int compress_stage2(sq_ctx* c, sq_lane* L, const u8* d_data, const u8* d_
                            (const u64*)L->b_slot_off.p, (u32*)L->b_frame_len.p, (u8*)L->b_ws.p,
                            (u64)L->job_ws_each, (u32*)L->b_misc.p /*queue*/, (u32*)L->b_misc.p + 16 /*err*/,
                            (const u32*)c->d_sched_tab, fast ? (const u32*)L->b_cert.p : (const u32*)nullptr, L->job_ws_persist,
-                           fast ? (const u32*)L->b_work.p : (const u32*)nullptr);
+                           fast ? (const u32*)L->b_work.p : (const u32*)nullptr,
+                           (fast && !L->job_list.empty()) ? (const u32*)L->b_pair.p : (const u32*)nullptr);
         HIPCHK(hipGetLastError());
     }
     HIPCHK(hipEventRecord(L->ev[5], L->stream));

@@ -1212,8 +1212,9 @@ SQ_DEV u32 fastpath_blocks(const u8* src, u32 n, u8* dst, u32 cap, u32 bA, const
 // call site: the scan is three instantiations of a long loop, inlined twice it no longer fits the instruction cache.)
 #if !SQ_ON_DEVICE
 SQ_DEV u32 fastpath_frame_wave(const u8* src, u32 n, u8* dst, u32 cap, u32* E, u32 genBits, const u32* schedTab,
-                                 FastLds* L, u32* certOut, u32 dbg = 0, u64* hashPool = nullptr, u8* hashedFlag = nullptr) {
+                                 FastLds* L, u32* certOut, u32 dbg = 0, u64* hashPool = nullptr, u8* hashedFlag = nullptr, u32* pairInfo = nullptr) {
     (void)E; (void)genBits;
+    if (pairInfo) *pairInfo = 0;
     CParams const cp = get_cparams(n);
     u32 c0 = 0, c1 = 0;
     u32 frame = 0;
@@ -1227,13 +1228,16 @@ SQ_DEV u32 fastpath_frame_wave(const u8* src, u32 n, u8* dst, u32 cap, u32* E, u
         }
         if (ok) frame = fast_frame_header_all(dst, n) + n + 3 * nBlocks;
     } else if (cp.strategy == STRAT_LAZY2 && !(dbg & 512)) { // (512: timing experiment, large chunks left to stage 2)
-        u32 ok = 1;
-        for (u32 bA = 0; bA < nBlocks && ok; bA += 2) {
+        u32 okAll = 1, info = 0;
+        for (u32 bA = 0; bA < nBlocks; bA += 2) { // (every pair, as the kernel's jobs do: stage 2 wants each pair's verdict)
             u32 e0, e1;
-            ok = fastpath_blocks(src, n, dst, cap, bA, cp, schedTab, L, &e0, &e1, dbg, nullptr, nullptr);
+            u32 const ok = fastpath_blocks(src, n, dst, cap, bA, cp, schedTab, L, &e0, &e1, dbg, nullptr, nullptr);
             fw_sync();
+            info += 1u + (ok ? 0u : (0x100u | (0x10000u << (bA / 2))));
+            okAll = okAll && ok;
         }
-        if (ok) frame = fast_frame_header_all(dst, n) + n + 3 * nBlocks;
+        if (pairInfo) *pairInfo = info;
+        if (okAll) frame = fast_frame_header_all(dst, n) + n + 3 * nBlocks;
     }
     if (fw_wave() == 0) WV_SERIAL {
         certOut[0] = c0;
@@ -1248,8 +1252,9 @@ SQ_DEV u32 fastpath_frame_wave(const u8* src, u32 n, u8* dst, u32 cap, u32* E, u
 // Persistent workgroups of FW_NW waves; every workgroup pulls JOBS from *queue until exhausted (every workgroup reaches
 // j >= n_jobs).  A job is a chunk of at most two blocks, or one pair of blocks of a larger chunk (jobs[j] = chunk index |
 // pair number << 28; jobs == null: job j = chunk j).  frame_len[idx] = frame size, or 0 = not decided here.
-// pair_state[idx] (zeroed by the host; large chunks only): pairs finished so far (bits 0..7) and how many of them
-// failed (bits 8..); the workgroup that finishes a chunk's last pair writes its frame header and its verdict.
+// pair_state[idx] (zeroed by the host; large chunks only): pairs finished so far (bits 0..7), how many of them
+// failed (bits 8..15) and which (bit 16 + pair); the workgroup that finishes a chunk's last pair writes its frame header and
+// its verdict; stage 2 reads the word (compress_frame_wave: certified pairs are replayed, not searched).
 __global__ void __launch_bounds__(64 * SQZ_FAST_WG_WAVES, SQZ_FAST_WAVES_PER_SIMD)
 k_incompressible_batch(const u8* data, const u64* off, const u32* len, const u8* select, u32 n, u8* slots,
                        const u64* slot_off, u32* frame_len, u32* cert_out, u8* etab_pool, u64 etab_bytes,
@@ -1299,12 +1304,8 @@ k_incompressible_batch(const u8* data, const u64* off, const u32* len, const u8*
             wv_mem_sync_inv(); // no L1 line from the previous chunk's data survives
             FPROF_T0(t_chunk);
             bool run = (cp.strategy == STRAT_BTLAZY2 && L >= 9) || (large && !(dbg & 512)); // (512: timing experiment, large chunks left to stage 2)
-            if (large) { // a pair of blocks of a large chunk is not worth its scan once another pair of the chunk has failed
-                if (first) lds.sh[FW_SH_IDX] = __hip_atomic_load(pair_state + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                fw_sync();
-                if (wv_uni(lds.sh[FW_SH_IDX]) >> 8) run = false;
-                fw_sync();
-            }
+            // (every pair of a large chunk is looked at even after another pair of it has failed: stage 2 replays the
+            // certified pairs' table insertions instead of searching them, row_replay_nomatch)
             u32 ok = 0, e0 = 0, e1 = 0, rawDone = 0;
             if (run) // (the ONE call site, see fastpath_frame_wave)
                 ok = fastpath_blocks(data + off[idx], L, dst, cap, large ? 2 * pair : 0u, cp, schedTab, &lds, &e0, &e1, dbg,
@@ -1320,13 +1321,16 @@ k_incompressible_batch(const u8* data, const u64* off, const u32* len, const u8*
                 }
             } else {
                 fw_sync();
-                if (first) lds.sh[FW_SH_IDX] = atomicAdd(pair_state + idx, 1u + (ok ? 0u : 0x100u)) + 1u + (ok ? 0u : 0x100u);
+                if (first) { // (one add: the fields do not overlap -- pairs finished, pairs failed, WHICH pairs failed)
+                    u32 const inc = 1u + (ok ? 0u : (0x100u | (0x10000u << pair)));
+                    lds.sh[FW_SH_IDX] = atomicAdd(pair_state + idx, inc) + inc;
+                }
                 fw_sync();
                 u32 const now = wv_uni(lds.sh[FW_SH_IDX]);
                 fw_sync();
                 if ((now & 0xFFu) == nPairs) { // the chunk's last pair to finish
                     verdict = true;
-                    if (!(now >> 8)) r = fast_frame_header_all(dst, L) + L + 3 * nBlocks;
+                    if (!((now >> 8) & 0xFFu)) r = fast_frame_header_all(dst, L) + L + 3 * nBlocks;
                     if (first) {
                         cert_out[2 * (size_t)idx] = 0;
                         cert_out[2 * (size_t)idx + 1] = 0;

@@ -351,8 +351,10 @@ struct TableGen {
 // Returns the frame length, 0 on error.
 // certHint: two words left by k_incompressible_batch for this chunk (certificate ends, see
 // fastpath_frame_wave) or nullptr.
+// pairInfo (chunks above 256 KiB): stage 1's word for the chunk -- pairs of blocks finished (bits 0..7), how many failed
+// (8..15), which (16..23) -- or 0.
 SQ_DEVFN u32 compress_frame_wave(const u8* src, u32 n, u8* dst, u32 cap, u8* ws, const WsLayout& L, TableGen& tg,
-                                 const u32* schedTab, const u32* certHint) {
+                                 const u32* schedTab, const u32* certHint, u32 pairInfo = 0) {
     MatchState ms;
     SeqStore ss;
     BlockState bs;
@@ -428,6 +430,11 @@ SQ_DEVFN u32 compress_frame_wave(const u8* src, u32 n, u8* dst, u32 cap, u8* ws,
     SQ_TRACE(39, 0);
     PROF_T0(t_clr);
     ms.genBits = 0;
+    ms.certPairs = 0;
+    if (cp.strategy == STRAT_LAZY2 && schedTab) {
+        u32 const nBlocks = (n + SQZ_BLOCKSIZE_MAX - 1) / SQZ_BLOCKSIZE_MAX, nPairs = (nBlocks + 1) / 2;
+        if (nPairs <= 8 && (pairInfo & 0xFFu) == nPairs) ms.certPairs = ~(pairInfo >> 16) & ((1u << nPairs) - 1u);
+    }
     if (cp.strategy == STRAT_BTLAZY2) {
         if (tg.gen == 0 || tg.gen >= SQZ_HT_GEN_MAX || tg.windowLog != cp.windowLog) {
             wv_fill32(ms.hashTable, 0, (size_t)1 << cp.hashLog);
@@ -583,11 +590,12 @@ SQ_DEVFN u32 compress_frame_wave(const u8* src, u32 n, u8* dst, u32 cap, u8* ws,
 // One chunk -> one frame in its output slot (kept out of line: keeps the queue loop simple).
 __device__ __noinline__ void compress_one(const u8* data, const u64* off, const u32* len, u32 idx, u8* slots,
                                           const u64* slot_off, u32* frame_len, u8* ws, u32* err, TableGen& tg, const u32* schedTab,
-                                          const u32* certHint) {
+                                          const u32* certHint, const u32* pair_state) {
     u32 const L = len[idx];
     WsLayout const lay = ws_layout(L); // offsets for this length are <= the pool's
     u32 const cap = (u32)(slot_off[idx + 1] - slot_off[idx]);
-    u32 const r = compress_frame_wave(data + off[idx], L, slots + slot_off[idx], cap, ws, lay, tg, schedTab, certHint ? certHint + 2 * (size_t)idx : nullptr);
+    u32 const r = compress_frame_wave(data + off[idx], L, slots + slot_off[idx], cap, ws, lay, tg, schedTab, certHint ? certHint + 2 * (size_t)idx : nullptr,
+                                      pair_state ? pair_state[idx] : 0u);
     if (wv_lane() == 0) {
         frame_len[idx] = r;
         if (r == 0) atomicOr(err, 1u);
@@ -599,7 +607,7 @@ __device__ __noinline__ void compress_one(const u8* data, const u64* off, const 
 __global__ void __launch_bounds__(64, 2) // 2 waves per SIMD: <= 256 registers, 8 waves per CU (LDS: 8 x 19 KiB)
 k_compress_batch(const u8* data, const u64* off, const u32* len, const u8* select, u32 n, u8* slots,
                  const u64* slot_off, u32* frame_len, u8* ws_pool, u64 ws_each, u32* queue, u32* err,
-                 const u32* schedTab, const u32* certHint, u32 persist, const u32* work) {
+                 const u32* schedTab, const u32* certHint, u32 persist, const u32* work, const u32* pair_state) {
     u8* const ws = ws_pool + (u64)blockIdx.x * ws_each;
     u32* const dbg = (u32*)(ws + ws_each - 256) + 8; // wave-level progress words for the watchdog
     u32 iter = 0;
@@ -645,7 +653,7 @@ k_compress_batch(const u8* data, const u64* off, const u32* len, const u8* selec
             if (wv_lane() == 0)
                 for (int k = 0; k < 29; k++) g_lds.prof0[k] = g_lds.prof[k];
 #endif
-            if (take) compress_one(data, off, len, idx, slots, slot_off, frame_len, ws, err, tg, schedTab, certHint);
+            if (take) compress_one(data, off, len, idx, slots, slot_off, frame_len, ws, err, tg, schedTab, certHint, pair_state);
             PROF_ADD(0, t_all);
 #ifdef SQ_PROF
             {   // the wave's longest chunk (ticks, index, list it came from) and when the wave finished it

@@ -109,6 +109,8 @@ struct MatchState {
     u32 tailBlkTried;    // one has been attempted in the current block
     u32 sbMax;       // current super-batch length of the filtered insertion stream (256..2048)
     u32 genBits;     // btlazy2 hash-table generation tag of this chunk, in place (bits 19..29)
+    u32 certPairs;   // lazy2 (chunks above 256 KiB): bit k = stage 1 certified that no search of blocks 2k, 2k + 1 finds a match
+                     // (while the repcode offset is 1 and the blocks are the full 128 KiB ones) -- row_replay_nomatch
     CParams cp;
 };
 
@@ -2016,6 +2018,113 @@ SQ_DEV void row_update(MatchState& ms, u32 target) {
     }
     row_insert_range(ms, idx, target);
     ms.nextToUpdate = target;
+}
+
+// The same for a LIST of positions, base0 + tab[k], k in [kFrom, kTo), ascending (what the finder inserts in lazy-skipping
+// mode: the searched positions only).
+SQ_DEV void row_insert_list(MatchState& ms, u32 base0, const u32* tab, u32 kFrom, u32 kTo) {
+    const u8* const base = ms.base;
+    u32 const hBits = ms.rowHashLog + 8;
+#if SQ_ON_DEVICE
+    u32 const lane = wv_lane();
+    for (u32 k0 = kFrom; k0 < kTo; k0 += 64) {
+        u32 const k = k0 + lane;
+        bool const active = k < kTo;
+        u32 const idx = base0 + sq_gld32(tab + (active ? k : kTo - 1));
+        u32 hash = 0;
+        if (active) hash = hash5(sq_grd64(base + idx), hBits);
+        u32 const relRow = (hash >> 8) << 6;
+        WvGroup const g = wv_group(relRow, active, g_lds.grp);
+        u32 hb = 0;
+        wv_mem_sync(); // (as in row_insert_range)
+        if (active) {
+            u8* const tagRow = ms.tagTable + relRow;
+            u32* const row = ms.hashTable + relRow;
+            hb = sq_tld8(tagRow);
+            u32 const pos = row_pos_after(hb, g.rank + 1);
+            if (g.rank + 63 >= g.gsize) {
+                sq_gwr8(tagRow + pos, hash);
+                sq_gst32(row + pos, idx);
+            }
+        }
+        wv_fence();
+        if (active && g.rank + 1 == g.gsize) sq_gwr8(ms.tagTable + relRow, row_pos_after(hb, g.gsize));
+    }
+#else
+    for (u32 k = kFrom; k < kTo; k++) {
+        u32 const idx = base0 + tab[k];
+        u32 const hash = hash5(sq_rd64(base + idx), hBits);
+        u32 const relRow = (hash >> 8) << 6;
+        u8* const tagRow = ms.tagTable + relRow;
+        u32 const pos = row_pos_after(tagRow[0], 1);
+        tagRow[0] = (u8)pos;
+        tagRow[pos] = (u8)hash;
+        ms.hashTable[relRow + pos] = idx;
+    }
+#endif
+}
+
+// A block in which every search of the lazy parser fails (stage 1's certificate for its pair of blocks, or the repcode
+// re-check below), WITHOUT the searches: what is left of ZSTD_compressBlock_lazy_generic + ZSTD_RowFindBestMatch then is
+// their effect on the tables.  The searched positions are the no-match schedule s_0 < s_1 < ... (step =
+// ((s - blockStart) >> 8) + 1, the constant tables of sched_tab_fill, up to 16 bytes before the block's end).  While the
+// step is <= 8 a search first inserts every position up to itself (ZSTD_row_update_internal, with its rule for gaps
+// above 384 on the first one) and then itself; the search after which the step exceeds 8 switches the finder to lazy
+// skipping, where only the searched positions are inserted.  So: everything up to s_m (the first search at or beyond
+// 2 KiB into the block), then the later s_k alone, 64 per step instead of one search each.
+#if !SQ_ON_DEVICE
+static u32 g_sim_replayed_blocks = 0; // (simulator build: lets the tests see that the path was taken)
+#endif
+SQ_DEVFN void row_replay_nomatch(MatchState& ms, u32 istartPos, u32 srcSize) {
+#if !SQ_ON_DEVICE
+    g_sim_replayed_blocks++;
+#endif
+    bool const first = istartPos == SQZ_WINDOW_START;
+    const u32* const tab = ms.schedTab + 2 + (first ? 0u : SQZ_SCHEDTAB_N);
+    u32 const full = gld32(ms.schedTab + (first ? 0u : 1u));
+    u32 const n = (srcSize <= 16) ? 0u : sched_count(tab, full, srcSize - 16);
+    if (n == 0) return;
+    u32 const m1 = sched_count(tab, n, 2048); // entries below 2 KiB: searches 0 .. m1 run before the switch (m1 itself if it exists)
+    u32 const m = m1 < n ? m1 : n - 1;
+    u32 const s0 = istartPos + gld32(tab), sm = istartPos + gld32(tab + m);
+    row_update(ms, s0);
+    row_insert_range(ms, s0, sm + 1);
+    if (m + 1 < n) row_insert_list(ms, istartPos, tab, m + 1, n);
+    ms.nextToUpdate = istartPos + gld32(tab + n - 1) + 1;
+    wv_mem_sync();
+}
+// ... and the one thing the certificate assumed about the parser's state: the repcode test at s + 1 with offset 1.
+// For another offset the test is repeated here: true = no scheduled search of the block has a repcode match.
+SQ_DEVFN bool row_sched_rep_clear(MatchState& ms, u32 istartPos, u32 srcSize, u32 off1) {
+    bool const first = istartPos == SQZ_WINDOW_START;
+    const u32* const tab = ms.schedTab + 2 + (first ? 0u : SQZ_SCHEDTAB_N);
+    u32 const full = gld32(ms.schedTab + (first ? 0u : 1u));
+    u32 const n = (srcSize <= 16) ? 0u : sched_count(tab, full, srcSize - 16);
+    const u8* const base = ms.base;
+    bool hit = false;
+#if SQ_ON_DEVICE
+    u32 const lane = wv_lane();
+    for (u32 k0 = 0; k0 < n; k0 += 256) {
+        u32 a[4], b[4];
+#pragma unroll
+        for (u32 g = 0; g < 4; g++) {
+            u32 const k = k0 + 64 * g + lane;
+            u32 const sp = istartPos + sq_gld32(tab + (k < n ? k : n - 1));
+            bool const ok = sp + 1 >= off1 + SQZ_WINDOW_START;
+            a[g] = ok ? sq_grd32(base + sp + 1 - off1) : 0u;
+            b[g] = ok ? sq_grd32(base + sp + 1) : 1u;
+        }
+#pragma unroll
+        for (u32 g = 0; g < 4; g++) hit = hit || (k0 + 64 * g + lane < n && a[g] == b[g]);
+    }
+    return wv_ballot(hit) == 0;
+#else
+    for (u32 k = 0; k < n; k++) {
+        u32 const sp = istartPos + tab[k];
+        if (sp + 1 >= off1 + SQZ_WINDOW_START && sq_rd32(base + sp + 1 - off1) == sq_rd32(base + sp + 1)) hit = true;
+    }
+    return !hit;
+#endif
 }
 
 // ZSTD_RowFindBestMatch (noDict, mls 5, rowLog 6)

@@ -694,6 +694,18 @@ SQ_DEV u32 compressBlock_lazy_rb_impl(MatchState& ms, SeqStore& ss, u32* rep, co
     u32 ip = istartPos, anchor = istartPos;
     u32 offset_1 = rep[0], offset_2 = rep[1];
     u32 offsetSaved1 = 0, offsetSaved2 = 0;
+    // A block of a pair that stage 1 certified (no search of it finds a match, ms.certPairs): no searches, only their
+    // effect on the tables (row_replay_nomatch).  The certificate assumed full 128 KiB blocks at their places and the
+    // repcode offset 1; another offset is re-checked over the block's schedule.
+    if (ms.certPairs) {
+        u32 const o = istartPos - SQZ_WINDOW_START;
+        if ((o & (SQZ_BLOCKSIZE_MAX - 1)) == 0 && ((ms.certPairs >> (o >> 18)) & 1) &&
+            (srcSize == SQZ_BLOCKSIZE_MAX || iendPos == ms.chunkEndPos) && offset_1 != 0 && offset_1 <= istartPos - SQZ_WINDOW_START + (o == 0 ? 1u : 0u) &&
+            (offset_1 == 1 || row_sched_rep_clear(ms, istartPos, srcSize, offset_1))) {
+            row_replay_nomatch(ms, istartPos, srcSize);
+            return srcSize; // no sequence: the repcodes stay as they came
+        }
+    }
     ip += (ip == prefixLowestPos);
     {
         u32 const maxRep = ip - SQZ_WINDOW_START;

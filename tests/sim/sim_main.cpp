@@ -72,7 +72,8 @@ extern "C" size_t sim_compress_two_stage(const uint8_t* src, size_t n, uint8_t* 
     }
     memset(&lds, 0x77, sizeof(lds));
     u32 hint[2] = {0x55555555u, 0x55555555u};
-    u32 r = sqz::fastpath_frame_wave(src, (u32)n, dst, (u32)cap, etab, gen << SQZ_HT_GEN_SHIFT, sched_tab(), &lds, hint);
+    u32 pairInfo = 0; // chunks above 256 KiB: stage 1's verdict per pair of blocks, as the kernel leaves it in pair_state
+    u32 r = sqz::fastpath_frame_wave(src, (u32)n, dst, (u32)cap, etab, gen << SQZ_HT_GEN_SHIFT, sched_tab(), &lds, hint, 0, nullptr, nullptr, &pairInfo);
     *decided = r != 0;
     if (r) return r;
     sqz::WsLayout L = sqz::ws_layout((u32)n);
@@ -81,10 +82,11 @@ extern "C" size_t sim_compress_two_stage(const uint8_t* src, size_t n, uint8_t* 
     memset(&sqz::g_lds, 0x5A, sizeof(sqz::g_lds));
     u8* wsa = (u8*)(((uintptr_t)ws + 255) & ~(uintptr_t)255);
     sqz::TableGen tg = {0, 0, 0};
-    r = sqz::compress_frame_wave(src, (u32)n, dst, (u32)cap, wsa, L, tg, sched_tab(), hint);
+    r = sqz::compress_frame_wave(src, (u32)n, dst, (u32)cap, wsa, L, tg, sched_tab(), hint, pairInfo);
     free(ws);
     return r;
 }
+extern "C" unsigned sim_replayed_blocks(void) { return sqz::g_sim_replayed_blocks; } // blocks whose searches were replaced by row_replay_nomatch so far
 // The arithmetic that tells the scan which positions are scheduled ones (fast_sched_mask) against the
 // schedule tables, for a chunk of n bytes: returns the number of positions where they disagree and
 // the first such position through *firstBad.

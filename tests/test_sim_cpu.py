@@ -139,6 +139,45 @@ def test_sim_incompressible_kernel_then_compressor(sim, oracle, kind, seed, n):
         assert decided.value == 0
 
 
+# Chunks above 256 KiB: stage 1 leaves a verdict per pair of 128 KiB blocks, and stage 2 replays the table insertions of the
+# certified pairs instead of searching them (row_replay_nomatch), re-checking the repcode test when the offset is not 1.
+LARGE_TWO_STAGE = ([("plantedL%d" % v, 3, n) for v in range(10) for n in (2097152, 700000)]
+                   + [("random", 4, 2097152), ("random", 5, 1048576 + 777), ("random", 6, 262145 + 131072),
+                      ("text_then_random", 0, 2097152), ("random_then_text_then_random", 0, 2097152), ("random_with_run", 0, 1048576)])
+
+
+def _large_input(kind, seed, n):
+    if kind == "text_then_random":           # sequences first (repcode offsets no longer 1, 4, 8), then certified pairs
+        return corpus.make("text", 7, 300000) + corpus.random_bytes(8, 8, n - 300000)
+    if kind == "random_then_text_then_random":
+        return corpus.random_bytes(9, 1, 600000) + corpus.make("text", 9, 200000) + corpus.random_bytes(9, 2, n - 800000)
+    if kind == "random_with_run":            # a run of one byte in the middle: offset 1 becomes the repcode of what follows
+        return corpus.random_bytes(3, 1, 400000) + bytes([7]) * 5000 + corpus.random_bytes(3, 2, n - 405000)
+    try:
+        return corpus.make(kind, seed, n)
+    except IndexError:                       # plantedL*: the last block is too short to hold the plant
+        return corpus.make("random", seed, n)
+
+
+@pytest.mark.parametrize("kind,seed,n", LARGE_TWO_STAGE)
+def test_sim_large_chunks_pairs_then_compressor(sim, oracle, kind, seed, n):
+    sim.sim_compress_two_stage.restype = ctypes.c_size_t
+    sim.sim_compress_two_stage.argtypes = [ctypes.c_char_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_size_t,
+                                           ctypes.POINTER(ctypes.c_int)]
+    d = _large_input(kind, seed, n)
+    cap = len(d) + (len(d) >> 8) + 1024
+    dst = ctypes.create_string_buffer(cap)
+    decided = ctypes.c_int(0)
+    sim.sim_replayed_blocks.restype = ctypes.c_uint
+    before = sim.sim_replayed_blocks()
+    r = sim.sim_compress_two_stage(d, len(d), dst, cap, ctypes.byref(decided))
+    assert dst.raw[:r] == oracle.compress_chunk(d), (kind, n, decided.value)
+    replayed = sim.sim_replayed_blocks() - before
+    print(f"{kind} {n}: decided by stage 1 = {decided.value}, blocks replayed in stage 2 = {replayed} of {(len(d) + 131071) // 131072}")
+    if not decided.value and kind.startswith("plantedL") and n == 2097152:
+        assert replayed >= 12      # every block outside the pair(s) with the plant
+
+
 def test_fast_kernel_lds_allows_4_workgroups_per_cu(sim):
     """Stage 1 runs 4 workgroups of 4 waves per CU (128 registers per lane).  The simulator's FastLds is the
     one-wave layout; on the device every further wave adds its candidate list (256 words) and its staging area of
