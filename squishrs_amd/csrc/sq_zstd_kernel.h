@@ -587,7 +587,9 @@ SQ_DEVFN u32 compress_frame_wave(const u8* src, u32 n, u8* dst, u32 cap, u8* ws,
 }
 
 #if SQ_ON_DEVICE
-// One chunk -> one frame in its output slot (kept out of line: keeps the queue loop simple).
+// One chunk -> one frame in its output slot.  Kept OUT OF LINE on purpose: it keeps the persistent queue loop small, and an
+// experiment of round 3 that inlined a per-chunk body of this size (with calls inside) into such a loop hung on the device --
+// the wave never returned to the queue's atomicAdd.
 __device__ __noinline__ void compress_one(const u8* data, const u64* off, const u32* len, u32 idx, u8* slots,
                                           const u64* slot_off, u32* frame_len, u8* ws, u32* err, TableGen& tg, const u32* schedTab,
                                           const u32* certHint, const u32* pair_state) {
