@@ -966,7 +966,8 @@ static int pack_enqueue(sq_ctx* c, sq_lane* L, sq_lane* other, const u8* d_data,
     int r;
     *committed = false;
     int const mode = (c->cfg.flags & SQ_CFG_ALWAYS_FUSE_HASH) ? 1 : (c->cfg.flags & SQ_CFG_NEVER_FUSE_HASH) ? 0 : g_env.fuse_hash;
-    bool const fused = mode == 1 || (mode < 0 && c->dup_ratio_last < 0.25f);
+    // (the crossover, measured: tools/bench_dupratio.py, profiles/round3_fused_vs_split_by_duplicates.txt)
+    bool const fused = mode == 1 || (mode < 0 && c->dup_ratio_last < 0.20f);
     if ((r = compress_prepare(c, L, h_len, n, d_comp, comp_cap, in_place, fused))) return r;
     u64 const seen0 = (flags & 1u) ? 0 : c->n_seen;
     if (seen0 + n > c->key_capacity || seen0 + n >= 0xFFFFFFFFull) return SQ_E_CAP;
