@@ -381,3 +381,67 @@ def test_pipelined_sharded_packer_two_in_flight():
         assert got[0] == (model_new, model_len)
         assert got[1][0] == [0] * len(model_new) and got[1][1] == [0] * len(model_new)
         assert got[2] == (model_new, model_len)
+
+
+def test_pwritev_all_loops_over_short_writes_and_refuses_zero(tmp_path):
+    """ADVICE r3 (sharded_pack.py:190): a record run must reach the file whole even when the kernel writes short (Linux
+    caps one write at 0x7ffff000 bytes); a write of 0 bytes is an error, not a silent truncation."""
+    sys.path.insert(0, ROOT)
+    from squishrs_amd.sharded_pack import pwritev_all
+    path = tmp_path / "f.bin"
+    path.write_bytes(b"\xee" * 10)
+    fd = os.open(str(path), os.O_WRONLY)
+    calls = []
+
+    def short(fd_, bufs, at):   # writes at most 7 bytes per call, across iovec boundaries
+        flat = b"".join(bytes(b) for b in bufs)[:7]
+        calls.append((len(bufs), at, len(flat)))
+        return os.pwrite(fd_, flat, at)
+
+    bufs = [b"abc", memoryview(np.arange(40, dtype=np.uint8)), b"", b"tail-of-the-run"]
+    n = pwritev_all(fd, bufs, 5, _pwritev=short)
+    os.close(fd)
+    want = b"abc" + bytes(range(40)) + b"tail-of-the-run"
+    assert n == len(want) and len(calls) == (len(want) + 6) // 7
+    assert path.read_bytes() == b"\xee" * 5 + want
+    fd = os.open(str(path), os.O_WRONLY)
+    with pytest.raises(OSError):
+        pwritev_all(fd, [b"xyz"], 0, _pwritev=lambda *_: 0)
+    os.close(fd)
+    # more iovecs than one pwritev takes
+    many = [bytes([i & 255]) * 3 for i in range(2500)]
+    fd = os.open(str(path), os.O_WRONLY | os.O_TRUNC)
+    assert pwritev_all(fd, many, 0) == 7500
+    os.close(fd)
+    assert path.read_bytes() == b"".join(many)
+
+
+def test_sharded_pack_short_writes_small_runs_and_threaded_reader(tmp_path, monkeypatch):
+    """The same archive through a writer that always writes short, with runs flushed every few hundred bytes, files read
+    from disk by the threaded pread reader into the staging buffer, and the per-stage statistics filled in."""
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib
+    import squishrs_amd.sharded_pack as sp
+    files = _sharded_files()
+    root = tmp_path / "tree"
+    for p, c in files:
+        (root / p).parent.mkdir(parents=True, exist_ok=True)
+        (root / p).write_bytes(c)
+    walked = sp.walk_files(str(root))
+    body = {p: c for p, c in files}
+    want = oracle_lib.load().pack_archive([(r, body[r]) for r, _ in walked], timestamp=7)
+    monkeypatch.setattr(sp, "WRITE_RUN_BYTES", 300)
+
+    def short(fd_, bufs, at):
+        flat = b"".join(bytes(b) for b in bufs)[:1001]
+        return os.pwrite(fd_, flat, at)
+
+    for threads in (1, 4):
+        out = str(tmp_path / ("t%d.squish" % threads))
+        stats = {}
+        size = sp.pack_sharded(walked, out, OracleStages(), device="cpu", timestamp=7, batch_chunks=4, read_threads=threads,
+                               stats=stats, _pwritev=short)
+        assert open(out, "rb").read() == want and size == len(want)
+        assert stats["chunks"] >= stats["compressed"] > 0 and stats["super_batches"] >= 2
+        assert all(k in stats for k in ("read", "h2d", "submit", "wait", "d2h", "exchange2", "write"))
