@@ -175,8 +175,9 @@ int sq_pack_wait(sq_ctx* ctx, uint64_t* h_comp_off, uint32_t* h_comp_len);
  *     is then in flight exactly as after sq_pack_submit and is collected by sq_pack_wait.  d_all_hashes, d_is_new and
  *     d_comp must stay valid until then.  The reference's counterpart of the exchange is the one DashMap all Rayon
  *     workers share (src/util/chunk.rs:52-56,83).
- * SQ_E_INVAL: no lane free, or the calls out of order.  A failing sq_shard_submit_rest consumes the hash step (start
- * the batch again with sq_shard_submit_hash).  SQ_E_CAP (dedup capacity or comp_cap too small), SQ_E_NOMEM and
+ * SQ_E_INVAL: no lane free, or the calls out of order.  A sq_shard_submit_rest[_idx] that finds a pending hash step
+ * consumes it WHATEVER it returns -- every failure, SQ_E_CAP and SQ_E_INVAL for a bad argument included: start the
+ * batch again with sq_shard_submit_hash (a second sq_shard_submit_rest returns SQ_E_INVAL: nothing is pending).  SQ_E_CAP (dedup capacity or comp_cap too small), SQ_E_NOMEM and
  * SQ_E_INVAL are detected before anything is enqueued and commit nothing -- neither the hashes nor the reset of flags
  * bit 0 -- so this rank's replicated set stays equal to the other ranks'; SQ_E_DEVICE (a HIP call failed after the
  * commit) leaves the set in an undefined relation to theirs: every rank must sq_dedup_reset. */
@@ -188,7 +189,12 @@ int sq_shard_submit_rest(sq_ctx* ctx, const uint8_t* d_all_hashes, uint64_t n_to
 /* The same for ANY assignment of the chunks of the global order to ranks (block-cyclic stripes spread the first occurrences,
  * i.e. the compression work, evenly -- with contiguous ranges the first rank holds first occurrences only): this rank's
  * chunk i is entry d_my_idx[i] (device, n x u32, ascending) of d_all_hashes, which holds all ranks' hashes in GLOBAL
- * chunk-index order (the caller permutes the rank-major result of its all-gather). */
+ * chunk-index order (the caller permutes the rank-major result of its all-gather); d_my_idx may be NULL when this rank
+ * holds no chunk of the batch (n == 0 at sq_shard_submit_hash).
+ *
+ * Environment switches of the library (SQ_DEBUG, SQ_FUSE_HASH, SQ_NO_FASTPATH, SQ_FAST_DBG, SQ_STAGE*_WAVES_PER_CU ...:
+ * experiment / bring-up switches, none needed in production) are read ONCE PER PROCESS, by the first call that creates
+ * a context (thread-safe); changing the environment afterwards has no effect on that process. */
 int sq_shard_submit_rest_idx(sq_ctx* ctx, const uint8_t* d_all_hashes, uint64_t n_total, const uint32_t* d_my_idx, uint8_t* d_is_new,
                              uint8_t* d_comp, uint64_t comp_cap, uint32_t flags);
 

@@ -29,10 +29,12 @@ struct sq_env {
     bool allow_any_arch = false;
 };
 static sq_env g_env;
-static void sq_env_read() {
-    static bool done = false;
-    if (done) return;
-    done = true;
+static std::once_flag g_env_once;
+static void sq_env_read_once();
+// read once per PROCESS (squish_gpu.h): the first sq_ctx_create or stateless call of any thread fills g_env, later changes
+// of the environment are not seen
+static void sq_env_read() { std::call_once(g_env_once, sq_env_read_once); }
+static void sq_env_read_once() {
     g_env.debug = getenv("SQ_DEBUG") != nullptr;
     g_env.debug_stats = getenv("SQ_DEBUG_STATS") != nullptr;
     g_env.hash_wave_per_chunk = getenv("SQ_HASH_WAVE_PER_CHUNK") != nullptr;
@@ -122,6 +124,7 @@ struct sq_lane {
     u32 job_waves = 0, job_fwaves = 0;
     size_t job_ws_each = 0, job_etab_bytes = 0;
     bool job_fast = false, job_in_place = false, job_fused = false;
+    bool job_sharded = false; // enqueued through sq_shard_submit_rest[_idx] (sq_pack_wait: no duplicate-ratio note)
     u8* job_slots = nullptr;
     std::vector<u32> job_list; // stage 1's jobs when the batch holds chunks of more than two blocks (one job per pair of blocks)
     u32 job_count = 0;
@@ -1164,6 +1167,7 @@ int sq_pack_submit(sq_ctx* c, const uint8_t* data, const uint64_t* h_off, const 
         HIPCHK(hipEventRecord(L->ev[7], L->stream));
     }
     L->busy = true;
+    L->job_sharded = false;
     c->submitted++;
     return SQ_OK;
 #endif
@@ -1198,8 +1202,8 @@ int sq_shard_wait_hash(sq_ctx* c) {
 }
 
 #ifndef SQ_NO_COMPRESS
-static int shard_submit_rest(sq_ctx* c, const uint8_t* d_all_hashes, uint64_t n_total, uint64_t my_first, const uint32_t* d_my_idx,
-                             uint8_t* d_is_new, uint8_t* d_comp, uint64_t comp_cap, uint32_t flags);
+static int shard_submit_rest(sq_ctx* c, const uint8_t* d_all_hashes, uint64_t n_total, uint64_t my_first, bool by_idx,
+                             const uint32_t* d_my_idx, uint8_t* d_is_new, uint8_t* d_comp, uint64_t comp_cap, uint32_t flags);
 #endif
 
 int sq_shard_submit_rest(sq_ctx* c, const uint8_t* d_all_hashes, uint64_t n_total, uint64_t my_first, uint8_t* d_is_new,
@@ -1208,7 +1212,7 @@ int sq_shard_submit_rest(sq_ctx* c, const uint8_t* d_all_hashes, uint64_t n_tota
     (void)c; (void)d_all_hashes; (void)n_total; (void)my_first; (void)d_is_new; (void)d_comp; (void)comp_cap; (void)flags;
     return SQ_E_COMPRESS;
 #else
-    return shard_submit_rest(c, d_all_hashes, n_total, my_first, nullptr, d_is_new, d_comp, comp_cap, flags);
+    return shard_submit_rest(c, d_all_hashes, n_total, my_first, false, nullptr, d_is_new, d_comp, comp_cap, flags);
 #endif
 }
 
@@ -1218,27 +1222,30 @@ int sq_shard_submit_rest_idx(sq_ctx* c, const uint8_t* d_all_hashes, uint64_t n_
     (void)c; (void)d_all_hashes; (void)n_total; (void)d_my_idx; (void)d_is_new; (void)d_comp; (void)comp_cap; (void)flags;
     return SQ_E_COMPRESS;
 #else
-    if (c && c->shard_pending && !c->ln[c->submitted & 1].shard_len.empty() && (!d_my_idx || !is_device_ptr(d_my_idx))) return SQ_E_INVAL;
-    return shard_submit_rest(c, d_all_hashes, n_total, 0, d_my_idx ? d_my_idx : (const uint32_t*)(uintptr_t)16, d_is_new, d_comp, comp_cap, flags);
+    return shard_submit_rest(c, d_all_hashes, n_total, 0, true, d_my_idx, d_is_new, d_comp, comp_cap, flags);
 #endif
 }
 
 #ifndef SQ_NO_COMPRESS
-// d_my_idx == null: this rank's chunks are the contiguous range [my_first, my_first + n) of the global order; else
-// chunk i of this rank is entry d_my_idx[i] of it (any assignment of chunks to ranks, e.g. block-cyclic).
-static int shard_submit_rest(sq_ctx* c, const uint8_t* d_all_hashes, uint64_t n_total, uint64_t my_first, const uint32_t* d_my_idx,
-                             uint8_t* d_is_new, uint8_t* d_comp, uint64_t comp_cap, uint32_t flags) {
+// by_idx false: this rank's chunks are the contiguous range [my_first, my_first + n) of the global order; true: chunk i
+// of this rank is entry d_my_idx[i] of it (any assignment of chunks to ranks, e.g. block-cyclic; d_my_idx may be null
+// when the rank holds no chunk of the batch).
+// A call that finds a pending hash step CONSUMES it whatever it returns (squish_gpu.h): after a failure the caller starts
+// the batch again with sq_shard_submit_hash.
+static int shard_submit_rest(sq_ctx* c, const uint8_t* d_all_hashes, uint64_t n_total, uint64_t my_first, bool by_idx,
+                             const uint32_t* d_my_idx, uint8_t* d_is_new, uint8_t* d_comp, uint64_t comp_cap, uint32_t flags) {
     if (!c || !c->shard_pending) return SQ_E_INVAL;
+    c->shard_pending = false; // (before the first check that can fail)
     sq_lane* const L = &c->ln[c->submitted & 1];
     sq_lane* const other = &c->ln[(c->submitted & 1) ^ 1];
     u32 const n = (u32)L->shard_len.size();
+    if (by_idx && n && (!d_my_idx || !is_device_ptr(d_my_idx))) return SQ_E_INVAL;
     if ((n_total && !d_all_hashes) || my_first + n > n_total || (n && (!d_is_new || !d_comp))) return SQ_E_INVAL;
     if (n && (!is_device_ptr(d_all_hashes) || !is_device_ptr(d_is_new) || !is_device_ptr(d_comp))) return SQ_E_INVAL;
-    if (d_my_idx && n_total >= 0xFFFFFFFFull) return SQ_E_INVAL;
+    if (by_idx && n_total >= 0xFFFFFFFFull) return SQ_E_INVAL;
     if (sq_slots_bound(L->shard_len.data(), n) > comp_cap) return SQ_E_CAP;
     HIPCHK(hipSetDevice(c->device));
     int r;
-    c->shard_pending = false; // (whatever happens below, the hash step is consumed)
     // every allocation and capacity check of the batch comes BEFORE the replicated dedup set is touched: a failure
     // here leaves this rank's set as the other ranks' (squish_gpu.h)
     {
@@ -1246,7 +1253,7 @@ static int shard_submit_rest(sq_ctx* c, const uint8_t* d_all_hashes, uint64_t n_
         if (seen0 + n_total > c->key_capacity || seen0 + n_total >= 0xFFFFFFFFull) return SQ_E_CAP;
     }
     if ((r = compress_prepare(c, L, L->shard_len.data(), n, d_comp, comp_cap, true, false))) return r;
-    if (d_my_idx && (r = L->b_isnew.ensure((size_t)n_total + 16))) return r;
+    if (by_idx && (r = L->b_isnew.ensure((size_t)n_total + 16))) return r;
     // the dedup set is shared: this batch's reset / insert must follow the previous batch's dedup kernels
     if (other->busy) HIPCHK(hipStreamWaitEvent(L->stream, other->dedup_done, 0));
     if (flags & 1u) {
@@ -1254,7 +1261,7 @@ static int shard_submit_rest(sq_ctx* c, const uint8_t* d_all_hashes, uint64_t n_
         HIPCHK(hipMemsetAsync(c->d_unique, 0, 64, L->stream));
         c->n_seen = 0;
     }
-    if (d_my_idx) { // flags of ALL chunks of the global order, then this rank's picked out of them
+    if (by_idx) { // flags of ALL chunks of the global order, then this rank's picked out of them
         if ((r = dedup_async(c, L, d_all_hashes, n_total, 0, (u32)n_total, (u8*)L->b_isnew.p))) return r;
         if (n) {
             hipLaunchKernelGGL(sqd::k_pick_flags, dim3((n + 255) / 256), dim3(256), 0, L->stream, (const u8*)L->b_isnew.p, d_my_idx, n,
@@ -1269,6 +1276,7 @@ static int shard_submit_rest(sq_ctx* c, const uint8_t* d_all_hashes, uint64_t n_
         return r;
     }
     L->busy = true;
+    L->job_sharded = true; // (this rank's share of a global batch: its new-ratio says nothing about the fused form's crossover)
     c->submitted++;
     return SQ_OK;
 }
@@ -1311,7 +1319,7 @@ int sq_pack_wait(sq_ctx* c, uint64_t* h_comp_off, uint32_t* h_comp_len) {
     L->busy = false;
     c->collected++;
     if (r) return r;
-    if (n && !c->shard_pending) {
+    if (n && !L->job_sharded) {
         u32 n_new = 0;
         for (u32 i = 0; i < n; i++) n_new += h_comp_len[i] != 0;
         note_dup_ratio(c, n, n_new);

@@ -535,6 +535,56 @@ def test_shard_split_form_two_batches_in_flight(oracle):
     st.close()
 
 
+def test_failing_shard_rest_consumes_the_hash_step(oracle):
+    """include/squish_gpu.h: a sq_shard_submit_rest[_idx] that finds a pending hash step consumes it whatever it returns
+    (SQ_E_CAP for a small comp buffer, SQ_E_INVAL for a missing index array) and commits nothing: a second rest call is
+    out of order, the batch starts again with sq_shard_submit_hash and then gives the flags of a fresh set."""
+    import torch
+    import squishrs_amd
+    from squishrs_amd import SquishError
+    L, n = 65536, 16
+    base = [corpus.random_bytes(91, i, L) for i in range(n)]
+    st = squishrs_amd.ChunkStore(device=0, max_chunk=L, dedup_capacity=1024)
+    try:
+        d = torch.frombuffer(bytearray(b"".join(base)), dtype=torch.uint8).cuda()
+        offs = np.arange(n, dtype=np.uint64) * np.uint64(L)
+        lens = np.full(n, L, dtype=np.uint32)
+        h = torch.zeros(n * 16, dtype=torch.uint8, device="cuda")
+        f = torch.zeros(n, dtype=torch.uint8, device="cuda")
+        comp = torch.empty(st.slots_bound(lens), dtype=torch.uint8, device="cuda")
+        idx = torch.arange(n, dtype=torch.int32, device="cuda")
+        # (a) comp_cap too small: SQ_E_CAP, the hash step is gone
+        st.shard_submit_hash(d, offs, lens, h)
+        st.shard_wait_hash()
+        with pytest.raises(SquishError):
+            st.shard_submit_rest(h, n, 0, f, comp[:1024])
+        with pytest.raises(SquishError):
+            st.shard_submit_rest(h, n, 0, f, comp)           # nothing pending any more
+        assert st.len() == 0                                  # nothing was committed
+        # (b) the idx form without an index array: SQ_E_INVAL, consumed as well
+        st.shard_submit_hash(d, offs, lens, h)
+        st.shard_wait_hash()
+
+        class _Null:
+            @staticmethod
+            def data_ptr():
+                return 0
+        with pytest.raises(SquishError):
+            st.shard_submit_rest_idx(h, n, _Null, f, comp)
+        with pytest.raises(SquishError):
+            st.shard_wait_hash()
+        assert st.len() == 0
+        # (c) the batch again, from the hash: all first occurrences
+        st.shard_submit_hash(d, offs, lens, h)
+        st.shard_wait_hash()
+        st.shard_submit_rest_idx(h, n, idx, f, comp)
+        co, cl = st.pack_wait(n)
+        assert f.cpu().tolist() == [1] * n and st.len() == n
+        assert comp[int(co[5]):int(co[5]) + int(cl[5])].cpu().numpy().tobytes() == oracle.compress_chunk(base[5])
+    finally:
+        st.close()
+
+
 def test_empty_shard_batch_still_orders_the_shared_dedup_set(oracle):
     """A rank may hold 0 chunks of a super-batch while the other ranks' hashes (n_total > 0) must be committed to its
     replicated set: sq_shard_submit_rest queues that copy + insert on the lane, and sq_pack_wait of such an EMPTY batch
