@@ -61,6 +61,38 @@ def _pmc_traffic(kernel, n, L):
         return None
 
 
+def _whole_step_traffic(n, L):
+    """Sum of _pmc_traffic over every kernel of a step that the committed PMC passes saw at this chunk size."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
+            t = json.load(f)
+    except (OSError, ValueError):
+        return None
+    tot, seen = 0.0, 0
+    for key in t:
+        k, _, ls = key.partition("@")
+        if ls == str(L) and k != "sqd::k_read_bw":
+            v = _pmc_traffic(k, n, L)
+            if v is not None:
+                tot += v
+                seen += 1
+    return tot if seen else None
+
+
+def _mixed_traffic():
+    """configs[3]: HBM bytes the compress kernel moves per algorithmic byte on 2 MiB mixed chunks, from the committed
+    rocprofv3 PMC passes (tools/pmc_mixed_traffic.sh -> profiles/pmc_traffic_mixed.json); None when absent."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "pmc_traffic_mixed.json")) as f:
+            m = json.load(f)["mixed"]
+        return {"traffic_ratio": m["traffic_ratio"], "fetched_bytes_per_chunk": m["FETCH_SIZE_KB"] * 1024 / m["chunks"],
+                "written_bytes_per_chunk": m["WRITE_SIZE_KB"] * 1024 / m["chunks"], "measured_on_chunks": m["chunks"],
+                "source": "profiles/pmc_traffic_mixed.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, steady-state launch of "
+                          "sqz::k_compress_batch on 2 MiB mixed chunks)"}
+    except (OSError, ValueError, KeyError, TypeError):
+        return None
+
+
 def _usable_cpus():
     try:    # CPUs this process may really use: affinity mask, and the cgroup's CPU quota if there is one
         T = len(os.sched_getaffinity(0))
@@ -348,6 +380,9 @@ def main():
                                                            "order to the ranks (0 = contiguous ranges: rank 0 then holds first occurrences only)")
     ap.add_argument("--no-small-classes", action="store_true")
     ap.add_argument("--no-random-2m", action="store_true")
+    ap.add_argument("--oracle-sample", type=int, default=16384,
+                    help="headline chunks whose frames the CPU-baseline pass (the oracle's pack pipeline) also produces; each is compared "
+                         "with the GPU's frame by (length, XXH3-128 of the frame)")
     a = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -487,7 +522,7 @@ def main():
                         note()
             return r
 
-        run(max(W, 2) if pipelined else W, False)   # (both lanes of the context warm)
+        run(max(W, 2) if (pipelined or (world == 1 and slots) or cyclic) else W, False)   # (both lanes of the context warm: submit alternates them)
         barrier()
         t_start = time.perf_counter()
         r = run(K, True)
@@ -560,8 +595,11 @@ def main():
         hh = hashes.cpu().numpy().reshape(-1, 16)
         for i in pick[:32]:
             assert hh[i].tobytes() == o.hash_chunk(corpus.random_bytes(cfg_id, int(my_plan[i]), L))
-        parity = {"raw_block_frames_checked_on_device": int(raw_rows.numel()), "frames_with_compressed_blocks": int(len(odd)),
-                  "frames_compared_with_oracle": len(pick), "of_them_from_stage2_list": int(min(len(s2), 24)),
+        parity = {"raw_block_frames_equal_to_the_raw_block_form_of_their_input_on_device": int(raw_rows.numel()),
+                  "what_that_proves": "the frame is a valid frame of raw blocks of ITS chunk; that libzstd would also emit raw blocks for the chunk "
+                                      "is what the comparisons with the oracle's frames show (next keys), on a sample",
+                  "frames_with_compressed_blocks": int(len(odd)),
+                  "frames_compared_with_oracle_bytes": len(pick), "of_them_from_stage2_list": int(min(len(s2), 24)),
                   "stage2_list_len": int(len(s2))}
     else:
         for i in sorted(set([0, 1, n // 2, n - 1])):
@@ -570,6 +608,18 @@ def main():
                 fr = comp[int(comp_off[i]):int(comp_off[i]) + int(comp_len[i])].cpu().numpy().tobytes()
                 assert fr == o.compress_chunk(c)
         parity = {"frames_compared_with_oracle": 4}
+
+    # (length, XXH3-128) of the headline's first frames by the product's own hash kernel (pinned by tests/test_hash_gpu.py),
+    # taken now: the other legs reuse `data` and `comp`.  The CPU-baseline pass below pushes the same chunks through the
+    # oracle's pack pipeline and every frame it produces is compared with these.
+    pool_n = min(n, a.oracle_sample) if (world == 1 and slots and not a.no_cpu_baseline and not a.no_frame_check) else 0
+    head_dig = head_len = None
+    if pool_n:
+        dg = torch.zeros(pool_n * 16, dtype=torch.uint8, device="cuda")
+        store.hash_device(comp, comp_off[:pool_n].astype(np.uint64), comp_len[:pool_n].astype(np.uint32), dg)
+        head_dig = dg.cpu().numpy().reshape(pool_n, 16)
+        head_len = comp_len[:pool_n].copy()
+        del dg
 
     out = None
     if rank == 0:
@@ -623,7 +673,11 @@ def main():
                     "dominant_kernel_frac": fast_bytes / (kern_solo["fast"] / 1e3) / 1e9 / 8000.0 if kern_solo["fast"] > 0 else None},
                 "whole_step": {"algorithmic_bytes": path_bytes, "ms": ms_per_step,
                                "achieved": path_bytes / (ms_per_step / 1e3) / 1e9,
-                               "frac": path_bytes / (ms_per_step / 1e3) / 1e9 / 8000.0},
+                               "frac": path_bytes / (ms_per_step / 1e3) / 1e9 / 8000.0,
+                               "traffic": _whole_step_traffic(n_new, L),
+                               "traffic_note": "sum over the step's kernels (stage 1, hash finish, dedup, stage 2) of the committed steady-state PMC "
+                                               "passes (profiles/pmc_traffic.json: both lanes warm, the last launch of each lane averaged), corrected "
+                                               "for gfx950's half-counted streaming reads, scaled to this batch"},
                 "compress_stage": {"k_incompressible_batch_ms": fms, "k_compress_batch_ms": cms,
                                    "chunks_decided_by_stage1": decided,
                                    "stage_GBps": (n_new * L + clen_total) / ((fms + cms) / 1e3) / 1e9},
@@ -641,7 +695,7 @@ def main():
         cpu = None
         host_random = None
         if world == 1 and not a.no_cpu_baseline:
-            host_random = data[:min(n, 4 * T_cpu + 64) * L].cpu().numpy()
+            host_random = data[:max(pool_n, min(n, 4 * T_cpu + 64)) * L].cpu().numpy()
         e2e = None
         if other and not a.no_end_to_end and L == 262144:
             e2e = _end_to_end(torch, o, data, L, min(a.e2e_files, n))
@@ -679,8 +733,19 @@ def main():
             # workers over the files, sharded dedup map with the lock held during compression, ONE writer thread --
             # at -j = usable CPUs and at -j 25 (the reference's default, src/cmd/mod.rs:16), on a bounded sample of
             # the headline workload (the buffer is cycled; each pass counts as new files).
-            pool_n = host_random.size // L
-            pj = _cpu_pipeline(o, host_random, pool_n, L, T_cpu, max(2.0, a.cpu_seconds * 0.5))
+            pool_h = host_random.size // L
+            if pool_n:
+                # the timed pass also keeps (length, XXH3-128) of every frame of its first sweep over the sample: parity
+                # against the GPU's frames of the same chunks, thousands of them instead of a hand-picked few
+                _bind_oracle_bench(o)
+                pj, ol, od, _cov = _cpu_pipeline2(o, host_random, offs[:pool_h], lens[:pool_h], T_cpu, max(2.0, a.cpu_seconds * 0.5))
+                got = np.nonzero(ol[:pool_n])[0]
+                assert (ol[got] == head_len[got]).all(), "headline: a frame's length differs from the oracle pipeline's"
+                assert (od[got] == head_dig[got]).all(), "headline: a frame differs from the oracle pipeline's (XXH3-128 of the frame)"
+                parity["frames_equal_to_oracle_frame_length_and_xxh3"] = int(len(got))
+            else:
+                pj = _cpu_pipeline(o, host_random, pool_h, L, T_cpu, max(2.0, a.cpu_seconds * 0.5))
+            pool_n = pool_h
             p25 = _cpu_pipeline(o, host_random, pool_n, L, 25, max(2.0, a.cpu_seconds * 0.4))
             # and the bare hash + compress loop of round 1 (no map, no writer), for continuity
             o.lib.sqo_bench_insert_threads.restype = ctypes.c_uint64
@@ -898,6 +963,7 @@ def main():
                 "MiB_per_s_per_wave": in3_total / 2**20 / (float(np.mean(ks["compress"])) / 1e3) / min(n3, 2048),
                 "parity": {"frames": n3, "equal_to_oracle_frame_length_and_xxh3": n_cmp, "equal_to_oracle_bytes": len(direct),
                            "decoded_and_rehashed_on_host": done, "unchecked_time_budget": int(len(rest) - done)},
+                "traffic": _mixed_traffic(),
                 "random_access_probe": {"requests_per_s": gather,
                                         "note": "sq_calibrate_gather: 16-byte loads at random places of this corpus, 8 in flight per lane (DESIGN.md 4.3)"},
                 "cpu_baseline": cmix, "gen_seconds_host": mixed_gen_s}
