@@ -338,9 +338,9 @@ SQ_DEV void cert_lds_core(CertCtx& cx, FastLds* L, u8* rawOut) {
     cx.hashDone = 0;
     const u8* const base = cx.base;
     u32 const nCert = cx.nCert;
-    u32 const blk1 = (nCert > cx.certCnt0) ? cx.base1Pos : 0xFFFFFFFFu;
+    u32 const blk1 = wv_uni((nCert > cx.certCnt0) ? cx.base1Pos : 0xFFFFFFFFu);
     u32 certEnd = cx.chunkEndPos, certEnd1 = cx.chunkEndPos;
-    u32 const pEnd = cx.chunkEndPos - 3; // one past the last p with p + 4 <= chunkEnd
+    u32 const pEnd = wv_uni(cx.chunkEndPos - 3); // one past the last p with p + 4 <= chunkEnd
     const u32* const lvlWords = cx.schedTab + SQZ_SCHEDLVL_OFF;
     SQ_L u32* const bloom = (SQ_L u32*)L->bloom;
     SQ_L u16* const vals = (SQ_L u16*)L->vals; // 16-bit tags: with the bucket's 10 bits, 26 bits of the value
@@ -596,11 +596,16 @@ SQ_DEV void cert_lds_core(CertCtx& cx, FastLds* L, u8* rawOut) {
     FPROF_ADD(L, 0, t_build);
     // ---- scan
     const SQ_L u32* const B = bloom;
-    const u8* const src0 = base + SQZ_WINDOW_START;
+    // (wv_uni: the chunk's address and length reach this function through vector loads of off[] / len[]; values derived
+    // from them are wave-uniform but sit in vector registers, and hipcc then computes every address of the scan with
+    // 64-bit VALU adds per lane.  One v_readfirstlane each puts them where the scalar unit can do that arithmetic.)
+    const u8* const src0 = (const u8*)wv_uni64((u64)(size_t)(base + SQZ_WINDOW_START));
     const u8* const a0 = src0 - ((size_t)src0 & 15);
     s32 const p0 = (s32)SQZ_WINDOW_START - (s32)(src0 - a0); // position of a0 (may be negative)
-    const u8* const lastByte = base + cx.chunkEndPos - 1;
+    u32 const chunkEndU = wv_uni(cx.chunkEndPos), base0U = wv_uni(cx.base0Pos), tailU = wv_uni(cx.tail), tab0U = wv_uni(cx.tab0);
+    const u8* const lastByte = src0 - SQZ_WINDOW_START + chunkEndU - 1;
     const u8* const aLast = lastByte - ((size_t)lastByte & 15);
+    rawOut = (u8*)wv_uni64((u64)(size_t)rawOut);
     bool const rawCopy = rawOut != nullptr && src0 == a0;
     // the fused hash needs the whole chunk streamed (a scan that would stop at an early certificate end goes on:
     // what it finds beyond that end changes nothing) and rounds that are XXH3 blocks (aligned chunk)
@@ -610,12 +615,12 @@ SQ_DEV void cert_lds_core(CertCtx& cx, FastLds* L, u8* rawOut) {
         return (ce < pEnd && !hashOn) ? ce : pEnd;
     };
     // the rounds of 1 KiB from p0 up to the stop are dealt out in contiguous runs, one per wave
-    u32 const nRounds = p0 < (s32)scanStop() ? ((u32)((s32)scanStop() - p0) + 1023u) >> 10 : 0u;
+    u32 const nRounds = wv_uni(p0 < (s32)scanStop() ? ((u32)((s32)scanStop() - p0) + 1023u) >> 10 : 0u);
     // (fused hash: runs of a multiple of four rounds, so that only the last wave's last loop step can be short)
     u32 const perWave = hashOn ? ((nRounds + NW - 1) / NW + SQZ_FAST_DEPTH_HS - 1) / SQZ_FAST_DEPTH_HS * SQZ_FAST_DEPTH_HS : (nRounds + NW - 1) / NW;
     auto runStart = [&](u32 w) -> s32 { return p0 + (s32)(1024u * (perWave * w < nRounds ? perWave * w : nRounds)); };
-    s32 pos = runStart(wv);
-    s32 const myStop = (runStart(wv + 1) < (s32)scanStop()) ? runStart(wv + 1) : (s32)scanStop();
+    s32 pos = (s32)wv_uni((u32)runStart(wv));
+    s32 const myStop = (s32)wv_uni((u32)((runStart(wv + 1) < (s32)scanStop()) ? runStart(wv + 1) : (s32)scanStop()));
     u32 const lastOff = (u32)(aLast - a0);
     auto loadRound = [&](s32 rp) -> sq_v4u { // uniform base + 32-bit lane offset, clamped to the last window
         u32 const o = (u32)(rp - p0) + 16 * lane;
@@ -633,15 +638,15 @@ SQ_DEV void cert_lds_core(CertCtx& cx, FastLds* L, u8* rawOut) {
     // AL (std::true_type): the chunk starts on a 16-byte boundary, so a lane's 16 positions are one window
     // of the schedule's bitmap (SQZ_SCHEDBITS_OFF): `wl` is then that window's mask itself, loaded with the
     // stream, and none of the level arithmetic below runs.
-    const u16* const schedBits = (const u16*)(cx.schedTab + SQZ_SCHEDBITS_OFF);
+    const u16* const schedBits = (const u16*)wv_uni64((u64)(size_t)(cx.schedTab + SQZ_SCHEDBITS_OFF));
     auto loadLevels = [&](auto AL, s32 rp, u32& wl) {
         if constexpr (decltype(AL)::value) {
             // (rounds in front of the first certified block -- the earlier blocks of a large chunk, base0Pos > the
             // chunk's start -- hold no scheduled position of THIS certificate: their word is loaded like any other, from
             // a clamped index, and dropped in round())
             bool const second = (blk1 != 0xFFFFFFFFu) && rp >= (s32)blk1;
-            u32 const tabSel = second ? SQZ_SCHEDBITS_N : (cx.tab0 ? SQZ_SCHEDBITS_N : 0u);
-            u32 const wi = (((u32)rp - (second ? blk1 : cx.base0Pos)) >> 4) + lane;
+            u32 const tabSel = second ? SQZ_SCHEDBITS_N : (tab0U ? SQZ_SCHEDBITS_N : 0u);
+            u32 const wi = (((u32)rp - (second ? blk1 : base0U)) >> 4) + lane;
             // (a 4-byte load of the 2-byte word: the upper half -- the next window's word -- never reaches the result,
             // the masks it is combined with have 16 bits; as a 2-byte load the value's zero extension became an
             // instruction of its own that hipcc placed at the loop's back edge, behind a wait for ALL loads in flight)
@@ -692,11 +697,11 @@ SQ_DEV void cert_lds_core(CertCtx& cx, FastLds* L, u8* rawOut) {
     auto schedMaskFast = [&](s32 lo, u32 wa, u32 wb) -> u32 {
         bool const second = (blk1 != 0xFFFFFFFFu) && lo >= (s32)blk1;
         u32 const bs = second ? blk1 : SQZ_WINDOW_START;
-        u32 const blkEnd = (!second && blk1 != 0xFFFFFFFFu) ? blk1 : cx.chunkEndPos;
+        u32 const blkEnd = (!second && blk1 != 0xFFFFFFFFu) ? blk1 : chunkEndU;
         s32 const r = lo - (s32)bs;
         bool const plain = r >= 4096 && (u32)(lo + 16) <= blkEnd - 8 && !((blk1 != 0xFFFFFFFFu) && lo < (s32)blk1 && lo + 16 > (s32)blk1);
         if (wv_ballot(!plain)) {
-            u32 const m = fast_sched_mask_rare(lvlWords, lo, blk1, cx.chunkEndPos, wa, wb, plain ? 1u : 0u);
+            u32 const m = fast_sched_mask_rare(lvlWords, lo, blk1, chunkEndU, wa, wb, plain ? 1u : 0u);
             // This rare path loads level words itself.  Left pending at the join, such a load makes hipcc
             // guard the main path's registers with s_waitcnt vmcnt(0) in EVERY round, which drains the four
             // rounds of stream loads in flight (measured: the scan ran at one memory latency per round).
@@ -727,6 +732,8 @@ SQ_DEV void cert_lds_core(CertCtx& cx, FastLds* L, u8* rawOut) {
     // one round: Bloom tests, scheduled positions removed, positives collected; false = list of hits full
     // fused hash: this lane's slot of the wave's staging area (rows of 64 B: lanes 0..3 of each row write)
     SQ_L u32* const hstWave = (SQ_L u32*)L->hstage + wv * (SQZ_FAST_DEPTH_HS * 64u);
+    // byte address (LDS) of this lane's staging slot for round 0 of a step: rows of 16 lanes, lanes 0..3 of a row hold its sums
+    u32 const hstLaneAddr = (u32)(size_t)hstWave + 4u * (((lane & 0x30u) >> 2) | (lane & 3u));
     const SQ_L u32* const hsecLane = (const SQ_L u32*)L->hsec + lane; // word k of the lane's secret at [64 k + lane]: four
                                                                       // conflict-free 4-byte reads (a 16-byte read per lane costs ~40 LDS cycles)
     // fused hash: the loop always runs whole steps of SQZ_FAST_DEPTH_HS rounds with ONE exit test per step (exits
@@ -734,56 +741,30 @@ SQ_DEV void cert_lds_core(CertCtx& cx, FastLds* L, u8* rawOut) {
     // loads in flight, i.e. a wait for all of them in every step).  Rounds beyond the wave's run, and all rounds
     // once the filter part has given up (hsDead: the list of hits is full), only hash and copy.
     bool hsDead = false;
-    auto round = [&](auto AL, auto HS, auto IR, sq_v4u w, sq_v4u wn, u32 wl) -> bool {
-        bool const active = !decltype(HS)::value || (!hsDead && pos < myStop);
-        u32 wa = 0, wb = 0;
-        if constexpr (!decltype(AL)::value) pickLevels(pos, wl, wa, wb);
-        u32 d4;
-        {
-            u32 const nx = (u32)__builtin_amdgcn_update_dpp(0, (int)w.x, 0x130 /* wave_shl:1 */, 0xF, 0xF, false);
-            // lane 63 continues in lane 0 of the next round's load: a wave rotation, no trip through an SGPR
-            // (a v_readfirstlane of that vector gets hoisted into earlier rounds, where it waits for a load
-            // that is meant to stay in flight)
-            u32 const n63 = (u32)__builtin_amdgcn_update_dpp(0, (int)wn.x, 0x134 /* wave_rol:1 */, 0xF, 0xF, false);
-            d4 = (lane == 63) ? n63 : nx;
-        }
+    u32 const lane16 = 16u * lane, lane2 = 2u * lane; // the constant per-lane offsets behind the scan's wave-uniform pointers
+    // ---- the pieces of a round (every lambda is inlined at each of its uses)
+    // the dword behind the lane's 16 bytes: lane l + 1's first, for lane 63 the next round's lane 0
+    auto nextDword = [&](sq_v4u w, sq_v4u wn) __attribute__((always_inline)) -> u32 {
+        // lane 63 continues in lane 0 of the next round's load: a wave rotation, no trip through an SGPR
+        // (a v_readfirstlane of that vector gets hoisted into earlier rounds, where it waits for a load
+        // that is meant to stay in flight)
+        u32 const n63 = (u32)__builtin_amdgcn_update_dpp(0, (int)wn.x, 0x134 /* wave_rol:1 */, 0xF, 0xF, false);
+        // wave_shl:1 has no source for lane 63, which therefore keeps `old` (bound_ctrl off): the rotated word -- two DPP
+        // moves, no select, no lane mask to keep in scalar registers
+        return (u32)__builtin_amdgcn_update_dpp((int)n63, (int)w.x, 0x130 /* wave_shl:1 */, 0xF, 0xF, false);
+    };
+    // The filter's probes of the value at p are keyed by its three 2-byte windows (at p, p + 1, p + 2) in
+    // ONE table: a probe of position p is also a probe of its neighbours.  So each of the lane's 18
+    // windows (16 of its own bytes, 2 reaching into the next lane's) is looked up once, and a position
+    // passes when the bits of its own window and of the next two are set: three probes (0.3 % false
+    // positives at 10,500 keys in 64 Kibit) for the price of one.  Returns the 16 positions' verdicts.
+    // The 18 answers are collected Horner-wise (one v_lshl_or each), i.e. in REVERSE order: window j ends up
+    // at bit 17 - j, the three-window AND works the same on the mirrored word, and one v_bfrev turns it back.
+    // Order of issue: all 18 addresses, all 18 reads, then the 18 bit indices (VALU work that covers the reads'
+    // latency), then the answers.  (Compiled as written above -- four reads, their answers, the next four --
+    // a round paid five LDS round trips one after the other.)
+    auto filterBits = [&](sq_v4u w, u32 d4) __attribute__((always_inline)) -> u32 {
         u32 const d[5] = {w.x, w.y, w.z, w.w, d4};
-        u32 const stop = scanStop();
-        s32 const lo = pos + (s32)(16 * lane);
-        u32 okMask;
-        if constexpr (decltype(AL)::value) {
-            // aligned chunk: the round starts at or after the chunk start and lies in one block, so the
-            // destination of the raw copy is a wave-uniform base plus 16 bytes per lane
-            // (block b's payload sits 3 (b + 1) bytes behind its place in the chunk: every block but the last is full;
-            // of a large chunk only the certified blocks are copied, the ones in front belong to other workgroups)
-            if (rawCopy && (u32)pos >= cx.base0Pos && (u32)lo + 16 <= cx.chunkEndPos) // (clamped loads beyond the end fail this test)
-#if SQZ_FAST_NT & 2
-                sq_gwr128_nt(rawOut + ((u32)pos - SQZ_WINDOW_START) + 3u * ((((u32)pos - SQZ_WINDOW_START) >> 17) + 1u) + 16 * lane, w);
-#else
-                sq_gwr128(rawOut + ((u32)pos - SQZ_WINDOW_START) + 3u * ((((u32)pos - SQZ_WINDOW_START) >> 17) + 1u) + 16 * lane, w);
-#endif
-            okMask = active ? 0xFFFFu : 0u;
-            if ((u32)pos + 1024 > stop) {
-                s32 l = (s32)stop - lo;
-                l = l < 0 ? 0 : (l > 16 ? 16 : l);
-                okMask &= (1u << l) - 1u;
-            }
-        } else {
-            s32 f = (s32)SQZ_WINDOW_START - lo, l = (s32)stop - lo;
-            f = f < 0 ? 0 : (f > 16 ? 16 : f);
-            l = l < 0 ? 0 : (l > 16 ? 16 : l);
-            okMask = ((1u << l) - 1u) & ~((1u << f) - 1u);
-        }
-        // The filter's probes of the value at p are keyed by its three 2-byte windows (at p, p + 1, p + 2) in
-        // ONE table: a probe of position p is also a probe of its neighbours.  So each of the lane's 18
-        // windows (16 of its own bytes, 2 reaching into the next lane's) is looked up once, and a position
-        // passes when the bits of its own window and of the next two are set: three probes (0.3 % false
-        // positives at 10,500 keys in 64 Kibit) for the price of one.
-        // The 18 answers are collected Horner-wise (one v_lshl_or each), i.e. in REVERSE order: window j ends up
-        // at bit 17 - j, the three-window AND works the same on the mirrored word, and one v_bfrev turns it back.
-        // Order of issue: all 18 addresses, all 18 reads, then the 18 bit indices (VALU work that covers the reads'
-        // latency), then the answers.  (Compiled as written above -- four reads, their answers, the next four --
-        // a round paid five LDS round trips one after the other.)
         u32 src[18], pw[18];
 #pragma unroll
         for (u32 q = 0; q < 5; q++) {
@@ -814,26 +795,13 @@ SQ_DEV void cert_lds_core(CertCtx& cx, FastLds* L, u8* rawOut) {
             // (spelled out: left to itself hipcc turns the chain into shifts and three-way ORs, 7 instead of 4 per word)
             asm("v_lshl_or_b32 %0, %1, 1, %2" : "=v"(bm) : "v"(bm), "v"(bit));
         }
-        u32 cm = (__builtin_bitreverse32(bm & (bm << 1) & (bm << 2)) >> 14) & okMask;
-        if constexpr (decltype(AL)::value) {
-            // the window's bitmap word; a block's searches stop 8 bytes before its end (a short last block
-            // uses a prefix of the table)
-            bool const second = (blk1 != 0xFFFFFFFFu) && pos >= (s32)blk1;
-            u32 const lim = ((!second && blk1 != 0xFFFFFFFFu) ? blk1 : cx.chunkEndPos) - cx.tail;
-            u32 sm = (u32)pos >= cx.base0Pos ? wl : 0u;
-            if ((u32)pos + 1024 > lim) {
-                s32 nb = (s32)lim - lo;
-                nb = nb < 0 ? 0 : (nb > 16 ? 16 : nb);
-                sm &= (1u << nb) - 1u;
-            }
-            cm &= ~sm;
-        } else
-            cm &= ~schedMaskFast(lo, wa, wb);
+        return __builtin_bitreverse32(bm & (bm << 1) & (bm << 2)) >> 14; // (16 bits: windows j, j + 1, j + 2 of position j)
+    };
+    // compaction (one positive per lane and turn) into the list that collects the positives of several
+    // rounds: a look-up is a chain of dependent LDS reads, paid once per 64 positives instead of once
+    // per round.  false = the list of hits is full
+    auto collect = [&](u32 cm, s32 lo, sq_v4u w, u32 d4) __attribute__((always_inline)) -> bool {
         bool ok = true;
-        if (nCand == 0 && active) pendFrom = pos; // nothing older than this round is waiting for its look-up
-        // compaction (one positive per lane and turn) into the list that collects the positives of several
-        // rounds: a look-up is a chain of dependent LDS reads, paid once per 64 positives instead of once
-        // per round
         for (;;) {
             u64 const m = wv_ballot(cm != 0);
             if (!m) break;
@@ -853,30 +821,129 @@ SQ_DEV void cert_lds_core(CertCtx& cx, FastLds* L, u8* rawOut) {
             nCand += (u32)__popcll(m);
         }
         wv_fence();
-        if constexpr (decltype(HS)::value) { // (here, after the compaction loop: the filter's 54 temporaries are dead)
-            // XXH3: the eight sums of this 1 KiB block (XXH3_accumulate_512 over its 16 stripes, without the
-            // accumulators): two per lane, then over the four stripes of the row
-            sq_v4u const ks = (sq_v4u){hsecLane[0], hsecLane[64], hsecLane[128], hsecLane[192]};
-            u64 const d0 = ((u64)w.y << 32) | w.x, d1 = ((u64)w.w << 32) | w.z;
-            u64 const k0 = d0 ^ (((u64)ks.y << 32) | ks.x), k1 = d1 ^ (((u64)ks.w << 32) | ks.z);
-            u64 c0 = (u64)(u32)k0 * (u64)(u32)(k0 >> 32) + d1;
-            u64 c1 = (u64)(u32)k1 * (u64)(u32)(k1 >> 32) + d0;
-            u32 a0 = (u32)c0, a1 = (u32)(c0 >> 32), b0 = (u32)c1, b1 = (u32)(c1 >> 32);
-            SQZ_ROW_SUM4(a0, a1, b0, b1);
-            // lanes 0..3 of each row write the row's four pairs of sums: 64 B per row.  (The predicate and the slot's
-            // offset are recomputed each round -- four instructions -- rather than kept in registers through the
-            // loop, which is at its limit of 128 vector and ~100 scalar registers: hence the laundered lane number.)
-            u32 l2 = lane;
-            asm volatile("" : "+v"(l2));
-            if ((l2 & 12) == 0) { // word k of (round, slot) at [64 k + 16 round + slot]: the flush reads [64 k + lane]
-                SQ_L u32* const hw = hstWave + 16 * decltype(IR)::value + (((l2 & 0x30u) >> 2) | (l2 & 3u));
-                hw[0] = a0;
-                hw[64] = a1;
-                hw[128] = b0;
-                hw[192] = b1;
-            }
+        return ok;
+    };
+    // XXH3: the eight sums of this 1 KiB block (XXH3_accumulate_512 over its 16 stripes, without the
+    // accumulators): two per lane, then over the four stripes of the row; lanes 0..3 of each row stage the row's four
+    // pairs of sums (64 B per row) for the step's flush.  (The predicate and the slot's offset are recomputed each
+    // round -- four instructions -- rather than kept in registers through the loop, which is at its limit of 128
+    // vector and ~100 scalar registers: hence the laundered lane number.)
+    auto hashRound = [&](auto IR, sq_v4u w) __attribute__((always_inline)) {
+        sq_v4u const ks = (sq_v4u){hsecLane[0], hsecLane[64], hsecLane[128], hsecLane[192]};
+        u64 const d0 = ((u64)w.y << 32) | w.x, d1 = ((u64)w.w << 32) | w.z;
+        u64 const k0 = d0 ^ (((u64)ks.y << 32) | ks.x), k1 = d1 ^ (((u64)ks.w << 32) | ks.z);
+        u64 c0 = (u64)(u32)k0 * (u64)(u32)(k0 >> 32) + d1;
+        u64 c1 = (u64)(u32)k1 * (u64)(u32)(k1 >> 32) + d0;
+        u32 a0_ = (u32)c0, a1_ = (u32)(c0 >> 32), b0_ = (u32)c1, b1_ = (u32)(c1 >> 32);
+        SQZ_ROW_SUM4(a0_, a1_, b0_, b1_);
+        // lanes 0..3 of each row -- exec = 0x000F000F000F000F, a literal: no compare, no mask register to keep -- store
+        // word k of (round, slot) at [64 k + 16 round + slot]: the flush reads [64 k + lane].  (Wave-uniform code: exec is
+        // all ones here and is put back; LDS executes a wave's accesses in order, the flush's reads come behind these.)
+        {
+            u32 const hwA = hstLaneAddr + 64u * decltype(IR)::value; // byte address of this lane's slot in round IR's row group
+            u64 keep;
+            asm volatile("s_mov_b64 %0, exec\n\t"
+                         "s_mov_b32 exec_lo, 0x000f000f\n\t"
+                         "s_mov_b32 exec_hi, 0x000f000f\n\t"
+                         "ds_write2st64_b32 %1, %2, %3 offset1:1\n\t"
+                         "ds_write2st64_b32 %1, %4, %5 offset0:2 offset1:3\n\t"
+                         "s_mov_b64 exec, %0"
+                         : "=&s"(keep)
+                         : "v"(hwA), "v"(a0_), "v"(a1_), "v"(b0_), "v"(b1_)
+                         : "memory");
         }
+    };
+    // where the raw-block payload of the round at rp goes (block b's payload sits 3 (b + 1) bytes behind its place in
+    // the chunk: every block but the last is full)
+    auto rawDst = [&](u32 rp) __attribute__((always_inline)) -> u8* {
+        return rawOut + (rp - SQZ_WINDOW_START) + 3u * (((rp - SQZ_WINDOW_START) >> 17) + 1u);
+    };
+    // one round: filter tests, scheduled positions removed, positives collected; false = list of hits full
+    auto round = [&](auto AL, auto HS, auto IR, sq_v4u w, sq_v4u wn, u32 wl) -> bool {
+        bool const active = !decltype(HS)::value || (!hsDead && pos < myStop);
+        u32 wa = 0, wb = 0;
+        if constexpr (!decltype(AL)::value) pickLevels(pos, wl, wa, wb);
+        u32 const d4 = nextDword(w, wn);
+        // (the fused-hash form always streams the whole chunk: its stop is the chunk's last position, no certificate end to keep)
+        u32 const stop = decltype(HS)::value ? pEnd : scanStop();
+        s32 const lo = pos + (s32)(16 * lane);
+        u32 okMask = 0;
+        if constexpr (decltype(AL)::value) {
+            // aligned chunk: the round starts at or after the chunk start and lies in one block, so the
+            // destination of the raw copy is a wave-uniform base plus 16 bytes per lane
+            // (of a large chunk only the certified blocks are copied, the ones in front belong to other workgroups)
+            if (rawCopy && (u32)pos >= base0U && (u32)lo + 16 <= chunkEndU) // (clamped loads beyond the end fail this test)
+#if SQZ_FAST_NT & 2
+                sq_gwr128_nt(rawDst((u32)pos) + 16 * lane, w);
+#else
+                sq_gwr128(rawDst((u32)pos) + 16 * lane, w);
+#endif
+        } else {
+            s32 f = (s32)SQZ_WINDOW_START - lo, l = (s32)stop - lo;
+            f = f < 0 ? 0 : (f > 16 ? 16 : f);
+            l = l < 0 ? 0 : (l > 16 ? 16 : l);
+            okMask = ((1u << l) - 1u) & ~((1u << f) - 1u);
+        }
+        u32 cm = filterBits(w, d4);
+        if constexpr (decltype(AL)::value) {
+            // the window's bitmap word; a block's searches stop 8 bytes before its end (a short last block
+            // uses a prefix of the table)
+            bool const second = (blk1 != 0xFFFFFFFFu) && pos >= (s32)blk1;
+            u32 const lim = ((!second && blk1 != 0xFFFFFFFFu) ? blk1 : chunkEndU) - tailU;
+            // An INTERIOR round -- all of its 1,024 positions inside the scanned range, the certified blocks and one
+            // block's searched range: 250 of a 256 KiB chunk's 256 -- needs no per-lane clipping: the scheduled positions
+            // are the bitmap word as loaded (its upper half, the next window's word, lies above cm's 16 bits).  The test
+            // is wave-uniform and the edge rounds are kept behind a real branch (the asm statement: hipcc would otherwise
+            // turn the clipping into twelve selects that every round executes).
+            bool const interior = active && (u32)pos + 1024 <= stop && (u32)pos + 1024 <= lim && (u32)pos >= base0U;
+            if (interior)
+                cm &= ~wl;
+            else {
+                asm volatile("; edge round");
+                okMask = active ? 0xFFFFu : 0u;
+                if ((u32)pos + 1024 > stop) {
+                    s32 l = (s32)stop - lo;
+                    l = l < 0 ? 0 : (l > 16 ? 16 : l);
+                    okMask &= (1u << l) - 1u;
+                }
+                u32 sm = (u32)pos >= base0U ? wl : 0u;
+                if ((u32)pos + 1024 > lim) {
+                    s32 nb = (s32)lim - lo;
+                    nb = nb < 0 ? 0 : (nb > 16 ? 16 : nb);
+                    sm &= (1u << nb) - 1u;
+                }
+                cm &= okMask & ~sm;
+            }
+        } else
+            cm &= okMask & ~schedMaskFast(lo, wa, wb);
+        if (nCand == 0 && active) pendFrom = pos; // nothing older than this round is waiting for its look-up
+        bool ok = collect(cm, lo, w, d4);
+        if constexpr (decltype(HS)::value) hashRound(IR, w); // (here, after the compaction loop: the filter's 54 temporaries are dead)
         if (nCand > 128) { // not with a working filter on random data: treat like a full list of hits
+            ok = false;
+            cx.nOvf = 1u | (nCand << 8);
+            nCand = 128;
+        }
+        pos += 1024;
+        return ok;
+    };
+    // A PLAIN round of the fused-hash scan: all of its 1,024 positions lie inside the wave's run, inside the chunk and
+    // inside the searched range of one block (fastStep() below vouches for four of them at a time), so nothing is
+    // clipped per lane or tested per round: filter, the bitmap word as loaded, positives, hash, raw copy.
+    auto roundPlain = [&](auto IR, sq_v4u w, sq_v4u wn, u32 wl, u64 dstp) __attribute__((always_inline)) -> bool {
+        u32 const d4 = nextDword(w, wn);
+        s32 const lo = pos + (s32)(16 * lane);
+        if (rawCopy) // (dstp: the round's place in the frame, a scalar; 16 bytes per lane behind it)
+#if SQZ_FAST_NT & 2
+            sq_gwr128_nt((u8*)(size_t)dstp + lane16, w);
+#else
+            sq_gwr128((u8*)(size_t)dstp + lane16, w);
+#endif
+        u32 const cm = filterBits(w, d4) & ~wl;
+        if (nCand == 0 && !hsDead) pendFrom = pos;
+        bool ok = collect(cm, lo, w, d4);
+        hashRound(IR, w);
+        if (nCand > 128) {
             ok = false;
             cx.nOvf = 1u | (nCand << 8);
             nCand = 128;
@@ -891,7 +958,7 @@ SQ_DEV void cert_lds_core(CertCtx& cx, FastLds* L, u8* rawOut) {
     // DPP rotations as the stripes of a row, and the lanes of row 0 store round q's 64 bytes.  The other lanes (and the
     // rounds a short last step did not run) store into the pool's dump area instead: nothing here is conditional, so no
     // store is pending on one path only (hipcc would guard the stream loads of the next rounds conservatively).
-    u64* const hpool = cx.hashPool;
+    u64* const hpool = (u64*)wv_uni64((u64)(size_t)cx.hashPool);
     auto hflush = [&](u32 r, u32 blk0) {
         static_assert(SQZ_FAST_DEPTH_HS == 4, "one lane per (round, row, pair) of a step");
         wv_fence();
@@ -902,6 +969,16 @@ SQ_DEV void cert_lds_core(CertCtx& cx, FastLds* L, u8* rawOut) {
         u32 const blk = live ? blk0 + q : 256u + ((lane >> 2) & 3);
         sq_gwr128((u8*)(hpool + 8 * blk + 2 * j), (sq_v4u){a0, a1, b0, b1});
         wv_fence();
+    };
+    // ---- the fused-hash scan's fast steps (aligned chunk, HS): is the step of four rounds at pos made of plain rounds,
+    // and are the loads it issues for the three rounds behind it inside the chunk?  One wave-uniform test per step.
+    u32 const loadEnd = (u32)(p0 + (s32)lastOff) + 16u; // one past the last 16-byte window the stream may load
+    auto fastStep = [&]() -> bool {
+        bool const second = (blk1 != 0xFFFFFFFFu) && pos >= (s32)blk1;
+        u32 const lim = ((!second && blk1 != 0xFFFFFFFFu) ? blk1 : chunkEndU) - tailU; // end of the block's searched range
+        u32 const e = lim < (u32)myStop ? lim : (u32)myStop;
+        return !hsDead && !(cx.dbg & 1024) /* timing experiment: general steps only */ && pos >= (s32)base0U && !tab0U &&
+               (u32)pos + 1024u * SQZ_FAST_DEPTH_HS <= e && (u32)pos + 1024u * (2u * SQZ_FAST_DEPTH_HS - 1u) <= loadEnd;
     };
     auto scan = [&](auto AL, auto HS) {
         scanned = true;
@@ -926,15 +1003,45 @@ SQ_DEV void cert_lds_core(CertCtx& cx, FastLds* L, u8* rawOut) {
                     hsDead = true;
                 }
                 // (a compile-time loop: the rotation w[i] / w[(i + 1) % D] must be register names, not indices)
-                (void)fw_static_for<0, D>([&](auto I) -> bool {
-                    constexpr u32 i = decltype(I)::value;
-                    if (!round(AL, HS, I, w[i], w[(i + 1) % D], lv[i])) hsDead = true;
-                    if constexpr (i + 1 < D) {
-                        w[i] = loadRound(pos + (s32)(1024 * (D - 1)));
-                        loadLevels(AL, pos + (s32)(1024 * (D - 1)), lv[i]);
-                    }
-                    return true;
-                });
+                if (fastStep()) {
+                    // four PLAIN rounds: no clipping, no per-round tests.  The loads for the rounds behind them and the raw
+                    // copy go through three RUNNING scalar pointers (stream, schedule bitmap, frame) + one constant offset per
+                    // lane: the scalar unit adds 1,024 / 128 / 1,024 per round, no vector instruction computes an address.
+                    // (Laundered through "+s": hipcc otherwise re-associates base + lane offset + position into 64-bit vector
+                    // adds of a per-lane pointer it keeps in two registers.)  Without a second schedule table in front
+                    // (tab0U: fastStep) the bitmaps of block 0 and block 1 are one array: word (rp - base0) / 16 + lane.
+                    u64 sp = (u64)(size_t)a0 + (u32)(pos - p0) + 1024u * D;
+                    u64 bp = (u64)(size_t)schedBits + 2u * ((((u32)pos - base0U) >> 4) + 64u * D);
+                    u64 dp = (u64)(size_t)rawDst((u32)pos);
+                    asm volatile("" : "+s"(sp), "+s"(bp), "+s"(dp));
+                    (void)fw_static_for<0, D>([&](auto I) -> bool {
+                        constexpr u32 i = decltype(I)::value;
+                        if (!roundPlain(I, w[i], w[(i + 1) % D], lv[i], dp)) hsDead = true;
+                        dp += 1024;
+                        if constexpr (i + 1 < D) {
+#if SQZ_FAST_NT & 1
+                            w[i] = sq_grd128_nt((const u8*)(size_t)sp + lane16);
+#else
+                            w[i] = sq_grd128((const u8*)(size_t)sp + lane16);
+#endif
+                            lv[i] = sq_grd32((const u8*)(size_t)bp + lane2);
+                            sp += 1024;
+                            bp += 128;
+                        }
+                        return true;
+                    });
+                } else {
+                    asm volatile("; general step");
+                    (void)fw_static_for<0, D>([&](auto I) -> bool {
+                        constexpr u32 i = decltype(I)::value;
+                        if (!round(AL, HS, I, w[i], w[(i + 1) % D], lv[i])) hsDead = true;
+                        if constexpr (i + 1 < D) {
+                            w[i] = loadRound(pos + (s32)(1024 * (D - 1)));
+                            loadLevels(AL, pos + (s32)(1024 * (D - 1)), lv[i]);
+                        }
+                        return true;
+                    });
+                }
                 hflush(D, ((u32)(pos - p0) >> 10) - D); // the step's block sums (pos has advanced by 1 KiB per round)
                 if (pos >= myStop) break;
             } else {
@@ -996,7 +1103,7 @@ SQ_DEV void cert_lds_core(CertCtx& cx, FastLds* L, u8* rawOut) {
             at = fin;
             if (fin < runStart(w + 1)) break;
         }
-        if (any) cx.rawEnd = (u32)at < cx.chunkEndPos ? (u32)at : SQZ_WINDOW_START + ((cx.chunkEndPos - SQZ_WINDOW_START) & ~15u);
+        if (any) cx.rawEnd = (u32)at < chunkEndU ? (u32)at : SQZ_WINDOW_START + ((chunkEndU - SQZ_WINDOW_START) & ~15u);
     }
     FPROF_ADD(L, 1, t_scan);
     FPROF_T0(t_res);
