@@ -24,6 +24,10 @@ struct sq_env {
     bool debug = false, debug_stats = false, hash_wave_per_chunk = false, no_fastpath = false;
     int stage1_wgs_per_cu = 0, stage2_waves_per_cu = 0, fast_dbg = 0;
     bool s1_after_s2 = true; // SQ_S1_AFTER_S2=0: experiment switch of the launch order in pack_enqueue
+    bool s2_early = false;   // SQ_S2_EARLY=1: fused form, stage 2 launched BEFORE the hash finish / dedup kernels, which then run beside it on
+                             // the lane's second stream (pack_enqueue).  Built and measured in round 4: the step is the same 18.0-18.1 ms
+                             // either way (profiles/round4c_s2_early_ab.txt) -- it is the sum of the kernels' work, not a gap -- so the
+                             // plain order stays the default
     int stage1_grid = -1; // SQ_STAGE1_GRID: 1 = one workgroup per chunk instead of persistent workgroups (experiment)
     int fuse_hash = -1; // SQ_FUSE_HASH: 0 never, 1 always, unset: chosen per batch from the previous batch's duplicate ratio
     bool allow_any_arch = false;
@@ -46,6 +50,7 @@ static void sq_env_read_once() {
     if (const char* e = getenv("SQ_FUSE_HASH")) g_env.fuse_hash = atoi(e) ? 1 : 0;
     if (const char* e = getenv("SQ_STAGE1_GRID")) g_env.stage1_grid = atoi(e);
     if (const char* e = getenv("SQ_S1_AFTER_S2")) g_env.s1_after_s2 = atoi(e) != 0;
+    if (const char* e = getenv("SQ_S2_EARLY")) g_env.s2_early = atoi(e) != 0;
 }
 
 #define HIPCHK(x)                                                                                  \
@@ -102,6 +107,8 @@ struct sq_lane {
     hipEvent_t ev[10] = {};
     hipEvent_t dedup_done = nullptr; // recorded after this lane's dedup kernels: the other lane's dedup waits for it
     hipEvent_t pre_s2 = nullptr;     // recorded right before this lane's stage 2 is launched (fused form, see pack_enqueue)
+    hipStream_t aux = nullptr;       // fused form of sq_pack_submit: hash finish + dedup run here, beside stage 2 (pack_enqueue)
+    hipEvent_t s1_done = nullptr;    // recorded behind this lane's stage 1 (what `aux` waits for)
     DevBuf b_off, b_len, b_slot_off, b_frame_len, b_out_off, b_isnew, b_hashes, b_stage_in,
         b_stage_out, b_slots, b_ws, b_misc, b_cert, b_etab, b_work, b_hashed, b_hpool, b_jobs, b_pair;
     // shapes of the two table pools at the last launch that completed (persistent generation tags)
@@ -235,6 +242,8 @@ int sq_ctx_create(const sq_config* cfg_in, sq_ctx** out) {
             }
         if (hipEventCreateWithFlags(&L->dedup_done, hipEventDisableTiming) != hipSuccess ||
             hipEventCreateWithFlags(&L->pre_s2, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&L->s1_done, hipEventDisableTiming) != hipSuccess ||
+            hipStreamCreateWithFlags(&L->aux, hipStreamNonBlocking) != hipSuccess ||
             hipHostMalloc(&L->h_pinned, 4096, hipHostMallocDefault) != hipSuccess) {
             sq_ctx_destroy(c);
             return SQ_E_NOMEM;
@@ -279,6 +288,7 @@ void sq_ctx_destroy(sq_ctx* c) {
     for (sq_lane& ln : c->ln) {
         sq_lane* const L = &ln;
         if (L->stream) (void)hipStreamSynchronize(L->stream);
+        if (L->aux) (void)hipStreamSynchronize(L->aux);
         for (DevBuf* b : {&L->b_off, &L->b_len, &L->b_slot_off, &L->b_frame_len, &L->b_out_off, &L->b_isnew,
                           &L->b_hashes, &L->b_stage_in, &L->b_stage_out, &L->b_slots, &L->b_ws, &L->b_misc, &L->b_cert, &L->b_etab, &L->b_work,
                           &L->b_hashed, &L->b_hpool, &L->b_jobs, &L->b_pair})
@@ -289,6 +299,8 @@ void sq_ctx_destroy(sq_ctx* c) {
             if (e) (void)hipEventDestroy(e);
         if (L->dedup_done) (void)hipEventDestroy(L->dedup_done);
         if (L->pre_s2) (void)hipEventDestroy(L->pre_s2);
+        if (L->s1_done) (void)hipEventDestroy(L->s1_done);
+        if (L->aux) (void)hipStreamDestroy(L->aux);
         if (L->own_stream && L->stream) (void)hipStreamDestroy(L->stream);
     }
     if (c->d_table) (void)hipFree(c->d_table);
@@ -356,22 +368,24 @@ static int upload_off_len(sq_ctx* c, sq_lane* L, const u64* h_off, const u32* h_
 }
 
 // d_summed / d_sums (or null): chunks whose block sums the fused form of compress stage 1 has left in its pool
+// st (or null = the lane's stream): the stream the kernel is enqueued on
 static int launch_hash(sq_ctx* c, sq_lane* L, const u8* d_data, u32 n, u8* d_hashes, const u8* d_summed = nullptr,
-                       const u8* d_sums = nullptr) {
+                       const u8* d_sums = nullptr, hipStream_t st = nullptr) {
     if (n == 0) return SQ_OK;
+    if (!st) st = L->stream;
     const u32 wpb = 4;
-    HIPCHK(hipEventRecord(L->ev[0], L->stream));
+    HIPCHK(hipEventRecord(L->ev[0], st));
     if (g_env.hash_wave_per_chunk && !d_summed) { // the first mapping: one wave per chunk
         dim3 grid((n + wpb - 1) / wpb), block(64 * wpb);
-        hipLaunchKernelGGL(sqx::k_xxh3_128_batch, grid, block, 0, L->stream, d_data, (const u64*)L->b_off.p,
+        hipLaunchKernelGGL(sqx::k_xxh3_128_batch, grid, block, 0, st, d_data, (const u64*)L->b_off.p,
                            (const u32*)L->b_len.p, n, d_hashes);
     } else { // 16 lanes per chunk, four chunks per wave
         dim3 grid((n + 4 * wpb - 1) / (4 * wpb)), block(64 * wpb);
-        hipLaunchKernelGGL(sqx::k_xxh3_128_rows, grid, block, 0, L->stream, d_data, (const u64*)L->b_off.p,
+        hipLaunchKernelGGL(sqx::k_xxh3_128_rows, grid, block, 0, st, d_data, (const u64*)L->b_off.p,
                            (const u32*)L->b_len.p, n, d_hashes, d_summed, d_sums, (u64)SQZ_FAST_HPOOL_BYTES);
     }
     HIPCHK(hipGetLastError());
-    HIPCHK(hipEventRecord(L->ev[1], L->stream));
+    HIPCHK(hipEventRecord(L->ev[1], st));
     return SQ_OK;
 }
 
@@ -390,27 +404,28 @@ int sq_hash_batch(sq_ctx* c, const uint8_t* d_data, const uint64_t* h_off, const
 }
 
 static int dedup_async(sq_ctx* c, sq_lane* L, const u8* d_all_hashes, u64 n_total, u64 my_first, u32 my_n,
-                       u8* d_is_new) {
+                       u8* d_is_new, hipStream_t st = nullptr) {
     if (c->n_seen + n_total > c->key_capacity) return SQ_E_CAP;
     if (c->n_seen + n_total >= 0xFFFFFFFFull) return SQ_E_CAP;
     if (n_total == 0) return SQ_OK;
+    if (!st) st = L->stream;
     const u64 g0 = c->n_seen;
-    HIPCHK(hipEventRecord(L->ev[2], L->stream));
+    HIPCHK(hipEventRecord(L->ev[2], st));
     HIPCHK(hipMemcpyAsync(c->d_keys + 2 * g0, d_all_hashes, n_total * 16, hipMemcpyDeviceToDevice,
-                          L->stream));
+                          st));
     {
         dim3 block(256), grid((unsigned)((n_total + 255) / 256));
-        hipLaunchKernelGGL(sqd::k_dedup_insert, grid, block, 0, L->stream, (const u64*)c->d_keys, g0,
+        hipLaunchKernelGGL(sqd::k_dedup_insert, grid, block, 0, st, (const u64*)c->d_keys, g0,
                            n_total, c->d_table, c->table_mask, c->d_unique);
         HIPCHK(hipGetLastError());
     }
     if (my_n) {
         dim3 block(256), grid((my_n + 255) / 256);
-        hipLaunchKernelGGL(sqd::k_dedup_resolve, grid, block, 0, L->stream, (const u64*)c->d_keys,
+        hipLaunchKernelGGL(sqd::k_dedup_resolve, grid, block, 0, st, (const u64*)c->d_keys,
                            g0 + my_first, my_n, (const u32*)c->d_table, c->table_mask, d_is_new);
         HIPCHK(hipGetLastError());
     }
-    HIPCHK(hipEventRecord(L->ev[3], L->stream));
+    HIPCHK(hipEventRecord(L->ev[3], st));
     c->n_seen += n_total;
     return SQ_OK;
 }
@@ -651,11 +666,16 @@ static int compress_stage1(sq_ctx* c, sq_lane* L, const u8* d_data, const u8* d_
 // Stage 2, the compressor proper, for everything stage 1 left undecided (of the selected chunks), then the small
 // result copies.  Fused form: stage 1 ran before the dedup decision, so the frames it wrote for duplicates are dropped
 // here (their lengths zeroed) and the compressor skips the duplicates on its work lists.
-static int compress_stage2(sq_ctx* c, sq_lane* L, const u8* d_data, const u8* d_select) {
+// flags_ready (fused form of sq_pack_submit, or null): the dedup flags d_select are produced on ANOTHER stream and this
+// event says when; stage 2 is then launched at once, on every chunk stage 1 left undecided, and the duplicates' frames --
+// stage 2's first (no count to correct), then stage 1's -- are dropped behind it.
+static int compress_stage2(sq_ctx* c, sq_lane* L, const u8* d_data, const u8* d_select, hipEvent_t flags_ready = nullptr) {
     u32 const n = L->job_n;
     if (n == 0) return SQ_OK;
     bool const fast = L->job_fast, in_place = L->job_in_place;
-    if (L->job_fused && d_select) {
+    bool const late_drop = flags_ready != nullptr && L->job_fused && d_select != nullptr;
+    const u8* const d_take = late_drop ? nullptr : d_select;
+    if (L->job_fused && d_select && !late_drop) {
         hipLaunchKernelGGL(sqd::k_drop_unselected, dim3((n + 255) / 256), dim3(256), 0, L->stream, (u32*)L->b_frame_len.p, d_select, n,
                            (u32*)L->b_misc.p + 33 /* stage 1's count of decided chunks */);
         HIPCHK(hipGetLastError());
@@ -664,7 +684,7 @@ static int compress_stage2(sq_ctx* c, sq_lane* L, const u8* d_data, const u8* d_
     {
         dim3 block(64), grid(L->job_waves);
         hipLaunchKernelGGL(sqz::k_compress_batch, grid, block, 0, L->stream, d_data, (const u64*)L->b_off.p,
-                           (const u32*)L->b_len.p, d_select, n, L->job_slots,
+                           (const u32*)L->b_len.p, d_take, n, L->job_slots,
                            (const u64*)L->b_slot_off.p, (u32*)L->b_frame_len.p, (u8*)L->b_ws.p,
                            (u64)L->job_ws_each, (u32*)L->b_misc.p /*queue*/, (u32*)L->b_misc.p + 16 /*err*/,
                            (const u32*)c->d_sched_tab, fast ? (const u32*)L->b_cert.p : (const u32*)nullptr, L->job_ws_persist,
@@ -673,6 +693,15 @@ static int compress_stage2(sq_ctx* c, sq_lane* L, const u8* d_data, const u8* d_
         HIPCHK(hipGetLastError());
     }
     HIPCHK(hipEventRecord(L->ev[5], L->stream));
+    if (late_drop) {
+        HIPCHK(hipStreamWaitEvent(L->stream, flags_ready, 0));
+        hipLaunchKernelGGL(sqd::k_drop_listed, dim3((n + 255) / 256, 2), dim3(256), 0, L->stream, (u32*)L->b_frame_len.p, d_select, n,
+                           (const u32*)L->b_work.p);
+        HIPCHK(hipGetLastError());
+        hipLaunchKernelGGL(sqd::k_drop_unselected, dim3((n + 255) / 256), dim3(256), 0, L->stream, (u32*)L->b_frame_len.p, d_select, n,
+                           (u32*)L->b_misc.p + 33 /* stage 1's count of decided chunks */);
+        HIPCHK(hipGetLastError());
+    }
 #ifdef SQ_PROF
     if (const char* wd = getenv("SQ_WATCHDOG_MS")) {
         // bring-up aid of the PROFILING build only (libsquish_gpu_prof.so; the release library never terminates
@@ -974,6 +1003,12 @@ static int pack_enqueue(sq_ctx* c, sq_lane* L, sq_lane* other, const u8* d_data,
     if ((r = compress_prepare(c, L, h_len, n, d_comp, comp_cap, in_place, fused))) return r;
     u64 const seen0 = (flags & 1u) ? 0 : c->n_seen;
     if (seen0 + n > c->key_capacity || seen0 + n >= 0xFFFFFFFFull) return SQ_E_CAP;
+    // Experiment (SQ_S2_EARLY=1, off by default: measured, no gain): in the fused form with batches in flight stage 2
+    // needs nothing of the dedup decision but which chunks to skip, and duplicates are few -- so it can be launched right
+    // behind stage 1, on every chunk stage 1 left undecided, while the hash finish and the dedup kernels run beside it on
+    // the lane's second stream; the duplicates' frames are then dropped behind stage 2 (compress_stage2).
+    bool const early_s2 = L->job_fused && other != nullptr && g_env.s2_early;
+    hipStream_t const side = early_s2 ? L->aux : L->stream;
     if (L->job_fused) {
         // Stage 1's persistent workgroups take every wave slot of the GPU the moment the previous batch's stage 1
         // retires -- before that batch's stage 2 has even been launched (its hashes and dedup come first), which then
@@ -981,24 +1016,28 @@ static int pack_enqueue(sq_ctx* c, sq_lane* L, sq_lane* other, const u8* d_data,
         // stage 2's waves become resident first and this kernel fill the slots as they retire.
         if (other && other->busy && other->job_fused && g_env.s1_after_s2) HIPCHK(hipStreamWaitEvent(L->stream, other->pre_s2, 0));
         if ((r = compress_stage1(c, L, d_data, nullptr, true))) return r;
-        if ((r = launch_hash(c, L, d_data, n, d_hashes, (const u8*)L->b_hashed.p, (const u8*)L->b_hpool.p))) return r;
+        if (early_s2) {
+            HIPCHK(hipEventRecord(L->s1_done, L->stream));
+            HIPCHK(hipStreamWaitEvent(side, L->s1_done, 0));
+        }
+        if ((r = launch_hash(c, L, d_data, n, d_hashes, (const u8*)L->b_hashed.p, (const u8*)L->b_hpool.p, side))) return r;
     } else if ((r = launch_hash(c, L, d_data, n, d_hashes))) // (does not depend on the batch before)
         return r;
     // the dedup set is shared: this batch's reset / insert must follow the previous batch's dedup kernels
-    if (other && other->busy) HIPCHK(hipStreamWaitEvent(L->stream, other->dedup_done, 0));
+    if (other && other->busy) HIPCHK(hipStreamWaitEvent(side, other->dedup_done, 0));
     *committed = true;
     if (flags & 1u) {
-        HIPCHK(hipMemsetAsync(c->d_table, 0, (c->table_mask + 1) * sizeof(u32), L->stream));
-        HIPCHK(hipMemsetAsync(c->d_unique, 0, 64, L->stream));
+        HIPCHK(hipMemsetAsync(c->d_table, 0, (c->table_mask + 1) * sizeof(u32), side));
+        HIPCHK(hipMemsetAsync(c->d_unique, 0, 64, side));
         c->n_seen = 0;
     }
     if (!other) // (the synchronous form: what a roll-back restores)
         HIPCHK(hipMemcpyAsync(c->d_unique + 1, c->d_unique, sizeof(unsigned long long), hipMemcpyDeviceToDevice, L->stream));
-    if ((r = dedup_async(c, L, d_hashes, n, 0, n, d_isnew))) return r;
-    HIPCHK(hipEventRecord(L->dedup_done, L->stream));
+    if ((r = dedup_async(c, L, d_hashes, n, 0, n, d_isnew, side))) return r;
+    HIPCHK(hipEventRecord(L->dedup_done, side));
     if (!L->job_fused && (r = compress_stage1(c, L, d_data, d_isnew, false))) return r;
     if (L->job_fused) HIPCHK(hipEventRecord(L->pre_s2, L->stream));
-    return compress_stage2(c, L, d_data, d_isnew);
+    return compress_stage2(c, L, d_data, d_isnew, early_s2 ? L->dedup_done : nullptr);
 }
 
 static void note_dup_ratio(sq_ctx* c, u32 n, u32 n_new) {

@@ -91,6 +91,19 @@ k_drop_unselected(u32* __restrict__ frame_len, const u8* __restrict__ select, u3
     if ((threadIdx.x & 63) == 0 && b) atomicSub(decided, (u32)__popcll(b));
 }
 
+// Fused form with stage 2 launched before the dedup decision (sq_api.hip pack_enqueue): the chunks on stage 2's two work lists
+// (work[0] / work[1] = their lengths, entries at work + 2 and work + 2 + n) were compressed whatever their flag; the frames of
+// the duplicates among them are dropped here, BEFORE k_drop_unselected looks at what is left (stage 1's frames, whose count
+// it corrects).  grid.y = the list.
+__global__ void __launch_bounds__(256)
+k_drop_listed(u32* __restrict__ frame_len, const u8* __restrict__ select, u32 n, const u32* __restrict__ work) {
+    u32 const q = blockIdx.x * blockDim.x + threadIdx.x, pass = blockIdx.y;
+    if (q < work[pass] && q < n) {
+        u32 const idx = work[2 + (pass ? n : 0u) + q];
+        if (idx < n && select[idx] == 0) frame_len[idx] = 0;
+    }
+}
+
 // Sharded form with any assignment of chunks to ranks (sq_shard_submit_rest_idx): the dedup stage has resolved the flags
 // of ALL chunks of the global order; this rank's chunk i is entry idx[i] of it.
 __global__ void __launch_bounds__(256)
