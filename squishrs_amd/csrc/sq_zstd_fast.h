@@ -951,6 +951,36 @@ SQ_DEV void cert_lds_core(CertCtx& cx, FastLds* L, u8* rawOut) {
         pos += 1024;
         return ok;
     };
+    // The same for the scan WITHOUT the fused hash (split form of a batch, sharded batches, the block pairs of large chunks).
+    // INB (std::true_type): a plain round inside the certified blocks -- bitmap word, raw copy; false: a round in FRONT of
+    // them (the earlier blocks of a large chunk, three quarters of the rounds a 2 MiB chunk's jobs scan): no scheduled
+    // position, nothing to copy, no bitmap word loaded at all.
+    auto roundPlainN = [&](auto INB, sq_v4u w, sq_v4u wn, u32 wl) __attribute__((always_inline)) -> bool {
+        u32 const d4 = nextDword(w, wn);
+        s32 const lo = pos + (s32)(16 * lane);
+        u32 cm = filterBits(w, d4);
+        if constexpr (decltype(INB)::value) {
+            if (rawCopy) {
+                u64 dstp = (u64)(size_t)rawDst((u32)pos);
+                asm volatile("" : "+s"(dstp));
+#if SQZ_FAST_NT & 2
+                sq_gwr128_nt((u8*)(size_t)dstp + lane16, w);
+#else
+                sq_gwr128((u8*)(size_t)dstp + lane16, w);
+#endif
+            }
+            cm &= ~wl;
+        }
+        if (nCand == 0) pendFrom = pos;
+        bool ok = collect(cm, lo, w, d4);
+        if (nCand > 128) {
+            ok = false;
+            cx.nOvf = 1u | (nCand << 8);
+            nCand = 128;
+        }
+        pos += 1024;
+        return ok;
+    };
     FPROF_T0(t_scan);
     bool full = false, scanned = false;
     // fused hash: the sums of the (four) rounds of one loop step, staged in LDS as [round][row][pair] x 16 B = 1 KiB
@@ -979,6 +1009,37 @@ SQ_DEV void cert_lds_core(CertCtx& cx, FastLds* L, u8* rawOut) {
         u32 const e = lim < (u32)myStop ? lim : (u32)myStop;
         return !hsDead && !(cx.dbg & 1024) /* timing experiment: general steps only */ && pos >= (s32)base0U && !tab0U &&
                (u32)pos + 1024u * SQZ_FAST_DEPTH_HS <= e && (u32)pos + 1024u * (2u * SQZ_FAST_DEPTH_HS - 1u) <= loadEnd;
+    };
+    // ... and of the scan without the hash (steps of SQZ_FAST_DEPTH rounds): 1 = plain rounds inside the certified blocks,
+    // 2 = rounds in front of them, with every round the step prefetches in front of them too (their bitmap words are not
+    // loaded), 0 = neither (a general step)
+    auto fastKindN = [&]() -> u32 {
+        if ((cx.dbg & 1024) || (u32)pos + 1024u * (2u * SQZ_FAST_DEPTH - 1u) > loadEnd) return 0u;
+        u32 const stepEnd = (u32)pos + 1024u * SQZ_FAST_DEPTH;
+        u32 const stp = scanStop();
+        if (stepEnd > (u32)myStop || stepEnd > stp) return 0u;
+        if (pos >= (s32)base0U) {
+            bool const second = (blk1 != 0xFFFFFFFFu) && pos >= (s32)blk1;
+            u32 const lim = ((!second && blk1 != 0xFFFFFFFFu) ? blk1 : chunkEndU) - tailU;
+            return stepEnd <= lim ? 1u : 0u;
+        }
+        return (u32)pos + 1024u * (2u * SQZ_FAST_DEPTH - 1u) <= base0U ? 2u : 0u;
+    };
+    auto loadStreamU = [&](s32 rp) __attribute__((always_inline)) -> sq_v4u { // (unclamped: the round lies inside the chunk)
+        u64 sp = (u64)(size_t)a0 + (u32)(rp - p0);
+        asm volatile("" : "+s"(sp));
+#if SQZ_FAST_NT & 1
+        return sq_grd128_nt((const u8*)(size_t)sp + lane16);
+#else
+        return sq_grd128((const u8*)(size_t)sp + lane16);
+#endif
+    };
+    auto loadBitsU = [&](s32 rp) __attribute__((always_inline)) -> u32 { // (as loadLevels(AL), index unclamped: inside a block)
+        bool const second = (blk1 != 0xFFFFFFFFu) && rp >= (s32)blk1;
+        u32 const tabSel = second ? SQZ_SCHEDBITS_N : (tab0U ? SQZ_SCHEDBITS_N : 0u);
+        u64 bp = (u64)(size_t)(schedBits + tabSel + (((u32)rp - (second ? blk1 : base0U)) >> 4));
+        asm volatile("" : "+s"(bp));
+        return sq_grd32((const u8*)(size_t)bp + lane2);
     };
     auto scan = [&](auto AL, auto HS) {
         scanned = true;
@@ -1050,19 +1111,47 @@ SQ_DEV void cert_lds_core(CertCtx& cx, FastLds* L, u8* rawOut) {
                     full = true;
                     break;
                 }
-                bool const done = !fw_static_for<0, D>([&](auto I) -> bool {
-                    constexpr u32 i = decltype(I)::value;
-                    if (!round(AL, HS, I, w[i], w[(i + 1) % D], lv[i])) {
-                        full = true;
-                        return false;
-                    }
-                    if (pos >= myStop) return false;
-                    if constexpr (i + 1 < D) {
-                        w[i] = loadRound(pos + (s32)(1024 * (D - 1)));
-                        loadLevels(AL, pos + (s32)(1024 * (D - 1)), lv[i]);
-                    }
-                    return true;
-                });
+                bool done;
+                u32 const kind = decltype(AL)::value ? fastKindN() : 0u;
+                if (kind == 1) { // plain rounds inside the certified blocks
+                    done = !fw_static_for<0, D>([&](auto I) -> bool {
+                        constexpr u32 i = decltype(I)::value;
+                        if (!roundPlainN(std::true_type{}, w[i], w[(i + 1) % D], lv[i])) {
+                            full = true;
+                            return false;
+                        }
+                        if constexpr (i + 1 < D) {
+                            w[i] = loadStreamU(pos + (s32)(1024 * (D - 1)));
+                            lv[i] = loadBitsU(pos + (s32)(1024 * (D - 1)));
+                        }
+                        return true;
+                    }) || pos >= myStop;
+                } else if (kind == 2) { // rounds in front of the certified blocks
+                    done = !fw_static_for<0, D>([&](auto I) -> bool {
+                        constexpr u32 i = decltype(I)::value;
+                        if (!roundPlainN(std::false_type{}, w[i], w[(i + 1) % D], 0u)) {
+                            full = true;
+                            return false;
+                        }
+                        if constexpr (i + 1 < D) w[i] = loadStreamU(pos + (s32)(1024 * (D - 1)));
+                        return true;
+                    }) || pos >= myStop;
+                } else {
+                    asm volatile("; general step");
+                    done = !fw_static_for<0, D>([&](auto I) -> bool {
+                        constexpr u32 i = decltype(I)::value;
+                        if (!round(AL, HS, I, w[i], w[(i + 1) % D], lv[i])) {
+                            full = true;
+                            return false;
+                        }
+                        if (pos >= myStop) return false;
+                        if constexpr (i + 1 < D) {
+                            w[i] = loadRound(pos + (s32)(1024 * (D - 1)));
+                            loadLevels(AL, pos + (s32)(1024 * (D - 1)), lv[i]);
+                        }
+                        return true;
+                    });
+                }
                 if (done) break;
             }
         }
