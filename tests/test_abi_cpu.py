@@ -3,6 +3,8 @@ compute calls without a GPU, and the product refuses to run without a device (no
 import ctypes
 import os
 import re
+import subprocess
+import sys
 
 import pytest
 
@@ -63,3 +65,13 @@ def test_hand_issued_lds_reads_are_not_touched_before_their_wait():
     import sys
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "check_async_reads.py")], capture_output=True, text=True)
     assert r.returncode == 0, r.stdout + r.stderr
+
+
+def test_queue_loops_keep_the_shape_that_has_never_hung():
+    """DESIGN.md section 9 (round 3's hang from an inlined per-chunk body): tools/check_queue_loops.py compiles the library
+    to ISA and asserts that k_compress_batch reaches its per-chunk body through one s_swappc_b64 to compress_one, that the
+    queue's atomic add of both persistent kernels sits in the lane-election region only with EXEC restored behind it, and
+    that the only out-of-line callees inside stage 1's inlined body are stack-less leaves that do not touch the registers
+    holding the kernel's spilled scalars."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "check_queue_loops.py")], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
