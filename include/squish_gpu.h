@@ -34,7 +34,9 @@ typedef enum sq_err {
     SQ_E_CAP = -3,      /* output capacity too small */
     SQ_E_DEVICE = -4,   /* HIP runtime error / no gfx950 device / kernel fault */
     SQ_E_COMPRESS = -5, /* == AppError::Compression (src/util/chunk.rs:90, errors.rs:25-26) */
-    SQ_E_NODEVICE = -6  /* library built without a usable GPU at run time: fails loudly, no CPU path */
+    SQ_E_NODEVICE = -6, /* library built without a usable GPU at run time: fails loudly, no CPU path */
+    SQ_E_DECOMPRESS = -7 /* sq_decompress_batch: at least one frame did not decode (per-frame status in h_status); the reference
+                            reports zstd's message through AppError::ReaderError (src/archive/reader.rs:302-303) */
 } sq_err;
 
 typedef struct sq_ctx sq_ctx;
@@ -197,6 +199,31 @@ int sq_shard_submit_rest(sq_ctx* ctx, const uint8_t* d_all_hashes, uint64_t n_to
  * a context (thread-safe); changing the environment afterwards has no effect on that process. */
 int sq_shard_submit_rest_idx(sq_ctx* ctx, const uint8_t* d_all_hashes, uint64_t n_total, const uint32_t* d_my_idx, uint8_t* d_is_new,
                              uint8_t* d_comp, uint64_t comp_cap, uint32_t flags);
+
+/* ---- the unpack side: GPU zstd frame decoder -------------------------------------------------------
+ * == n x `zstd::bulk::decompress(&compressed_data, orig_size)`, the loop of ArchiveReader::read_chunks
+ * (/root/reference/src/archive/reader.rs:259-314; zstd-sys 2.0.15 = libzstd 1.5.7).  Record i's compressed bytes
+ * frames[h_off[i] .. h_off[i] + h_len[i]) -- one or more zstd frames, skippable frames allowed, no dictionary -- are decoded
+ * into out[h_out_off[i] .. h_out_off[i] + h_out_cap[i]) (h_out_cap[i] = the record's original_size, the capacity the
+ * reference hands to zstd).  h_out_len[i] = bytes produced (0 when the record failed), h_status[i] = 0 or an SQ_DZ_* code whose
+ * text (sq_decompress_strerror) is libzstd's for the same condition.  frames / out: host or device pointers, both on the same
+ * side (SQ_E_INVAL otherwise); the h_* arrays are host memory.  One wavefront per record; a record may be up to 4 GiB - 1.
+ * Returns SQ_OK when every record decoded, SQ_E_DECOMPRESS when some did not (the others are complete and valid), or
+ * SQ_E_INVAL / SQ_E_NOMEM / SQ_E_DEVICE.  Synchronous; not to be called while batches of sq_pack_submit are in flight. */
+enum sq_dz_status {
+    SQ_DZ_OK = 0,
+    SQ_DZ_CORRUPT = 1,     /* "Data corruption detected" */
+    SQ_DZ_SRCSIZE = 2,     /* "Src size is incorrect" */
+    SQ_DZ_UNKNOWN = 3,     /* "Unknown frame descriptor" */
+    SQ_DZ_UNSUPPORTED = 4, /* "Unsupported frame parameter" */
+    SQ_DZ_DICT = 5,        /* "Dictionary mismatch" */
+    SQ_DZ_DSTSIZE = 6,     /* "Destination buffer is too small" */
+    SQ_DZ_CHECKSUM = 7     /* "Restored data doesn't match checksum" */
+};
+int sq_decompress_batch(sq_ctx* ctx, const uint8_t* frames, const uint64_t* h_off, const uint32_t* h_len, uint32_t n,
+                        uint8_t* out, const uint64_t* h_out_off, const uint32_t* h_out_cap, uint32_t* h_out_len,
+                        uint32_t* h_status);
+const char* sq_decompress_strerror(uint32_t status);
 
 /* Page-locked host buffers for the batch forms (hipHostMalloc).  The reference's packer reads every
  * chunk into a heap buffer (BufReader + chunk_buf, src/archive/writer.rs:233-246) and hands the frames on

@@ -199,6 +199,51 @@ class ChunkStore:
         check(self._L.sq_shard_submit_rest_idx(self._h, all_hashes.data_ptr(), n_total, my_idx.data_ptr(), is_new.data_ptr(),
                                                comp.data_ptr(), comp.numel(), 1 if reset else 0))
 
+    def decompress_device(self, frames, offs: np.ndarray, lens: np.ndarray, out, out_offs: np.ndarray, out_caps: np.ndarray):
+        """sq_decompress_batch on device tensors: record i = frames[offs[i] : offs[i] + lens[i]] is decoded into
+        out[out_offs[i] : out_offs[i] + out_caps[i]] (== zstd::bulk::decompress(&data, orig_size), reader.rs:302-303).
+        Returns (out_len[n], status[n]); raises only for errors other than "some record did not decode"."""
+        n = len(lens)
+        offs = np.ascontiguousarray(offs, dtype=np.uint64)
+        lens = np.ascontiguousarray(lens, dtype=np.uint32)
+        out_offs = np.ascontiguousarray(out_offs, dtype=np.uint64)
+        out_caps = np.ascontiguousarray(out_caps, dtype=np.uint32)
+        out_len = np.zeros(n, dtype=np.uint32)
+        status = np.zeros(n, dtype=np.uint32)
+        rc = self._L.sq_decompress_batch(self._h, frames.data_ptr(), offs.ctypes.data, lens.ctypes.data, n, out.data_ptr(),
+                                         out_offs.ctypes.data, out_caps.ctypes.data, out_len.ctypes.data, status.ctypes.data)
+        if rc != _lib.SQ_OK and rc != _lib.SQ_E_DECOMPRESS:
+            check(rc)
+        return out_len, status
+
+    def decompress_batch(self, frames: Sequence[bytes], caps: Sequence[int]) -> List[Optional[bytes]]:
+        """Host convenience form: decodes every record on the GPU; entry i is the decoded bytes, or None when the record
+        did not decode (self.last_decode_errors[i] then holds libzstd's message for it)."""
+        n = len(frames)
+        if n == 0:
+            return []
+        lens = np.array([len(f) for f in frames], dtype=np.uint32)
+        offs = np.zeros(n, dtype=np.uint64)
+        offs[1:] = np.cumsum((lens.astype(np.uint64) + 15) & ~np.uint64(15))[:-1]
+        total = int(offs[-1] + lens[-1])
+        buf = bytearray(total + 16)
+        for f, o in zip(frames, offs):
+            buf[int(o):int(o) + len(f)] = f
+        ocap = np.array(caps, dtype=np.uint32)
+        ooff = np.zeros(n, dtype=np.uint64)
+        ooff[1:] = np.cumsum((ocap.astype(np.uint64) + 15) & ~np.uint64(15))[:-1]
+        out = ctypes.create_string_buffer(int(ooff[-1] + ocap[-1]) + 16)
+        src = (ctypes.c_char * len(buf)).from_buffer(buf)
+        out_len = np.zeros(n, dtype=np.uint32)
+        status = np.zeros(n, dtype=np.uint32)
+        rc = self._L.sq_decompress_batch(self._h, ctypes.addressof(src), offs.ctypes.data, lens.ctypes.data, n, ctypes.addressof(out),
+                                         ooff.ctypes.data, ocap.ctypes.data, out_len.ctypes.data, status.ctypes.data)
+        if rc != _lib.SQ_OK and rc != _lib.SQ_E_DECOMPRESS:
+            check(rc)
+        self.last_decode_errors = [None if s == 0 else self._L.sq_decompress_strerror(int(s)).decode() for s in status]
+        raw = out.raw
+        return [raw[int(o):int(o) + int(l)] if s == 0 else None for o, l, s in zip(ooff, out_len, status)]
+
     def stage2_list(self, cap: int = 1 << 20) -> np.ndarray:
         """Indices of the chunks the last compress launch's first stage left to the compressor proper."""
         out = np.zeros(cap, dtype=np.uint32)

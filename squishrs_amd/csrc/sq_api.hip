@@ -4,6 +4,7 @@
 #include "../../include/squish_gpu.h"
 #include "sq_common.h"
 #include "sq_dedup.h"
+#include "sq_zstd_decode.h"
 #include "sq_xxh3.h"
 #ifndef SQ_NO_COMPRESS
 #include "sq_zstd_kernel.h"
@@ -111,6 +112,7 @@ struct sq_lane {
     hipEvent_t s1_done = nullptr;    // recorded behind this lane's stage 1 (what `aux` waits for)
     DevBuf b_off, b_len, b_slot_off, b_frame_len, b_out_off, b_isnew, b_hashes, b_stage_in,
         b_stage_out, b_slots, b_ws, b_misc, b_cert, b_etab, b_work, b_hashed, b_hpool, b_jobs, b_pair;
+    DevBuf b_dz_in, b_dz_out, b_dz_ooff, b_dz_ocap, b_dz_olen, b_dz_stat, b_dz_lit; // sq_decompress_batch
     // shapes of the two table pools at the last launch that completed (persistent generation tags)
     void* ws_ptr_last = nullptr;
     size_t ws_each_last = 0;
@@ -191,6 +193,7 @@ const char* sq_strerror(int err) {
     case SQ_E_DEVICE: return "HIP device error";
     case SQ_E_COMPRESS: return "Compression error";
     case SQ_E_NODEVICE: return "no gfx950 device available (libsquish_gpu has no CPU path)";
+    case SQ_E_DECOMPRESS: return "Decompression error";
     default: return "unknown error";
     }
 }
@@ -291,7 +294,8 @@ void sq_ctx_destroy(sq_ctx* c) {
         if (L->aux) (void)hipStreamSynchronize(L->aux);
         for (DevBuf* b : {&L->b_off, &L->b_len, &L->b_slot_off, &L->b_frame_len, &L->b_out_off, &L->b_isnew,
                           &L->b_hashes, &L->b_stage_in, &L->b_stage_out, &L->b_slots, &L->b_ws, &L->b_misc, &L->b_cert, &L->b_etab, &L->b_work,
-                          &L->b_hashed, &L->b_hpool, &L->b_jobs, &L->b_pair})
+                          &L->b_hashed, &L->b_hpool, &L->b_jobs, &L->b_pair, &L->b_dz_in, &L->b_dz_out, &L->b_dz_ooff, &L->b_dz_ocap,
+                          &L->b_dz_olen, &L->b_dz_stat, &L->b_dz_lit})
             b->release();
         if (L->h_pinned) (void)hipHostFree(L->h_pinned);
         if (L->h_len_pinned) (void)hipHostFree(L->h_len_pinned);
@@ -1371,6 +1375,72 @@ int sq_pack_wait(sq_ctx* c, uint64_t* h_comp_off, uint32_t* h_comp_len) {
     c->ln[0].last = L->last; // sq_last_timings reports the batch collected last
     return SQ_OK;
 #endif
+}
+
+// ---- unpack side: n x zstd::bulk::decompress (reader.rs:259-314) ----------------------------------------------------------
+const char* sq_decompress_strerror(uint32_t status) {
+    switch (status) {
+    case SQ_DZ_OK: return "ok";
+    case SQ_DZ_CORRUPT: return "Data corruption detected";
+    case SQ_DZ_SRCSIZE: return "Src size is incorrect";
+    case SQ_DZ_UNKNOWN: return "Unknown frame descriptor";
+    case SQ_DZ_UNSUPPORTED: return "Unsupported frame parameter";
+    case SQ_DZ_DICT: return "Dictionary mismatch";
+    case SQ_DZ_DSTSIZE: return "Destination buffer is too small";
+    case SQ_DZ_CHECKSUM: return "Restored data doesn't match checksum";
+    default: return "unknown error";
+    }
+}
+
+int sq_decompress_batch(sq_ctx* c, const uint8_t* frames, const uint64_t* h_off, const uint32_t* h_len, uint32_t n,
+                        uint8_t* out, const uint64_t* h_out_off, const uint32_t* h_out_cap, uint32_t* h_out_len,
+                        uint32_t* h_status) {
+    if (!c || (n && (!frames || !h_off || !h_len || !out || !h_out_off || !h_out_cap || !h_out_len || !h_status))) return SQ_E_INVAL;
+    if (c->submitted != c->collected || c->shard_pending) return SQ_E_INVAL;
+    if (n == 0) return SQ_OK;
+    sq_lane* const L = &c->ln[0];
+    HIPCHK(hipSetDevice(c->device));
+    bool const dev = is_device_ptr(frames);
+    if (dev != is_device_ptr(out)) return SQ_E_INVAL;
+    u64 in_end = 0, out_end = 0;
+    for (u32 i = 0; i < n; i++) {
+        in_end = std::max<u64>(in_end, h_off[i] + h_len[i]);
+        out_end = std::max<u64>(out_end, h_out_off[i] + h_out_cap[i]);
+    }
+    int r;
+    const u8* d_in = frames;
+    u8* d_out = out;
+    if (!dev) { // staged: one copy in, one copy out (the spans the records cover)
+        if ((r = L->b_dz_in.ensure((size_t)in_end + 64))) return r;
+        if ((r = L->b_dz_out.ensure((size_t)out_end + 64))) return r;
+        HIPCHK(hipMemcpyAsync(L->b_dz_in.p, frames, (size_t)in_end, hipMemcpyHostToDevice, L->stream));
+        d_in = (const u8*)L->b_dz_in.p;
+        d_out = (u8*)L->b_dz_out.p;
+    }
+    u32 const waves = std::min<u32>(n, (u32)c->num_cu * 12u);
+    if ((r = L->b_off.ensure((size_t)n * 8)) || (r = L->b_len.ensure((size_t)n * 4)) || (r = L->b_dz_ooff.ensure((size_t)n * 8)) ||
+        (r = L->b_dz_ocap.ensure((size_t)n * 4)) || (r = L->b_dz_olen.ensure((size_t)n * 4)) || (r = L->b_dz_stat.ensure((size_t)n * 4)) ||
+        (r = L->b_dz_lit.ensure((size_t)waves * SQDZ_LITBUF_BYTES)) || (r = L->b_misc.ensure(256)))
+        return r;
+    HIPCHK(hipMemcpyAsync(L->b_off.p, h_off, (size_t)n * 8, hipMemcpyHostToDevice, L->stream));
+    HIPCHK(hipMemcpyAsync(L->b_len.p, h_len, (size_t)n * 4, hipMemcpyHostToDevice, L->stream));
+    HIPCHK(hipMemcpyAsync(L->b_dz_ooff.p, h_out_off, (size_t)n * 8, hipMemcpyHostToDevice, L->stream));
+    HIPCHK(hipMemcpyAsync(L->b_dz_ocap.p, h_out_cap, (size_t)n * 4, hipMemcpyHostToDevice, L->stream));
+    HIPCHK(hipMemsetAsync(L->b_misc.p, 0, 256, L->stream));
+    HIPCHK(hipEventRecord(L->ev[6], L->stream));
+    hipLaunchKernelGGL(sqdz::k_decompress_batch, dim3(waves), dim3(64), 0, L->stream, d_in, (const u64*)L->b_off.p, (const u32*)L->b_len.p, n,
+                       d_out, (const u64*)L->b_dz_ooff.p, (const u32*)L->b_dz_ocap.p, (u32*)L->b_dz_olen.p, (u32*)L->b_dz_stat.p,
+                       (u8*)L->b_dz_lit.p, (u32*)L->b_misc.p);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipEventRecord(L->ev[7], L->stream));
+    HIPCHK(hipMemcpyAsync(h_out_len, L->b_dz_olen.p, (size_t)n * 4, hipMemcpyDeviceToHost, L->stream));
+    HIPCHK(hipMemcpyAsync(h_status, L->b_dz_stat.p, (size_t)n * 4, hipMemcpyDeviceToHost, L->stream));
+    if (!dev) HIPCHK(hipMemcpyAsync(out, L->b_dz_out.p, (size_t)out_end, hipMemcpyDeviceToHost, L->stream));
+    HIPCHK(hipStreamSynchronize(L->stream));
+    HIPCHK(hipEventElapsedTime(&L->last.compact_ms, L->ev[6], L->ev[7])); // (sq_last_timings: the decode kernel's time is reported in compact_ms)
+    for (u32 i = 0; i < n; i++)
+        if (h_status[i]) return SQ_E_DECOMPRESS;
+    return SQ_OK;
 }
 
 void* sq_host_alloc(size_t bytes) {

@@ -658,7 +658,7 @@ static void list_cmd(const std::string& squish, bool simple) {
 // decoded by zstd_frame_decoder.hpp with the record's original_size as the capacity
 // (zstd::bulk::decompress(&compressed_data, orig_size), reader.rs:302-303).
 static std::string os_error(int e) { return std::string(strerror(e)) + " (os error " + std::to_string(e) + ")"; }
-static void unpack_cmd(const std::string& squish, const std::string& outdir, long threads) {
+static void unpack_cmd(const std::string& squish, const std::string& outdir, long threads, int device) {
     Summary hdr = read_summary(squish); // ArchiveReader::new: header / version checks, table offsets
     FILE* f = fopen(squish.c_str(), "rb");
     if (!f) throw AppError{"Specified file does not exist: `" + squish + "`"};
@@ -680,27 +680,109 @@ static void unpack_cmd(const std::string& squish, const std::string& outdir, lon
         r.frame.resize((size_t)csz);
         rd(f, r.frame.data(), (size_t)csz);
     }
+    // Where the frames are decoded: on the GPU (sq_decompress_batch: one wavefront per record, batches of records whose
+    // outputs fit 4 GiB) when a gfx950 device is there, on host threads (zstd_frame_decoder.hpp, the same statement of
+    // RFC 8878) otherwise -- `unpack` and `list` must work on a machine without a GPU, as the reference's do.
+    // SQUISH_UNPACK=host|gpu pins the choice (gpu: fail when there is no device); SQUISH_TIMING=1 says which ran.
+    bool on_gpu = false;
     {
-        std::atomic<size_t> next{0};
-        auto work = [&]() {
-            for (;;) {
-                size_t const i = next.fetch_add(1);
-                if (i >= recs.size()) return;
-                try {
-                    recs[i].data = zfd::decompress(recs[i].frame.data(), recs[i].frame.size(), (size_t)recs[i].osz);
-                } catch (const zfd::DecodeError& e) {
-                    recs[i].err = e.msg;
-                }
-                std::vector<uint8_t>().swap(recs[i].frame);
+        const char* mode = getenv("SQUISH_UNPACK");
+        bool const want_host = mode && !strcmp(mode, "host"), want_gpu = mode && !strcmp(mode, "gpu");
+        sq_ctx* ctx = nullptr;
+        if (!want_host && !recs.empty()) {
+            sq_config cfg;
+            memset(&cfg, 0, sizeof(cfg));
+            cfg.abi_version = SQ_ABI_VERSION;
+            cfg.device = device;
+            cfg.dedup_capacity = 1024;
+            int const rc = sq_ctx_create(&cfg, &ctx);
+            if (rc != SQ_OK) {
+                ctx = nullptr;
+                if (want_gpu) throw AppError{std::string("sq_ctx_create: ") + sq_strerror(rc)};
             }
-        };
-        unsigned hw = std::thread::hardware_concurrency();
-        size_t nt = (size_t)std::max(1L, std::min<long>(threads, hw ? (long)hw : 1L));
-        nt = std::min(nt, std::max<size_t>(1, recs.size()));
-        std::vector<std::thread> pool;
-        for (size_t t = 1; t < nt; t++) pool.emplace_back(work);
-        work();
-        for (auto& t : pool) t.join();
+        }
+        double const t0 = now_s();
+        if (ctx) {
+            on_gpu = true;
+            uint64_t const out_budget = 4ull << 30;
+            size_t i0 = 0;
+            std::vector<uint8_t> in, out;
+            std::vector<uint64_t> off, ooff;
+            std::vector<uint32_t> len, ocap, olen, stat;
+            while (i0 < recs.size()) {
+                size_t i1 = i0;
+                uint64_t in_bytes = 0, out_bytes = 0;
+                while (i1 < recs.size() && (i1 == i0 || (out_bytes + recs[i1].osz <= out_budget && in_bytes + recs[i1].frame.size() <= out_budget))) {
+                    if (recs[i1].osz > 0xFFFFFFFFull || recs[i1].frame.size() > 0xFFFFFFFFull) break;
+                    in_bytes += (recs[i1].frame.size() + 15) & ~(uint64_t)15;
+                    out_bytes += (recs[i1].osz + 15) & ~(uint64_t)15;
+                    i1++;
+                }
+                if (i1 == i0) { // a record no batch can take (> 4 GiB): the host decoder's business
+                    try {
+                        recs[i0].data = zfd::decompress(recs[i0].frame.data(), recs[i0].frame.size(), (size_t)recs[i0].osz);
+                    } catch (const zfd::DecodeError& e) {
+                        recs[i0].err = e.msg;
+                    }
+                    i0++;
+                    continue;
+                }
+                size_t const n = i1 - i0;
+                in.resize((size_t)in_bytes + 16);
+                out.resize((size_t)out_bytes + 16);
+                off.resize(n), ooff.resize(n), len.resize(n), ocap.resize(n), olen.assign(n, 0), stat.assign(n, 0);
+                uint64_t a = 0, b = 0;
+                for (size_t k = 0; k < n; k++) {
+                    Rec& r = recs[i0 + k];
+                    off[k] = a;
+                    len[k] = (uint32_t)r.frame.size();
+                    if (!r.frame.empty()) memcpy(in.data() + a, r.frame.data(), r.frame.size());
+                    a += (r.frame.size() + 15) & ~(uint64_t)15;
+                    ooff[k] = b;
+                    ocap[k] = (uint32_t)r.osz;
+                    b += (r.osz + 15) & ~(uint64_t)15;
+                }
+                int const rc = sq_decompress_batch(ctx, in.data(), off.data(), len.data(), (uint32_t)n, out.data(), ooff.data(), ocap.data(),
+                                                   olen.data(), stat.data());
+                if (rc != SQ_OK && rc != SQ_E_DECOMPRESS) {
+                    sq_ctx_destroy(ctx);
+                    throw AppError{std::string("sq_decompress_batch: ") + sq_strerror(rc)};
+                }
+                for (size_t k = 0; k < n; k++) {
+                    Rec& r = recs[i0 + k];
+                    if (stat[k])
+                        r.err = sq_decompress_strerror(stat[k]);
+                    else
+                        r.data.assign(out.data() + ooff[k], out.data() + ooff[k] + olen[k]);
+                    std::vector<uint8_t>().swap(r.frame);
+                }
+                i0 = i1;
+            }
+            sq_ctx_destroy(ctx);
+        } else {
+            std::atomic<size_t> next{0};
+            auto work = [&]() {
+                for (;;) {
+                    size_t const i = next.fetch_add(1);
+                    if (i >= recs.size()) return;
+                    try {
+                        recs[i].data = zfd::decompress(recs[i].frame.data(), recs[i].frame.size(), (size_t)recs[i].osz);
+                    } catch (const zfd::DecodeError& e) {
+                        recs[i].err = e.msg;
+                    }
+                    std::vector<uint8_t>().swap(recs[i].frame);
+                }
+            };
+            unsigned hw = std::thread::hardware_concurrency();
+            size_t nt = (size_t)std::max(1L, std::min<long>(threads, hw ? (long)hw : 1L));
+            nt = std::min(nt, std::max<size_t>(1, recs.size()));
+            std::vector<std::thread> pool;
+            for (size_t t = 1; t < nt; t++) pool.emplace_back(work);
+            work();
+            for (auto& t : pool) t.join();
+        }
+        if (getenv("SQUISH_TIMING"))
+            fprintf(stderr, "[squishrs timing] unpack: %zu records decoded on the %s in %.3f s\n", recs.size(), on_gpu ? "GPU" : "host", now_s() - t0);
     }
     std::unordered_map<std::string, const std::vector<uint8_t>*> chunk_map;
     for (auto& r : recs) {
@@ -861,7 +943,7 @@ int main(int argc, char** argv) {
                              ? squish.substr(0, squish.size() - suf.size())
                              : squish;
             }
-            unpack_cmd(squish, output, max_threads);
+            unpack_cmd(squish, output, max_threads, device);
             printf("%s\n%s was unsquished into /%s\n", green("Unpacking complete!").c_str(), squish.c_str(), output.c_str());
         }
     } catch (const AppError& e) {
