@@ -952,6 +952,27 @@ def main():
             rest = np.nonzero(~covered)[0]
             done, bad = _decode_verify(torch, o, c3, co3, cl3, rest, lens3, hh3, T_cpu, a.verify_seconds)
             assert bad == 0, f"configs[3]: {bad} frames do not decode to their chunk"
+            # ---- the way back: every frame of the leg decoded by the GPU decoder (sq_decompress_batch, one
+            # wave per record) into a third buffer; XXH3-128 of every output must be the chunk's hash
+            unpack3 = None
+            try:
+                o3 = torch.empty(n3 * L3, dtype=torch.uint8, device="cuda")
+                store.decompress_device(c3, co3, cl3, o3, offs3, lens3)            # warm-up (buffers, code)
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                ol3, st3 = store.decompress_device(c3, co3, cl3, o3, offs3, lens3)
+                torch.cuda.synchronize()
+                msd = (time.perf_counter() - t0) * 1e3
+                assert (st3 == 0).all() and (ol3 == lens3).all(), "configs[3]: a frame did not decode on the GPU"
+                dg = torch.zeros(n3 * 16, dtype=torch.uint8, device="cuda")
+                store.hash_device(o3, offs3, lens3, dg)
+                assert torch.equal(dg, h3), "configs[3]: GPU pack -> GPU unpack does not give the chunks back"
+                unpack3 = {"ms": msd, "MiB_per_s": in3_total / 2**20 / (msd / 1e3), "kernel_ms": float(store.timings().compact_ms),
+                           "compressed_MiB_per_s": cl3_total / 2**20 / (msd / 1e3),
+                           "parity": f"all {n3} frames decoded by sq_decompress_batch; XXH3-128 of every output equals the chunk's hash (computed by the GPU before packing)"}
+                del o3, dg
+            except torch.OutOfMemoryError:
+                unpack3 = {"skipped": "not enough device memory for a third copy of the corpus"}
             others["configs[3]"] = {
                 "workload": f"{n3} chunks = {reps} copies (each rotated by a different number of bytes: no two chunks equal) of {nb} distinct 2 MiB "
                             f"Silesia-style mixed-entropy chunks (text / records / runs / skewed / random regions), {len(tails)} of them cut short as "
@@ -964,6 +985,7 @@ def main():
                 "parity": {"frames": n3, "equal_to_oracle_frame_length_and_xxh3": n_cmp, "equal_to_oracle_bytes": len(direct),
                            "decoded_and_rehashed_on_host": done, "unchecked_time_budget": int(len(rest) - done)},
                 "traffic": _mixed_traffic(),
+                "gpu_unpack": unpack3,
                 "random_access_probe": {"requests_per_s": gather,
                                         "note": "sq_calibrate_gather: 16-byte loads at random places of this corpus, 8 in flight per lane (DESIGN.md 4.3)"},
                 "cpu_baseline": cmix, "gen_seconds_host": mixed_gen_s}
