@@ -503,6 +503,11 @@ SQ_DEVFN void rb_prepare(MatchState& ms, RowBatch& bt, u32 B0, u32 n, u32 off1, 
             __builtin_trap();                                                                               \
         }                                                                                                   \
     } while (0)
+// (measurement, simulator build only: rounds, pairs, pairs with a live candidate, distinct diagonals owner - candidate per
+// round, and how many pairs a diagonal's FIRST pair would also decide (the later pairs of a run of consecutive owners on one
+// diagonal, inside the first one's match) -- the round-3 review's question whether one fetch per diagonal instead of one
+// per pair would pay, tools/diag_stats.py)
+static unsigned long long g_sim_rb_stats[5];
 SQ_DEVFN void rb_eval(MatchState& ms, RowBatch& bt, u32 i0, u32 iendPos) {
     const u8* const base = ms.base;
     u32 const B0 = bt.B0;
@@ -570,6 +575,29 @@ SQ_DEVFN void rb_eval(MatchState& ms, RowBatch& bt, u32 i0, u32 iendPos) {
         else if (l > lim) l = lim;
         len[p] = l;
         R.cand[p] = c;
+    }
+    { // measurement only (see g_sim_rb_stats)
+        g_sim_rb_stats[0]++;
+        g_sim_rb_stats[1] += P;
+        s64 dg[SQZ_RB_PAIRS];
+        u32 nd = 0, live = 0, covered = 0;
+        for (u32 p = 0; p < P; p++) {
+            if (!has[p]) continue;
+            live++;
+            s64 const d = (s64)(B0 + own[p]) - (s64)R.cand[p];
+            bool seen = false;
+            for (u32 k = 0; k < nd; k++) seen = seen || dg[k] == d;
+            if (!seen) dg[nd++] = d;
+            // is this pair inside the match of an earlier owner's pair on the same diagonal?
+            for (u32 r = 0; r < P; r++)
+                if (has[r] && own[r] < own[p] && (s64)(B0 + own[r]) - (s64)R.cand[r] == d && len[r] != 255 && own[r] + len[r] > own[p]) {
+                    covered++;
+                    break;
+                }
+        }
+        g_sim_rb_stats[2] += live;
+        g_sim_rb_stats[3] += nd;
+        g_sim_rb_stats[4] += covered;
     }
     for (u32 p = 0; p < P; p++)
         if (has[p] && ord[p] < R.stop[own[p]]) {

@@ -133,3 +133,11 @@ extern "C" unsigned sim_sched_mask_check(size_t n, unsigned* firstBad) {
 extern "C" size_t sim_fast_lds_bytes(void) { return sizeof(sqz::FastLds); }
 extern "C" size_t sim_workspace_bytes(size_t n) { return sqz::workspace_bytes((u32)n); }
 extern "C" size_t sim_lds_bytes(void) { return sizeof(sqz::LdsState); }
+
+// measurement: counters of the row-batch evaluation (sq_zstd_rowbatch.h g_sim_rb_stats); reset on read
+extern "C" void sim_rb_stats(unsigned long long* out) {
+    for (int k = 0; k < 5; k++) {
+        out[k] = sqz::g_sim_rb_stats[k];
+        sqz::g_sim_rb_stats[k] = 0;
+    }
+}

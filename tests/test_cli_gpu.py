@@ -159,6 +159,16 @@ def test_pack_unpack_roundtrip(tmp_path):
         assert (out / rel).read_bytes() == data, rel
     n = sum(len(fs) for _, _, fs in os.walk(out))
     assert n == len(files)
+    # the same archive with the records decoded on the GPU (sq_decompress_batch; the default takes the GPU only from 1 GiB on)
+    # and, pinned, on the host: identical trees, and SQUISH_TIMING says where the frames were decoded
+    for mode, word in (("gpu", "on the GPU"), ("host", "on the host")):
+        o2 = tmp_path / ("output_" + mode)
+        r = subprocess.run([CLI, "unpack", str(arch), "--output", str(o2)], capture_output=True, text=True, timeout=600,
+                           env=dict(os.environ, SQUISH_UNPACK=mode, SQUISH_TIMING="1"))
+        assert r.returncode == 0, r.stderr
+        assert word in r.stderr, r.stderr
+        for rel, data in files.items():
+            assert (o2 / rel).read_bytes() == data, (mode, rel)
     # the driver's three stages (reader / GPU / writer threads) rotate three batches: with batches of a few
     # chunks the rotation wraps many times, and the archive must not change by a byte (timestamp aside)
     small = tmp_path / "small_batches.squish"
