@@ -483,6 +483,8 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    rank_stats = []   # N > 1: one entry per rank, filled by timed()
+
     def timed(K, W):
         kern = {"hash": [], "dedup": [], "compress": [], "compact": [], "fast": []}
 
@@ -524,12 +526,29 @@ def main():
 
         run(max(W, 2) if (pipelined or (world == 1 and slots) or cyclic) else W, False)   # (both lanes of the context warm: submit alternates them)
         barrier()
+        packer.reset_stats()
         t_start = time.perf_counter()
         r = run(K, True)
         barrier()
         el = time.perf_counter() - t_start
         if world > 1:
-            tt = torch.tensor([el], dtype=torch.float64, device="cpu" if backend == "gloo" else "cuda")
+            cdev = "cpu" if backend == "gloo" else "cuda"
+            # every rank's own view of the timed region, gathered for the line: its wall time per step, the host seconds per
+            # step it spent in each phase (hash + wait, all-gather of the hashes, enqueue of dedup + compression, waiting for
+            # frames) and its mean kernel times -- so that the first run on real links shows WHICH rank and WHICH phase
+            # sets the step
+            ps = packer.stats
+            mine = torch.tensor([el / K * 1e3, ps["hash_wait"] / K * 1e3, ps["exchange"] / K * 1e3, ps["rest"] / K * 1e3, ps["wait"] / K * 1e3,
+                                 float(np.mean(kern["hash"])), float(np.mean(kern["fast"])), float(np.mean(kern["compress"]))],
+                                dtype=torch.float64, device=cdev)
+            allr = torch.zeros(world * mine.numel(), dtype=torch.float64, device=cdev)
+            dist.all_gather_into_tensor(allr, mine)
+            rank_stats.clear()
+            for rr in allr.view(world, -1).cpu().tolist():
+                rank_stats.append({"ms_per_step": rr[0], "host_ms_per_step": {"hash_and_wait": rr[1], "all_gather_of_hashes": rr[2],
+                                                                            "enqueue_dedup_compress": rr[3], "wait_for_frames": rr[4]},
+                                   "kernels_ms": {"hash": rr[5], "stage1": rr[6], "stage2": rr[7]}})
+            tt = torch.tensor([el], dtype=torch.float64, device=cdev)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             el = float(tt.item())
         return r, el / K * 1e3, {k: float(np.mean(v)) for k, v in kern.items()}
@@ -1005,6 +1024,11 @@ def main():
                           "compressed_bytes_rank0": clen_total, "parallelism": f"shard{world}",
                           "output_layout": a.layout, "parity": parity, "gen_seconds": gen_s},
                "roofline": roof, "cpu_baseline": cpu, "end_to_end": e2e, "other_configs": others}
+        if world > 1:
+            out["per_rank"] = {"note": "each rank's own clock over the timed region (the line's ms_per_step is their maximum); host times are "
+                                       "what the rank's Python thread spent per step in each phase of ShardedPacker.submit / wait; chunks to "
+                                       "compress per rank are in config.workload",
+                               "ranks": list(rank_stats), "first_occurrences_per_rank": new_per_rank}
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

@@ -54,6 +54,14 @@ class ShardedPacker:
             stages.set_stream(torch.cuda.current_stream().cuda_stream)
         self._comm = None       # stream of the exchanges of the pipelined form (submit / wait)
         self._inflight = []     # per batch in flight: what must stay alive until it is collected
+        # host-side seconds this rank spent per phase of submit() / wait() since reset_stats(): hash_wait = launching the
+        # hash and waiting for it, exchange = the all-gather of the hashes (+ the permutation into global order), rest =
+        # enqueueing the global dedup + compression, wait = blocking in wait() for a batch's frames; `batches` counts them
+        self.stats = {"hash_wait": 0.0, "exchange": 0.0, "rest": 0.0, "wait": 0.0, "batches": 0}
+
+    def reset_stats(self):
+        for k in self.stats:
+            self.stats[k] = 0 if k == "batches" else 0.0
 
     def gather_hashes(self, hashes: torch.Tensor, n_local: int, uniform: bool = False):
         """All-gather of the ranks' hash arrays (16 B x n_local, padded to the max count).
@@ -124,10 +132,13 @@ class ShardedPacker:
         batches in flight, each with its own hashes / is_new / comp buffers.  The collective runs on a stream of its
         own: torch's current stream may be one of the context's lanes (see __init__) and would put the exchange
         behind the other batch's kernels."""
+        import time
         n = len(lens)
         st = self.stages
+        t0 = time.perf_counter()
         st.shard_submit_hash(data, offs, lens, hashes)
         st.shard_wait_hash()
+        t1 = time.perf_counter()
 
         def exchange():
             g, n_total, my_first = self.gather_hashes(hashes, n, uniform)
@@ -147,13 +158,23 @@ class ShardedPacker:
             all_hashes, n_total, my_first = exchange()
             if hashes.is_cuda:
                 torch.cuda.current_stream().synchronize()   # (the permutation ran on torch's stream, the rest runs on the lane's)
+        t2 = time.perf_counter()
         if perm is not None:   # ... and this rank names its chunks by their global index (my_idx)
             st.shard_submit_rest_idx(all_hashes, n_total, my_idx, is_new, comp, reset)
         else:
             st.shard_submit_rest(all_hashes, n_total, my_first, is_new, comp, reset)
+        t3 = time.perf_counter()
+        self.stats["hash_wait"] += t1 - t0
+        self.stats["exchange"] += t2 - t1
+        self.stats["rest"] += t3 - t2
+        self.stats["batches"] += 1
         self._inflight.append((all_hashes, n, my_idx))
 
     def wait(self):
         """(slot offsets[n], frame lengths[n]) of the oldest batch in flight."""
+        import time
         self.last_all_hashes, n, _idx = self._inflight.pop(0)   # (the batch's hashes in global order: the caller's manifest)
-        return self.stages.pack_wait(n)
+        t0 = time.perf_counter()
+        r = self.stages.pack_wait(n)
+        self.stats["wait"] += time.perf_counter() - t0
+        return r

@@ -270,3 +270,7 @@ def test_bench_config4_three_ranks_on_one_gpu_rehearsal():
         assert line["n_gpus"] == 3 and line["config"]["unique_chunks"] == unique and line["scaling"] == "weak"
         assert line["config"]["parity"]["frames_compared_with_oracle"] > 0 if "frames_compared_with_oracle" in line["config"]["parity"] else line["config"]["parity"]["frames_compared_with_oracle_bytes"] > 0
         assert ("block-cyclic" in line["config"]["workload"]) == (not extra)
+        # every rank's own clock, host phase times and kernel times travel in the line (the first run on real links must be diagnosable)
+        pr = line["per_rank"]["ranks"]
+        assert len(pr) == 3 and all(r["ms_per_step"] > 0 and r["kernels_ms"]["stage1"] > 0 and r["host_ms_per_step"]["all_gather_of_hashes"] >= 0 for r in pr)
+        assert max(r["ms_per_step"] for r in pr) <= line["ms_per_step"] * 1.0001
