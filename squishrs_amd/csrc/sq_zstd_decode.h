@@ -39,7 +39,7 @@ enum : u32 {
 #define SQDZ_LITBUF_BYTES (SQDZ_BLOCK_MAX + 64u) // per wave, global memory
 #define SQDZ_TILE 64u
 
-// LDS of one decoding wave (11.6 KB: 13 waves per CU)
+// LDS of one decoding wave (12.1 KB: 13 waves per CU)
 struct DecLds {
     u16 huf[2048];      // Huffman decode table: symbol | nbBits << 8
     u32 fse[3][512];    // LL / OF / ML decode tables: new-state base (16) | nbBits (8) << 16 | symbol (8) << 24
@@ -51,7 +51,14 @@ struct DecLds {
     u8 weights[256];
     s16 norm[64];
     u16 next[64];
+    // the sequence codes' base values and extra-bit counts (RFC 8878 3.1.1.3.2.1.1), copied from constant memory once per
+    // kernel: indexed by lane 0 once per SEQUENCE -- from constant memory each look-up was a trip to L2 (measured: 15 ms per
+    // 128 KiB block of text, four fifths of the decoder's time)
+    u32 llBase[36], mlBase[53];
+    u8 llBits[36], mlBits[53];
 };
+// fills the code tables of a wave's LDS (all lanes; call once before the first frame)
+SQ_DEV void dec_lds_init(DecLds* L);
 
 // ---- sequence code tables (RFC 8878 3.1.1.3.2.1)
 #if SQ_ON_DEVICE
@@ -71,6 +78,30 @@ SQDZ_CONST s16 kLLDefault[36] = {4, 3, 2, 2, 2, 2, 2, 2, 2, 2, 2, 2, 2, 1, 1, 1,
 SQDZ_CONST s16 kMLDefault[53] = {1, 4, 3, 2, 2, 2, 2, 2, 2, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1,
                                                 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, -1, -1, -1, -1, -1, -1, -1};
 SQDZ_CONST s16 kOFDefault[29] = {1, 1, 1, 1, 1, 1, 2, 2, 2, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, -1, -1, -1, -1, -1};
+
+SQ_DEV void dec_lds_init(DecLds* L) {
+#if SQ_ON_DEVICE
+    u32 const lane = wv_lane();
+    if (lane < 36) {
+        L->llBase[lane] = kLLBase[lane];
+        L->llBits[lane] = kLLBits[lane];
+    }
+    if (lane < 53) {
+        L->mlBase[lane] = kMLBase[lane];
+        L->mlBits[lane] = kMLBits[lane];
+    }
+    wv_fence();
+#else
+    for (u32 i = 0; i < 36; i++) {
+        L->llBase[i] = kLLBase[i];
+        L->llBits[i] = kLLBits[i];
+    }
+    for (u32 i = 0; i < 53; i++) {
+        L->mlBase[i] = kMLBase[i];
+        L->mlBits[i] = kMLBits[i];
+    }
+#endif
+}
 
 // ---- forward (little-endian) bit reader over [p, p + n): table descriptions
 struct FwdBits {
@@ -703,8 +734,8 @@ SQ_DEV u32 decode_block(DecLds* L, const u8* p, u32 n, u8* dst, u32 cap, u32 fra
                 } else
                     ofExtra = rev_read(b, ofCode);
                 u64 const ofVal = (1ull << ofCode) + ofExtra;
-                u32 const ml = kMLBase[mlCode] + rev_read(b, kMLBits[mlCode]);
-                u32 const ll = kLLBase[llCode] + rev_read(b, kLLBits[llCode]);
+                u32 const ml = ((const SQ_L u32*)L->mlBase)[mlCode] + rev_read(b, ((const SQ_L u8*)L->mlBits)[mlCode]);
+                u32 const ll = ((const SQ_L u32*)L->llBase)[llCode] + rev_read(b, ((const SQ_L u8*)L->llBits)[llCode]);
                 if (b.pos < 0) {
                     st = DZ_CORRUPT;
                     break;
@@ -1006,6 +1037,7 @@ __global__ void __launch_bounds__(64, 3)
 k_decompress_batch(const u8* src, const u64* src_off, const u32* src_len, u32 n, u8* dst, const u64* dst_off, const u32* dst_cap,
                    u32* out_len, u32* status, u8* litbuf, u32* queue) {
     __shared__ DecLds lds;
+    dec_lds_init(&lds);
     u8* const lb = litbuf + (u64)blockIdx.x * SQDZ_LITBUF_BYTES;
     for (;;) {
         u32 q = 0;

@@ -535,7 +535,14 @@ SQ_DEVFN u32 compress_frame_wave(const u8* src, u32 n, u8* dst, u32 cap, u8* ws,
         u32 const lastBlock = (blockSize == remaining);
         if ((u32)(oend - op) < 3 + 2 + 1) return 0;
         if (ms.nextToUpdate < SQZ_WINDOW_START) ms.nextToUpdate = SQZ_WINDOW_START;
-        u32 cSize = compressBlock_internal(ms, ss, bs, ws + L.optState, op + 3, (u32)(oend - op) - 3, ip, blockSize);
+        // Room for this block's attempt.  While stage 1's raw payload of LATER blocks sits in the slot (rawHave reaches beyond
+        // this block), an attempt must not write over it: the room ends where the next block's header goes.  That changes no
+        // result -- an attempt that would need more than blockSize bytes is emitted raw whatever it costs (compressLiterals /
+        // entropy_compress_seqstore fall back to "raw" when the room runs out, as libzstd's cSize >= maxCSize test does) -- but it
+        // makes the in-place shortcut below safe by construction instead of by the arithmetic of sequence costs.
+        u32 room = (u32)(oend - op) - 3;
+        if (rawHave > (u32)(ip - src) + blockSize && room > blockSize) room = blockSize;
+        u32 cSize = compressBlock_internal(ms, ss, bs, ws + L.optState, op + 3, room, ip, blockSize);
         if (is_err(cSize) || ms.fault) return 0;
         if (cSize == 0) { // ZSTD_noCompressBlock
             u32 const h = lastBlock + (0u << 1) + (blockSize << 3);

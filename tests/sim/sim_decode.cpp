@@ -9,6 +9,7 @@
 extern "C" unsigned sim_decompress(const uint8_t* src, size_t n, uint8_t* dst, size_t cap, size_t* out_len, int poison) {
     static thread_local sqdz::DecLds lds;
     memset(&lds, poison ? 0x5A : 0, sizeof(lds));
+    sqdz::dec_lds_init(&lds);
     u8* lit = (u8*)malloc(SQDZ_LITBUF_BYTES);
     memset(lit, poison ? 0xA5 : 0, SQDZ_LITBUF_BYTES);
     u32 len = 0;

@@ -197,3 +197,42 @@ def test_form_is_chosen_from_the_previous_batch(oracle):
                 assert fr[i] == (oracle.compress_chunk(c) if exp_new[i] else b"")
     finally:
         st.close()
+
+
+def _far_repeats(seed, n, first, count, spacing, block1_random=True):
+    """Random bytes with `count` planted 4-byte repeats of far-away earlier positions, `spacing` bytes apart from position `first`
+    on: a block that has hundreds of short matches and is STILL emitted raw (each saves less than it costs), i.e. a block
+    whose compression attempt writes a long sequences section before it is thrown away."""
+    rng = np.random.default_rng(seed)
+    a = rng.integers(0, 256, size=n, dtype=np.uint8)
+    for k in range(count):
+        p, q = first + spacing * k, 500 + 13 * k
+        if p + 4 <= n and q + 4 < p:
+            a[p:p + 4] = a[q:q + 4]
+    return a.tobytes()
+
+
+def test_rejected_attempt_of_one_block_leaves_the_next_blocks_raw_payload_alone(oracle):
+    """ADVICE r3 (sq_zstd_kernel.h, the in-place raw-block shortcut): stage 1's scan writes the raw payload of EVERY block of a
+    chunk into the slot; when stage 2 then attempts block 0 -- here with 600 / 2,000 / 6,000 short far repeats: raw literals plus
+    a long sequences section, rejected as raw in the end -- that attempt must not run over block 1's payload, which is emitted
+    without another copy.  Fused and split form, 2 and 1.5 blocks; every frame against the oracle."""
+    import torch
+    import squishrs_amd
+    chunks = []
+    for seed, (cnt, sp) in enumerate(((600, 100), (2000, 40), (6000, 16), (1500, 60))):
+        chunks.append(_far_repeats(40 + seed, 262144, 30000, cnt, sp))
+        chunks.append(_far_repeats(50 + seed, 131072 + 65536, 20000, cnt, sp))
+    chunks.append(corpus.random_bytes(77, 1, 262144))
+    buf, offs, lens = _layout(chunks, [0] * len(chunks))
+    data = torch.from_numpy(buf).cuda()
+    want = [oracle.compress_chunk(c) for c in chunks]
+    for fuse in (True, False):
+        st = squishrs_amd.ChunkStore(device=0, max_chunk=262144, dedup_capacity=1024, fuse_hash=fuse)
+        try:
+            _h, new, frames, _u = _pack(st, data, offs, lens, True)
+            assert new.tolist() == [1] * len(chunks)
+            for i, (f, w) in enumerate(zip(frames, want)):
+                assert f == w, (fuse, i, len(f), len(w))
+        finally:
+            st.close()
