@@ -793,7 +793,7 @@ static int compress_finish(sq_ctx* c, sq_lane* L, u8* d_comp, u64 comp_cap, u64*
             L->etab_waves_last = fwaves;
         }
     }
-#ifdef SQ_PROF
+#ifdef SQ_PROF_S1 // (stage 1's timers are a switch of their own: with them the fast steps' scalar pointers do not compile)
     if (fast) { // stage 1 phase timers (one 256-byte slice per wave: its saved state, then 8 tick sums)
         std::vector<unsigned long long> tot(8, 0), one(8);
         for (u32 w = 0; w < fwaves; w++) {
@@ -805,6 +805,8 @@ static int compress_finish(sq_ctx* c, sq_lane* L, u8* d_comp, u64 comp_cap, u64*
         for (int k = 0; k < 6; k++) fprintf(stderr, " %s=%.3f", nm1[k], (double)tot[k] / fwaves / 1e5);
         fprintf(stderr, "\n");
     }
+#endif
+#ifdef SQ_PROF
     {   // profiling build: sum the per-wave phase timers (100 MHz ticks) and print them
         std::vector<unsigned long long> tot(33, 0), one(71), worst(71, 0), worst1(71, 0);
         std::vector<std::pair<unsigned long long, unsigned long long>> longest; // (ticks, pass<<32 | chunk) per wave

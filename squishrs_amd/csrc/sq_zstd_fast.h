@@ -83,6 +83,8 @@ SQ_DEV bool fw_static_for(F&& f) {
 #define FW_SH_CERT0 1u  // certEnd  (atomic minimum over the waves)
 #define FW_SH_CERT1 2u  // certEnd1
 #define FW_SH_FLAGS 3u  // 1: the repeats inside S do not fit the hit list, 2: a bucket too large for this path
+#define FW_SH_WAKE 4u   // second pass: 4 = the search position the bucket check belongs to (0: none), 6 = the match's position,
+                        // (| the table's hash bits << 24), 7 = that search's bucket hash | its first byte << 24 (FW_SH_FLAGS bit 8: the check failed)
 #define FW_SH_IDX 5u    // the chunk index the workgroup pulled from the queue
 #define FW_SH_FIN 8u    // [FW_NW] position each wave's scan ended at
 #define FW_SH_SAMPLE 12u // [4] largest count of each 4 KiB sample of the HUF pre-check
@@ -133,9 +135,10 @@ struct FastLds {
     u32 hits[2 * SQZ_FAST_HITS];     // (position, bytes) of scanned positions whose bytes equal a scheduled position's;
                                      // position 0 = two scheduled positions with equal bytes
     u32 sh[16];                      // words shared by the waves (FW_SH_*)
+    u32 keep[8];                     // fastpath_blocks: the first pass's answers while the second pass runs (registers are short there)
     u32 hsec[256];                   // fused hash: lane l's two secret words (dword k at 64 k + l), the same for every chunk
     u32 hstage[FW_NW * SQZ_FAST_DEPTH_HS * 64]; // fused hash: per wave, the (round, row, pair) sums of a loop step, dword k at 64 k + 16 round + 4 row + pair
-#ifdef SQ_PROF
+#ifdef SQ_PROF_S1
     unsigned long long prof[8]; // 100 MHz ticks: 0 build, 1 scan loop, 2 look-ups (inside 1), 3 hit resolution, 4 pre-check + frame, 5 whole chunk
 #endif
 };
@@ -181,7 +184,7 @@ SQ_DEV u32 fast_frame_header_all(u8* dst, u32 n) {
     return 5 + (n < 256 ? 1u : (n < 65536 + 256 ? 2u : 4u));
 }
 
-#if defined(SQ_PROF) && SQ_ON_DEVICE
+#if defined(SQ_PROF_S1) && SQ_ON_DEVICE
 #define FPROF_T0(v) unsigned long long v = __builtin_amdgcn_s_memrealtime()
 #define FPROF_ADD(L, slot, v)                                              \
     do {                                                                   \
@@ -297,17 +300,20 @@ SQ_DEV void cert_pos8(const CertCtx& cx, u32 i, u32 nCert, u32 (&sp)[8]) {
     u32 t[8], ad[8];
 #pragma unroll
     for (u32 g = 0; g < 8; g++) {
-        u32 const j = (i + 64 * g < nCert) ? i + 64 * g : nCert - 1;
+        u32 const j0 = (i + 64 * g < nCert) ? i + 64 * g : nCert - 1;
+        bool const x = (cx.tab0 & 2u) && j0 + 2 >= nCert; // (second pass: the two searches that are not on the schedule; as cert_pos_g)
+        u32 const j = x ? 0u : j0;
         bool const first = j < cx.certCnt0;
         u32 const slot = first ? (cx.tab0 ? SQZ_SCHEDTAB_N : 0u) + j : SQZ_SCHEDTAB_N + cx.tabOff1 + (j - cx.certCnt0);
         t[g] = sq_gld32(cx.schedTab + 2 + slot);
         ad[g] = first ? cx.base0Pos : cx.base1Pos;
+        if (x) ad[g] = 0x80000000u | (3u - (nCert - j0));
     }
     // all eight words pass through one empty asm: nothing that uses one of them can be scheduled before
     // the last load has been issued
     asm volatile("" : "+v"(t[0]), "+v"(t[1]), "+v"(t[2]), "+v"(t[3]), "+v"(t[4]), "+v"(t[5]), "+v"(t[6]), "+v"(t[7]));
 #pragma unroll
-    for (u32 g = 0; g < 8; g++) sp[g] = t[g] + ad[g];
+    for (u32 g = 0; g < 8; g++) sp[g] = (ad[g] & 0x80000000u) ? cx.wakeLim + (ad[g] & 3u) : t[g] + ad[g];
 }
 
 // the three 2-byte windows of a scheduled value as keys of the scan's filter (see the scan).  A key's cell is the
@@ -336,6 +342,7 @@ SQ_DEV void vbloom_add3(SQ_L u32* const B, u32 v) {
 SQ_DEV void cert_lds_core(CertCtx& cx, FastLds* L, u8* rawOut) {
     cx.rawEnd = SQZ_WINDOW_START;
     cx.hashDone = 0;
+    cx.wakeBad = 0;
     const u8* const base = cx.base;
     u32 const nCert = cx.nCert;
     u32 const blk1 = wv_uni((nCert > cx.certCnt0) ? cx.base1Pos : 0xFFFFFFFFu);
@@ -365,6 +372,9 @@ SQ_DEV void cert_lds_core(CertCtx& cx, FastLds* L, u8* rawOut) {
         sh[FW_SH_CERT0] = certEnd;
         sh[FW_SH_CERT1] = certEnd1;
         sh[FW_SH_FLAGS] = 0;
+        sh[FW_SH_WAKE] = cx.wakeLim;
+        sh[FW_SH_WAKE + 2] = cx.wakeSkip | (cx.wakeHashLog << 24);
+        sh[FW_SH_WAKE + 3] = cx.wakeHash | (cx.wakeByte << 24);
     }
     fw_sync();
     u32 vmin = 0xFFFFFFFFu, vmin1 = 0xFFFFFFFFu; // lane-local minima of the violating scheduled positions
@@ -609,7 +619,7 @@ SQ_DEV void cert_lds_core(CertCtx& cx, FastLds* L, u8* rawOut) {
     bool const rawCopy = rawOut != nullptr && src0 == a0;
     // the fused hash needs the whole chunk streamed (a scan that would stop at an early certificate end goes on:
     // what it finds beyond that end changes nothing) and rounds that are XXH3 blocks (aligned chunk)
-    bool const hashOn = cx.hashPool != nullptr && src0 == a0 && !(cx.dbg & 2);
+    bool const hashOn = cx.hashPool != nullptr && src0 == a0 && !(cx.dbg & 2) && !(tab0U & 2u); // (not in the second pass)
     auto scanStop = [&]() -> u32 {
         u32 const ce = (blk1 != 0xFFFFFFFFu) ? certEnd1 : certEnd;
         return (ce < pEnd && !hashOn) ? ce : pEnd;
@@ -639,7 +649,16 @@ SQ_DEV void cert_lds_core(CertCtx& cx, FastLds* L, u8* rawOut) {
     // of the schedule's bitmap (SQZ_SCHEDBITS_OFF): `wl` is then that window's mask itself, loaded with the
     // stream, and none of the level arithmetic below runs.
     const u16* const schedBits = (const u16*)wv_uni64((u64)(size_t)(cx.schedTab + SQZ_SCHEDBITS_OFF));
-    auto loadLevels = [&](auto AL, s32 rp, u32& wl) {
+    auto loadLevels = [&](auto AL, auto HS, s32 rp, u32& wl) {
+        if constexpr (decltype(AL)::value && !decltype(HS)::value) {
+            if (tab0U & 2u) { // second pass: the "later" bitmap laid at base0U, any byte offset -- the two words around the
+                              // lane's first position (round() shifts them into place); lanes in front of base0U: word 0
+                s32 const r = rp + (s32)(16 * lane) - (s32)base0U;
+                u32 const wi = r > 0 ? (u32)r >> 4 : 0u;
+                wl = sq_grd32((const u8*)(schedBits + SQZ_SCHEDBITS_N + (wi < SQZ_SCHEDBITS_N ? wi : SQZ_SCHEDBITS_N - 1)));
+                return;
+            }
+        }
         if constexpr (decltype(AL)::value) {
             // (rounds in front of the first certified block -- the earlier blocks of a large chunk, base0Pos > the
             // chunk's start -- hold no scheduled position of THIS certificate: their word is loaded like any other, from
@@ -884,6 +903,41 @@ SQ_DEV void cert_lds_core(CertCtx& cx, FastLds* L, u8* rawOut) {
             l = l < 0 ? 0 : (l > 16 ? 16 : l);
             okMask = ((1u << l) - 1u) & ~((1u << f) - 1u);
         }
+        if constexpr (decltype(AL)::value && !decltype(HS)::value) {
+            if (tab0U & 2u) { // second pass (in front of the filter, whose 54 temporaries leave no room for anything else)
+                // the bucket check (FW_SH_WAKE): positions in front of the search that share its first byte are hashed
+                u32 const wLim = sh[FW_SH_WAKE];
+                if (wLim && (u32)pos < wLim) {
+                    u32 const wSkip = sh[FW_SH_WAKE + 2] & 0xFFFFFFu, wLog = sh[FW_SH_WAKE + 2] >> 24, wHB = sh[FW_SH_WAKE + 3];
+                    u32 const b4 = (wHB >> 24) * 0x01010101u;
+                    u32 const dd[4] = {w.x, w.y, w.z, w.w};
+                    u32 zm = 0;
+#pragma unroll
+                    for (u32 q = 0; q < 4; q++) { // (zero-byte test; a byte above a zero byte may be flagged too: rechecked below)
+                        u32 const x = dd[q] ^ b4;
+                        u32 const z = (x - 0x01010101u) & ~x & 0x80808080u;
+                        zm |= (((z >> 7) & 1u) | ((z >> 14) & 2u) | ((z >> 21) & 4u) | ((z >> 28) & 8u)) << (4 * q);
+                    }
+                    {
+                        s32 l = (s32)stop - lo; // (the positions the scan covers)
+                        l = l < 0 ? 0 : (l > 16 ? 16 : l);
+                        zm &= (1u << l) - 1u;
+                    }
+                    bool bad = false;
+                    while (wv_ballot(zm != 0)) {
+                        if (zm) {
+                            u32 const j = (u32)__builtin_ctz(zm);
+                            zm &= zm - 1;
+                            u32 const p = (u32)(lo + (s32)j), v = valAt(w, d4, j);
+                            if (p >= SQZ_WINDOW_START && p < wLim && p != wSkip && (v & 0xFFu) == (wHB >> 24) &&
+                                hash4(v, wLog) == (wHB & 0xFFFFFFu))
+                                bad = true;
+                        }
+                    }
+                    if (wv_ballot(bad) && lane == 0) __hip_atomic_fetch_or(&sh[FW_SH_FLAGS], 8u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
+            }
+        }
         u32 cm = filterBits(w, d4);
         if constexpr (decltype(AL)::value) {
             // the window's bitmap word; a block's searches stop 8 bytes before its end (a short last block
@@ -895,7 +949,8 @@ SQ_DEV void cert_lds_core(CertCtx& cx, FastLds* L, u8* rawOut) {
             // are the bitmap word as loaded (its upper half, the next window's word, lies above cm's 16 bits).  The test
             // is wave-uniform and the edge rounds are kept behind a real branch (the asm statement: hipcc would otherwise
             // turn the clipping into twelve selects that every round executes).
-            bool const interior = active && (u32)pos + 1024 <= stop && (u32)pos + 1024 <= lim && (u32)pos >= base0U;
+            bool const tailPass = !decltype(HS)::value && (tab0U & 2u) != 0; // (second pass: every round is an edge round)
+            bool const interior = active && !tailPass && (u32)pos + 1024 <= stop && (u32)pos + 1024 <= lim && (u32)pos >= base0U;
             if (interior)
                 cm &= ~wl;
             else {
@@ -907,6 +962,15 @@ SQ_DEV void cert_lds_core(CertCtx& cx, FastLds* L, u8* rawOut) {
                     okMask &= (1u << l) - 1u;
                 }
                 u32 sm = (u32)pos >= base0U ? wl : 0u;
+                if constexpr (!decltype(HS)::value) {
+                    if (tailPass) {
+                        // the schedule's bitmap starts at base0U, which is no multiple of 16 away from the lane's window:
+                        // bit k of the window = bit k + r of the bitmap, r = lo - base0U (word r >> 4 and the one behind it
+                        // are in wl; in front of base0U nothing is scheduled)
+                        s32 const r = lo - (s32)base0U;
+                        sm = r >= 0 ? (wl >> (r & 15)) & 0xFFFFu : (r > -16 ? (wl << (u32)(-r)) & 0xFFFFu : 0u);
+                    }
+                }
                 if ((u32)pos + 1024 > lim) {
                     s32 nb = (s32)lim - lo;
                     nb = nb < 0 ? 0 : (nb > 16 ? 16 : nb);
@@ -1014,7 +1078,7 @@ SQ_DEV void cert_lds_core(CertCtx& cx, FastLds* L, u8* rawOut) {
     // 2 = rounds in front of them, with every round the step prefetches in front of them too (their bitmap words are not
     // loaded), 0 = neither (a general step)
     auto fastKindN = [&]() -> u32 {
-        if ((cx.dbg & 1024) || (u32)pos + 1024u * (2u * SQZ_FAST_DEPTH - 1u) > loadEnd) return 0u;
+        if ((cx.dbg & 1024) || (tab0U & 2u) || (u32)pos + 1024u * (2u * SQZ_FAST_DEPTH - 1u) > loadEnd) return 0u;
         u32 const stepEnd = (u32)pos + 1024u * SQZ_FAST_DEPTH;
         u32 const stp = scanStop();
         if (stepEnd > (u32)myStop || stepEnd > stp) return 0u;
@@ -1051,11 +1115,11 @@ SQ_DEV void cert_lds_core(CertCtx& cx, FastLds* L, u8* rawOut) {
 #pragma unroll
         for (u32 i = 0; i + 1 < D; i++) {
             w[i] = loadRound(pos + (s32)(1024 * i));
-            loadLevels(AL, pos + (s32)(1024 * i), lv[i]);
+            loadLevels(AL, HS, pos + (s32)(1024 * i), lv[i]);
         }
         for (;;) {
             w[D - 1] = loadRound(pos + (s32)(1024 * (D - 1)));
-            loadLevels(AL, pos + (s32)(1024 * (D - 1)), lv[D - 1]);
+            loadLevels(AL, HS, pos + (s32)(1024 * (D - 1)), lv[D - 1]);
             // ONE look-up site for the D rounds below (inlined into each of them, the look-up code made
             // the loop several times the size of the instruction cache's share of a wave)
             if constexpr (decltype(HS)::value) {
@@ -1098,7 +1162,7 @@ SQ_DEV void cert_lds_core(CertCtx& cx, FastLds* L, u8* rawOut) {
                         if (!round(AL, HS, I, w[i], w[(i + 1) % D], lv[i])) hsDead = true;
                         if constexpr (i + 1 < D) {
                             w[i] = loadRound(pos + (s32)(1024 * (D - 1)));
-                            loadLevels(AL, pos + (s32)(1024 * (D - 1)), lv[i]);
+                            loadLevels(AL, HS, pos + (s32)(1024 * (D - 1)), lv[i]);
                         }
                         return true;
                     });
@@ -1147,7 +1211,7 @@ SQ_DEV void cert_lds_core(CertCtx& cx, FastLds* L, u8* rawOut) {
                         if (pos >= myStop) return false;
                         if constexpr (i + 1 < D) {
                             w[i] = loadRound(pos + (s32)(1024 * (D - 1)));
-                            loadLevels(AL, pos + (s32)(1024 * (D - 1)), lv[i]);
+                            loadLevels(AL, HS, pos + (s32)(1024 * (D - 1)), lv[i]);
                         }
                         return true;
                     });
@@ -1236,11 +1300,20 @@ SQ_DEV void cert_lds_core(CertCtx& cx, FastLds* L, u8* rawOut) {
     certEnd = sh[FW_SH_CERT0];
     certEnd1 = sh[FW_SH_CERT1];
     if (sh[FW_SH_FLAGS] & 1) certEnd = certEnd1 = SQZ_WINDOW_START;
+    cx.wakeBad = (sh[FW_SH_FLAGS] & 8u) ? 1u : 0u;
     wv_fence();
     FPROF_ADD(L, 3, t_res);
 #else
     // scalar twin: the same statement, computed plainly
-    (void)bloom; (void)vals; (void)ends; (void)hits; (void)lvlWords;
+    (void)bloom; (void)vals; (void)ends; (void)lvlWords;
+    u32 nH = 0; // the list of hits as the device leaves it: (p, bytes) of a scanned position, (0, bytes) of a pair inside S
+    auto pushHit = [&](u32 p, u32 v) {
+        if (nH < SQZ_FAST_HITS) {
+            hits[2 * nH] = p;
+            hits[2 * nH + 1] = v;
+        }
+        nH++;
+    };
     auto note = [&](u32 sviol) {
         if (sviol < blk1)
             certEnd = sviol < certEnd ? sviol : certEnd;
@@ -1274,7 +1347,10 @@ SQ_DEV void cert_lds_core(CertCtx& cx, FastLds* L, u8* rawOut) {
     std::sort(sv.begin(), sv.end());
     for (u32 i = 1; i < nCert; i++) // an earlier scheduled position with the same bytes
         for (u32 j = i; j-- > 0 && sv[j].first == sv[i].first;)
-            if (reaches(sv[j].second, sv[i].second)) note(sv[i].second);
+            if (reaches(sv[j].second, sv[i].second)) {
+                note(sv[i].second);
+                pushHit(0u, sv[i].first);
+            }
     // every scheduled position must be one the arithmetic knows (else the scan would skip a wrong set)
     for (u32 i = 0; i < nCert; i++)
         if (!isSched[sv[i].second]) certEnd = certEnd1 = SQZ_WINDOW_START;
@@ -1283,8 +1359,16 @@ SQ_DEV void cert_lds_core(CertCtx& cx, FastLds* L, u8* rawOut) {
         u32 const vp = sq_rd32(base + p);
         auto it = std::lower_bound(sv.begin(), sv.end(), std::make_pair(vp, p + 1));
         for (; it != sv.end() && it->first == vp; ++it) // scheduled positions beyond p with these bytes
-            if (reaches(p, it->second)) note(it->second);
+            if (reaches(p, it->second)) {
+                note(it->second);
+                pushHit(p, vp);
+            }
     }
+    L->sh[FW_SH_NHITS] = nH;
+    L->sh[FW_SH_FLAGS] = 0;
+    if (cx.wakeLim) // second pass: the bucket check (see CertCtx)
+        for (u32 p = SQZ_WINDOW_START; p < cx.wakeLim && p < pEnd; p++)
+            if (p != cx.wakeSkip && base[p] == (u8)cx.wakeByte && hash4(sq_rd32(base + p), cx.wakeHashLog) == cx.wakeHash) cx.wakeBad = 1;
 #endif
     cx.certEnd = certEnd;
     cx.certEnd1 = (blk1 != 0xFFFFFFFFu) ? certEnd1 : 0u;
@@ -1303,6 +1387,14 @@ SQ_DEV void cert_lds_core(CertCtx& cx, FastLds* L, u8* rawOut) {
 //     data that is what makes the certificate hold at all (a 2 MiB chunk has ~6 four-byte coincidences at searched
 //     positions, 0.03 five-byte ones).  Blocks: 128 KiB each while every block so far was emitted raw -- libzstd's
 //     pre-block splitter only acts once `savings >= 3`, and a raw block contributes -3 (ZSTD_optimalBlockSize).
+#if !SQ_ON_DEVICE && defined(SQ_SIM_TRACE) // (tools/one_match_stats.py: why the second pass was not tried / did not hold)
+#define SQ_OM_BREAK { fprintf(stderr, "[one match] refused at line %d\n", __LINE__); break; }
+#else
+#define SQ_OM_BREAK break
+#endif
+#if !SQ_ON_DEVICE
+static u32 g_sim_one_match_blocks = 0; // (simulator build: blocks decided by the second pass)
+#endif
 SQ_DEV u32 fastpath_blocks(const u8* src, u32 n, u8* dst, u32 cap, u32 bA, const CParams& cp, const u32* schedTab, FastLds* L,
                            u32* e0, u32* e1, u32 dbg, u64* hashPool, u8* hashedFlag, u32* rawDone = nullptr) {
     constexpr u32 BS = SQZ_BLOCKSIZE_MAX;
@@ -1343,21 +1435,140 @@ SQ_DEV u32 fastpath_blocks(const u8* src, u32 n, u8* dst, u32 cap, u32 bA, const
     cx.hashPool = hashPool;
     cx.hashedFlag = hashedFlag;
     cx.hashDone = 0;
+    cx.wakeLim = cx.wakeSkip = cx.wakeHash = cx.wakeByte = cx.wakeBad = 0;
+    cx.wakeHashLog = cp.hashLog;
     if (cx.nCert == 0 || cx.nCert > SQZ_FAST_VALS || lenA < 9) return 0;
     cx.dbg = dbg;
     u32 const nB = lenB ? 2u : 1u;
     bool const sized = lenA >= SQZ_FAST_MIN_BLOCK && (lenB == 0 || lenB >= SQZ_FAST_MIN_BLOCK);
     u32 const hdr = 5 + (n < 256 ? 1u : (n < 65536 + 256 ? 2u : 4u)); // = fast_frame_header()
     bool const room = cap >= n + hdr + 3 * nBlocksAll;
-    cert_lds_core(cx, L, (sized && room && !(dbg & 4)) ? dst + hdr : nullptr);
+    // ONE call site of the scan, in a loop of at most two turns (the scan is three instantiations of a long loop: a second
+    // copy of it no longer fits the instruction cache).  Turn 1: the certificate of the two blocks.  Turn 2 (chunks of the
+    // btlazy2 class, 16-byte aligned): see "one short match" below.
+    // What outlives the second turn is kept in LDS (L->keep: 0 / 1 the first pass's certificate ends, 2 its rawEnd, 3 the
+    // block that ends up with ONE sequence (2: none), 4 / 5 the bytes its match covers, 6 the verdict), not in registers: the
+    // scan is at its limit of 128 vector registers.
+    SQ_L u32* const keep = (SQ_L u32*)L->keep;
+#if SQ_ON_DEVICE
+#pragma clang loop unroll(disable)
+#endif
+    for (;;) {
+        bool const second = cx.tab0 == 3;
+        cert_lds_core(cx, L, (!second && sized && room && !(dbg & 4)) ? dst + hdr : nullptr);
+        if (second) { // the tail certificate's answer
+            u32 const ilimPos = cx.chunkEndPos - tail;
+            bool const holds = cx.certEnd >= ilimPos && !cx.wakeBad && cx.nOvf == 0;
+#if !SQ_ON_DEVICE && defined(SQ_SIM_TRACE)
+            fprintf(stderr, "[one match] second pass: certEnd %u ilim %u wakeBad %u nOvf %u anchor %u n %u\n", cx.certEnd, ilimPos, cx.wakeBad, cx.nOvf, cx.base0Pos, cx.nCert);
+#endif
+            if (fw_first()) {
+                keep[6] = holds ? 1u : 0u;
+                if (!holds) keep[3] = 2;
+            }
+            break;
+        }
+        u32 const ce0 = cx.certEnd, ce1 = cx.certEnd1;
+        // every search of the two blocks certainly fails?
+        bool const fail0 = ce0 < cx.base0Pos + lenA - tail, fail1 = lenB && ce1 < cx.base1Pos + lenB - tail;
+        bool const whole = !fail0 && !fail1;
+        if (fw_first()) {
+            keep[0] = ce0;
+            keep[1] = ce1;
+            keep[2] = cx.rawEnd;
+            keep[3] = 2;
+            keep[6] = whole ? 1u : 0u;
+        }
+        // ---- one short match.  ~7 % of random chunks have a searched position s* with the 4 bytes of ONE earlier position q
+        // (the rest of the chunk certified).  What libzstd does there is a matter of a few byte comparisons, given that s*'s
+        // bucket holds nothing that could disturb the tree walk (the second pass checks that): the search at s* finds q
+        // (length = common prefix), the depth searches at s* + 1 and s* + 2 find nothing if no earlier position holds their 4
+        // bytes, the match is extended backwards, and the parser goes on behind it with a NEW no-match schedule laid at the
+        // match's end (repcode offset = the match's).  If that schedule's certificate -- the second pass, which also covers
+        // the two depth searches -- holds as well, the block has exactly one sequence: its literals are raw (HUF's sampled
+        // pre-check, on the literals), so its compressed form is larger than the block and libzstd emits it raw, like a
+        // certified block, with the repcodes of the block's start handed on (the other block's certificate stands).
+        // Anything else (a second coincidence, a repcode hit, a long match, a crowded bucket) is left to k_compress_batch.
+#if !SQ_ON_DEVICE && defined(SQ_SIM_TRACE)
+        fprintf(stderr, "[turn0] ce0 %u ce1 %u fail0 %d fail1 %d whole %d row %d sized %d room %d bA %u al %u nOvf %u\n", ce0, ce1, fail0, fail1, whole, row, sized, room, bA, (unsigned)((size_t)src & 15), cx.nOvf);
+#endif
+        if (whole || !(fail0 != fail1) || row || !sized || !room || bA != 0 || ((size_t)src & 15) || (dbg & (4 | 2048)) || cx.nOvf) SQ_OM_BREAK;
+        {
+            const u8* const base = cx.base;
+            u32 const b = fail1 ? 1u : 0u;
+            u32 const blk = b ? cx.base1Pos : cx.base0Pos, bs = b ? lenB : lenA, blkEnd = blk + bs, ilimPos = blkEnd - tail;
+            u32 const sS = b ? ce1 : ce0;
+            // s* is a scheduled search of the block (a full list of hits leaves another kind of end)
+            const u32* const tabS = schedTab + 2 + (b ? SQZ_SCHEDTAB_N : 0u);
+            u32 const nS = b ? cx.nCert - cx.certCnt0 : cx.certCnt0;
+            u32 const jS = sched_count(tabS, nS, sS - blk);
+            if (sS < blk || jS >= nS || gld32(tabS + jS) != sS - blk || sS + 3 >= ilimPos) SQ_OM_BREAK;
+            SQ_L u32* const sh = (SQ_L u32*)L->sh;
+            SQ_L u32* const hits = (SQ_L u32*)L->hits;
+            u32 const nHitsAll = wv_uni(sh[FW_SH_NHITS]);
+            if (nHitsAll > SQZ_FAST_HITS || (wv_uni(sh[FW_SH_FLAGS]) & 3u)) SQ_OM_BREAK;
+            u32 const vS = srd32(base + sS), vS1 = srd32(base + sS + 1), vS2 = srd32(base + sS + 2);
+            if (vS1 == vS || vS2 == vS1) SQ_OM_BREAK; // repcode (offset 1) at s* + 1 / s* + 2
+            // the earlier positions with s*'s bytes: exactly one, a scanned one
+            u32 q = 0, nq = 0;
+            bool odd = false;
+            for (u32 h = 0; h < nHitsAll; h++) {
+                u32 const hp = wv_uni(hits[2 * h]), hv = wv_uni(hits[2 * h + 1]);
+                if (hp == 0) {
+                    if ((hv >> 6) == (vS >> 6)) odd = true; // two scheduled positions share (26 bits of) these bytes
+                } else if (hv == vS && hp < sS) {
+                    q = hp;
+                    nq++;
+                }
+            }
+            if (odd || nq != 1) SQ_OM_BREAK;
+            u32 const off = sS - q;
+            if (off < 2 || srd32(base + q) != vS) SQ_OM_BREAK;
+            // the match: forwards to the block's end at most, backwards to the block's start / the window's first byte
+            u32 ml = 4;
+            while (ml < 64 && sS + ml < blkEnd && srd8(base + sS + ml) == srd8(base + q + ml)) ml++;
+            if (ml >= 64) SQ_OM_BREAK;
+            u32 start = sS;
+            while (start > blk && start - off > SQZ_WINDOW_START && sS - start < 64 && srd8(base + start - 1) == srd8(base + start - off - 1)) start--;
+            if (sS - start >= 64) SQ_OM_BREAK;
+            u32 const anc = sS + ml, mlAll = anc - start;
+            if (mlAll > (bs >> 6) || bs - mlAll < SQZ_FAST_MIN_BLOCK) SQ_OM_BREAK;
+            if (anc <= ilimPos && srd32(base + anc) == srd32(base + anc - 1)) SQ_OM_BREAK; // immediate repcode (offset_2 = 1)
+            // second pass: the "later" schedule laid at the match's end + the two depth searches, every position of the
+            // block and of what lies in front of it scanned; the bucket check for s*
+            u32 const nLater = gld32(schedTab + 1);
+            u32 const j1 = anc < ilimPos ? sched_count(schedTab + 2 + SQZ_SCHEDTAB_N, nLater, ilimPos - anc) : 0u;
+            cx.base0Pos = anc;
+            cx.tab0 = 3;
+            cx.certCnt0 = cx.nCert = j1 + 2; // (no second block)
+            cx.repOff = off;
+            cx.chunkEndPos = blkEnd;
+            cx.wakeLim = sS;
+            cx.wakeSkip = q;
+            cx.wakeHash = hash4(vS, cp.hashLog);
+            cx.wakeByte = vS & 0xFFu;
+            if (fw_first()) {
+                keep[3] = b;
+                keep[4] = start - blk;
+                keep[5] = anc - blk;
+            }
+        }
+        fw_sync(); // (the shared words and the list of hits are written again by the second pass)
+    }
+    fw_sync();
+    cx.certEnd = wv_uni(keep[0]); // what stage 2 is told is the first pass's answer
+    cx.certEnd1 = wv_uni(keep[1]);
+    cx.rawEnd = wv_uni(keep[2]);
+    u32 const seqBlk = wv_uni(keep[3]), seqStart = wv_uni(keep[4]), seqEnd = wv_uni(keep[5]);
+    bool whole = wv_uni(keep[6]) != 0;
     FPROF_T0(t_frame);
     *e0 = (dbg & 64) ? cx.nOvf : cx.certEnd; // (64: bring-up, why the scan gave up)
     *e1 = cx.certEnd1;
     if (rawDone) *rawDone = cx.rawEnd - SQZ_WINDOW_START; // chunk bytes whose raw-block payload the scan has put in place
-    // every search of the two blocks certainly fails?
-    bool whole = cx.certEnd >= cx.base0Pos + lenA - tail;
-    if (lenB) whole = whole && (cx.certEnd1 >= cx.base1Pos + lenB - tail);
     if (dbg & 4) whole = false; // timing experiment: certificate only
+#if !SQ_ON_DEVICE
+    if (whole && seqBlk < 2) g_sim_one_match_blocks++;
+#endif
     u32 ok = 0;
     if (whole && sized && room) {
         // HUF's sampled pre-check: the 4 KiB samples (first and last of each block) are dealt out to the
@@ -1366,10 +1577,19 @@ SQ_DEV u32 fastpath_blocks(const u8* src, u32 n, u8* dst, u32 cap, u32 bA, const
         u32 const nSamples = 2 * nB;
         for (u32 j = wv; j < nSamples; j += FW_NW) {
             u32 const b = j >> 1, bs = b ? lenB : lenA;
-            const u8* const at = src + offA + (b ? lenA : 0u) + ((j & 1) ? bs - 4096 : 0u);
+            const u8* const blkAt = src + offA + (b ? lenA : 0u);
             u32 l = 0, dummy;
             wv_zero_lds(L->bloom + 256 * wv, 256);
-            wv_hist_bytes(L->bloom + 256 * wv, at, 4096);
+            if (b != seqBlk)
+                wv_hist_bytes(L->bloom + 256 * wv, blkAt + ((j & 1) ? bs - 4096 : 0u), 4096);
+            else {
+                // the block's literals are the block without [seqStart, seqEnd): literal i sits at block offset i (< seqStart)
+                // or i + the match's length
+                u32 const mlAll = seqEnd - seqStart, a = (j & 1) ? bs - mlAll - 4096 : 0u; // first literal of the sample
+                u32 const n1 = a < seqStart ? (seqStart - a < 4096 ? seqStart - a : 4096u) : 0u; // ... of them in front of the match
+                if (n1) wv_hist_bytes(L->bloom + 256 * wv, blkAt + a, n1);
+                if (n1 < 4096) wv_hist_bytes(L->bloom + 256 * wv, blkAt + (a + n1) + mlAll, 4096 - n1);
+            }
             wv_max_and_last(L->bloom + 256 * wv, 256, &l, &dummy);
             WV_SERIAL L->sh[FW_SH_SAMPLE + j] = l;
         }
@@ -1474,7 +1694,7 @@ k_incompressible_batch(const u8* data, const u64* off, const u32* len, const u8*
         lds.hsec[128 + l] = (u32)k1;
         lds.hsec[192 + l] = (u32)(k1 >> 32);
     }
-#ifdef SQ_PROF
+#ifdef SQ_PROF_S1
     if (first)
         for (int k = 0; k < 8; k++) lds.prof[k] = 0;
 #endif
@@ -1553,7 +1773,7 @@ k_incompressible_batch(const u8* data, const u64* off, const u32* len, const u8*
             }
         }
     }
-#ifdef SQ_PROF
+#ifdef SQ_PROF_S1
     fw_sync();
     if (first)
         for (int k = 0; k < 8; k++) ((unsigned long long*)(etab_pool + (u64)blockIdx.x * (etab_bytes + 256) + etab_bytes + 32))[k] = lds.prof[k];

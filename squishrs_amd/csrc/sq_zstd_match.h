@@ -974,7 +974,7 @@ struct CertCtx {
     u32 certCnt0, nCert; // scheduled searches in block 0 / in the chunk
     u32 base0Pos;        // stage 1 (cert_lds_core) only: where the first certified block starts (SQZ_WINDOW_START for a chunk of
                          // at most two blocks; a later block of a large chunk, whose earlier blocks are then only scanned)
-    u32 tab0;            //   ... which schedule table that block uses: 0 "first" (the frame's first block), 1 "later"
+    u32 tab0;            //   ... which schedule table that block uses: 0 "first" (the frame's first block), 1 "later" (3: see below)
     u32 tail;            //   ... searches stop this many bytes before a block's end: 8, row-hash finder 16
     u32 hashBits;        //   ... 0: any earlier position with a search's 4 bytes breaks the certificate (btlazy2); else the
                          //   row-hash finder's rule: only one whose 5-byte hash (this many bits: row + tag) is the search's too
@@ -994,6 +994,16 @@ struct CertCtx {
     u8* hashedFlag;      //   ... the byte that says they are all there
     u32 hashDone;        // result: the sums are complete
     u32 dbg;             // timing experiments (SQ_FAST_DBG): 1 = no build, 2 = no scan, 8 = build without the exchange
+    // stage 1's SECOND pass only (fastpath_blocks: the tail certificate of a block that one short match keeps from being
+    // certified; zero otherwise):
+    // there tab0 = 3: one block, its schedule (the "later" table) laid at base0Pos = the anchor behind the match, which may
+    // sit at any byte offset; the last two of the nCert entries are not from the table: the lazy parser's two depth searches
+    // at wakeLim + 1 and wakeLim + 2.  (Few fields, and none that the first pass could not do without: they are live
+    // through the scan, which is at its limit of registers.)
+    u32 wakeLim;         // != 0: the search the match was found at; report in wakeBad whether a position p < wakeLim other than wakeSkip shares its first byte
+    u32 wakeSkip;        //    with the search at wakeLim (wakeByte) AND hashes into that search's bucket (wakeHash, wakeHashLog
+    u32 wakeHash, wakeHashLog, wakeByte; // bits): such a node could leave bestLength > 0 before the walk reaches the match
+    u32 wakeBad;         // result
 };
 
 #define SQZ_CERT_DUP SQZ_HT_PEND // table-word flag: another scheduled position shares this bucket
@@ -1006,9 +1016,12 @@ SQ_DEV u32 cert_pos_c(const CertCtx& cx, u32 i) { // position of the i-th schedu
 }
 // the same for stage 1's generalised form (base0Pos / tab0)
 SQ_DEV u32 cert_pos_g(const CertCtx& cx, u32 i) {
-    bool const first = i < cx.certCnt0;
-    u32 const slot = first ? (cx.tab0 ? SQZ_SCHEDTAB_N : 0u) + i : SQZ_SCHEDTAB_N + cx.tabOff1 + (i - cx.certCnt0);
-    return sq_gld32(cx.schedTab + 2 + slot) + (first ? cx.base0Pos : cx.base1Pos);
+    bool const x = (cx.tab0 & 2u) && i + 2 >= cx.nCert; // (second pass: the two searches that are not on the schedule)
+    u32 const j = x ? 0u : i;
+    bool const first = j < cx.certCnt0;
+    u32 const slot = first ? (cx.tab0 ? SQZ_SCHEDTAB_N : 0u) + j : SQZ_SCHEDTAB_N + cx.tabOff1 + (j - cx.certCnt0);
+    u32 const sp = sq_gld32(cx.schedTab + 2 + slot) + (first ? cx.base0Pos : cx.base1Pos);
+    return x ? cx.wakeLim + 3 - (cx.nCert - i) : sp;
 }
 
 SQ_DEVFN void cert_compute_core(CertCtx& cx) {

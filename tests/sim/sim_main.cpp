@@ -86,6 +86,7 @@ extern "C" size_t sim_compress_two_stage(const uint8_t* src, size_t n, uint8_t* 
     free(ws);
     return r;
 }
+extern "C" unsigned sim_one_match_blocks(void) { return sqz::g_sim_one_match_blocks; } // blocks stage 1's second pass decided so far
 extern "C" unsigned sim_replayed_blocks(void) { return sqz::g_sim_replayed_blocks; } // blocks whose searches were replaced by row_replay_nomatch so far
 // The arithmetic that tells the scan which positions are scheduled ones (fast_sched_mask) against the
 // schedule tables, for a chunk of n bytes: returns the number of positions where they disagree and

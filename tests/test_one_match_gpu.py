@@ -1,0 +1,41 @@
+"""Stage 1's second pass on the device ("one short match", squishrs_amd/csrc/sq_zstd_fast.h fastpath_blocks): a block that
+ONE short match keeps from being certified is settled by the workgroup itself -- the match by byte comparisons, the rest of the
+block by a second certificate laid at the match's end -- instead of being handed to k_compress_batch.  Every frame against
+the oracle, in the split and in the fused form of a batch; reference behaviour: zstd::encode_all(level 12) of
+/root/reference/src/fsutil/writer.rs:23-62."""
+import os
+import random
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+
+pytestmark = pytest.mark.gpu
+
+
+def test_one_short_match_chunks_split_and_fused_forms(oracle):
+    import fuzz_one_match_sim as f   # (its make_case; the simulator library it loads is not used here)
+    import squishrs_amd
+    from test_compress_gpu import _batch_compress
+    rng = random.Random(4242)
+    chunks, kinds = [], []
+    while len(chunks) < 360:
+        d, k = f.make_case(rng)
+        if d is not None:
+            chunks.append(d)
+            kinds.append(k)
+    want = [oracle.compress_chunk(c) for c in chunks]
+    st = squishrs_amd.ChunkStore(device=0, dedup_capacity=1 << 14)
+    frames = _batch_compress(st, chunks)
+    decided = st.timings().fast_decided
+    bad = [(i, kinds[i], len(chunks[i])) for i in range(len(chunks)) if frames[i] != want[i]]
+    assert not bad, bad[:10]
+    # the pass decided a good part of the plain cases (without it stage 1 decides none of these chunks: each has a coincidence)
+    assert decided >= 40, decided
+    st.reset()
+    res = st.insert_batch(chunks)
+    bad2 = [(i, kinds[i]) for i, r in enumerate(res) if r.compressed_data != want[i] or r.hash != oracle.hash_chunk(chunks[i])]
+    assert not bad2, bad2[:10]
+    st.close()

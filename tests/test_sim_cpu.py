@@ -208,3 +208,18 @@ def test_sim_fuzz_planted_coincidences(sim):
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_planted_sim.py"), "11", "60"],
                        capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "bad 0" in r.stdout, r.stdout + r.stderr
+
+
+def test_sim_one_short_match_second_pass(sim):
+    """Stage 1's second pass (sq_zstd_fast.h fastpath_blocks, "one short match"): 160 random chunks with ONE planted coincidence
+    on a searched position and the variants the pass must refuse (a second copy, a repeat behind the match or at the depth
+    searches, a run, a member of the search's bucket that shares its first byte, a second coincidence on the new schedule) --
+    the two kernels' simulator build vs the oracle; the pass must have decided some of them."""
+    import subprocess
+    import sys
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_one_match_sim.py"), "21", "160"],
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and " bad 0 " in r.stdout, r.stdout + r.stderr
+    import re
+    m = re.search(r"blocks decided by the second pass (\d+)", r.stdout)
+    assert m and int(m.group(1)) >= 15, r.stdout
