@@ -82,9 +82,9 @@ SQ_DEV bool fw_static_for(F&& f) {
 #define FW_SH_NHITS 0u  // hits listed so far (may run past SQZ_FAST_HITS: the list is then full)
 #define FW_SH_CERT0 1u  // certEnd  (atomic minimum over the waves)
 #define FW_SH_CERT1 2u  // certEnd1
-#define FW_SH_FLAGS 3u  // 1: the repeats inside S do not fit the hit list, 2: a bucket too large for this path
-#define FW_SH_WAKE 4u   // second pass: 4 = the search position the bucket check belongs to (0: none), 6 = the match's position,
-                        // (| the table's hash bits << 24), 7 = that search's bucket hash | its first byte << 24 (FW_SH_FLAGS bit 8: the check failed)
+#define FW_SH_FLAGS 3u  // 1: the repeats inside S do not fit the hit list, 2: a bucket too large for this path, 8: second pass, the bucket check failed
+#define FW_SH_WAKE 4u   // second pass, the bucket check: 4 = the search position it belongs to, 6 = the match's position, 7 = that
+                        // search's bucket hash | its first byte << 24
 #define FW_SH_IDX 5u    // the chunk index the workgroup pulled from the queue
 #define FW_SH_FIN 8u    // [FW_NW] position each wave's scan ended at
 #define FW_SH_SAMPLE 12u // [4] largest count of each 4 KiB sample of the HUF pre-check
@@ -296,12 +296,13 @@ SQ_DEV u32 fast_get16(const SQ_L u32* arr, u32 key) { return (arr[key >> 1] >> (
 
 // positions of the scheduled searches i, i + 64, ..., i + 448 (clamped to the last one): the eight table
 // loads are issued together (left to itself hipcc waits for each before it computes the next address)
+template <bool TAIL>
 SQ_DEV void cert_pos8(const CertCtx& cx, u32 i, u32 nCert, u32 (&sp)[8]) {
     u32 t[8], ad[8];
 #pragma unroll
     for (u32 g = 0; g < 8; g++) {
         u32 const j0 = (i + 64 * g < nCert) ? i + 64 * g : nCert - 1;
-        bool const x = (cx.tab0 & 2u) && j0 + 2 >= nCert; // (second pass: the two searches that are not on the schedule; as cert_pos_g)
+        bool const x = TAIL && j0 + 2 >= nCert; // (second pass: the two searches that are not on the schedule; as cert_pos_g)
         u32 const j = x ? 0u : j0;
         bool const first = j < cx.certCnt0;
         u32 const slot = first ? (cx.tab0 ? SQZ_SCHEDTAB_N : 0u) + j : SQZ_SCHEDTAB_N + cx.tabOff1 + (j - cx.certCnt0);
@@ -339,6 +340,9 @@ SQ_DEV void vbloom_add3(SQ_L u32* const B, u32 v) {
 // twice (values at S, stream) instead of three times; cx.rawEnd = the position up to which that was done
 // (SQZ_WINDOW_START = nothing).  Only for 16-byte aligned chunks: a lane's 16 source bytes then never
 // straddle the chunk start or the block boundary.
+// TAIL: the instantiation of stage 1's SECOND pass (fastpath_blocks; cx.tab0 == 3, see CertCtx): a copy of its own of the
+// aligned scan without the fused hash, so that nothing of it costs the first pass's loops a register or a branch.
+template <bool TAIL>
 SQ_DEV void cert_lds_core(CertCtx& cx, FastLds* L, u8* rawOut) {
     cx.rawEnd = SQZ_WINDOW_START;
     cx.hashDone = 0;
@@ -372,9 +376,6 @@ SQ_DEV void cert_lds_core(CertCtx& cx, FastLds* L, u8* rawOut) {
         sh[FW_SH_CERT0] = certEnd;
         sh[FW_SH_CERT1] = certEnd1;
         sh[FW_SH_FLAGS] = 0;
-        sh[FW_SH_WAKE] = cx.wakeLim;
-        sh[FW_SH_WAKE + 2] = cx.wakeSkip | (cx.wakeHashLog << 24);
-        sh[FW_SH_WAKE + 3] = cx.wakeHash | (cx.wakeByte << 24);
     }
     fw_sync();
     u32 vmin = 0xFFFFFFFFu, vmin1 = 0xFFFFFFFFu; // lane-local minima of the violating scheduled positions
@@ -429,7 +430,7 @@ SQ_DEV void cert_lds_core(CertCtx& cx, FastLds* L, u8* rawOut) {
             u32 sp[8];
 #pragma unroll
             for (u32 g = 0; g < 8; g++) sp[g] = 0;
-            if (i0 < nBuild) cert_pos8(cx, i0 + lane, nCert, sp);
+            if (i0 < nBuild) cert_pos8<TAIL>(cx, i0 + lane, nCert, sp);
 #pragma unroll
             for (u32 g = 0; g < 8; g++) spA[8 * it + g] = sp[g];
         }
@@ -480,31 +481,71 @@ SQ_DEV void cert_lds_core(CertCtx& cx, FastLds* L, u8* rawOut) {
             }
         }
     } else {
+        // (a tail certificate: repcode offset of a match.  As above -- positions, then all gathers at once -- with one more
+        // gather per search: the four bytes its repcode test compares with)
+        u32 spA[8 * ITS];
+        u64 q[8 * ITS];
+        u32 vr[8 * ITS];
+#pragma unroll
+        for (u32 it = 0; it < ITS; it++) {
+            u32 const i0 = 512 * (it * NW + wv);
+            u32 sp[8];
+#pragma unroll
+            for (u32 g = 0; g < 8; g++) sp[g] = 0;
+            if (i0 < nBuild) cert_pos8<TAIL>(cx, i0 + lane, nCert, sp);
+#pragma unroll
+            for (u32 g = 0; g < 8; g++) spA[8 * it + g] = sp[g];
+        }
 #pragma unroll
         for (u32 it = 0; it < ITS; it++) {
             u32 const i0 = 512 * (it * NW + wv);
 #pragma unroll
-            for (u32 g = 0; g < 8; g++) vv[8 * it + g] = 0;
+            for (u32 g = 0; g < 8; g++) q[8 * it + g] = 0, vr[8 * it + g] = 0;
             if (i0 < nBuild) {
-                u32 sp[8], v[8], v1[8], vr[8];
-                cert_pos8(cx, i0 + lane, nCert, sp);
 #pragma unroll
                 for (u32 g = 0; g < 8; g++) {
-                    v[g] = sq_grd32(base + sp[g]);
-                    v1[g] = sq_grd32(base + sp[g] + 1);
-                    vr[g] = sq_grd32(base + sp[g] + 1 - cx.repOff);
-                }
-#pragma unroll
-                for (u32 g = 0; g < 8; g++) {
-                    vv[8 * it + g] = v[g];
-                    if (i0 + 64 * g + lane < nCert) {
-                        vbloom_add3(bloom, v[g]);
-                        (void)fast_cnt16_add(ends, v[g] >> 22);
-                        if (v1[g] == vr[g]) note(sp[g], vmin, vmin1); // repcode at s+1
-                    }
+                    q[8 * it + g] = sq_grd64(base + spA[8 * it + g]); // s + 8 <= block end
+                    vr[8 * it + g] = sq_grd32(base + spA[8 * it + g] + 1 - cx.repOff);
                 }
             }
         }
+        wv_fence();
+#pragma unroll
+        for (u32 it = 0; it < ITS; it++) {
+            u32 const i0 = 512 * (it * NW + wv);
+#pragma unroll
+            for (u32 g = 0; g < 8; g++) {
+                u32 const vg = (u32)q[8 * it + g];
+                vv[8 * it + g] = vg;
+                if (i0 < nBuild && i0 + 64 * g + lane < nCert) {
+                    vbloom_add3(bloom, vg);
+                    (void)fast_cnt16_add(ends, vg >> 22);
+                    if ((u32)(q[8 * it + g] >> 8) == vr[8 * it + g]) note(spA[8 * it + g], vmin, vmin1); // repcode at s+1
+                }
+            }
+        }
+    }
+    // second pass: the bucket check (CertCtx::wakeLim) as members of the set.  A position in front of the search that shares
+    // the search's first byte AND its bucket holds one of the 2^(24 - hashLog) values  v = y * K^-1,  y = bucket << (32 - hashLog)
+    // | t << 8 | (first byte * K & 0xFF)  (K: hash4's odd multiplier): they join S' as entries of their own (index 0xFF00 + t),
+    // the scan then finds such a position like any other repeat and the hits' resolution tells it apart.
+    static_assert((u32)(2654435761u * 0x0E8B2F51u) == 1u, "inverse of hash4's multiplier");
+    u32 const nPseudo = (TAIL && cx.wakeLim) ? 1u << (24u - cx.wakeHashLog) : 0u;
+    u32 const hlog = cx.wakeHashLog; // (the size class's, not a per-pass value)
+    auto pseudoVal = [&](u32 t, u32 hashAndByte) -> u32 { // hashAndByte: bucket | first byte << 24
+        u32 const y = ((hashAndByte & 0xFFFFFFu) << (32u - hlog)) | (t << 8) | (((hashAndByte >> 24) * 2654435761u) & 0xFFu);
+        return y * 0x0E8B2F51u;
+    };
+    // (the check's parameters wait in LDS for the hits' resolution: registers are short during the scan)
+    if (tid == 0) {
+        sh[FW_SH_WAKE] = cx.wakeLim;
+        sh[FW_SH_WAKE + 2] = cx.wakeSkip;
+        sh[FW_SH_WAKE + 3] = cx.wakeHash | (cx.wakeByte << 24);
+    }
+    if (tid < nPseudo) {
+        u32 const pv = pseudoVal(tid, cx.wakeHash | (cx.wakeByte << 24));
+        vbloom_add3(bloom, pv);
+        (void)fast_cnt16_add(ends, pv >> 22);
     }
     fw_sync(); // every wave's counts are in
     // ---- prefix sum: counts -> bucket starts (16 buckets = 8 words per lane; one wave does it)
@@ -554,6 +595,14 @@ SQ_DEV void cert_lds_core(CertCtx& cx, FastLds* L, u8* rawOut) {
                         idxs[slot] = (u16)(i0 + 64 * g + lane);
                     }
                 }
+        }
+    }
+    if (tid < nPseudo) {
+        u32 const pv = pseudoVal(tid, cx.wakeHash | (cx.wakeByte << 24));
+        u32 const slot = fast_cnt16_add(ends, pv >> 22);
+        if (slot < SQZ_FAST_VALS) {
+            vals[slot] = (u16)(pv >> 6);
+            idxs[slot] = (u16)(0xFF00u + tid);
         }
     }
     fw_sync();
@@ -616,10 +665,10 @@ SQ_DEV void cert_lds_core(CertCtx& cx, FastLds* L, u8* rawOut) {
     const u8* const lastByte = src0 - SQZ_WINDOW_START + chunkEndU - 1;
     const u8* const aLast = lastByte - ((size_t)lastByte & 15);
     rawOut = (u8*)wv_uni64((u64)(size_t)rawOut);
-    bool const rawCopy = rawOut != nullptr && src0 == a0;
+    bool const rawCopy = !TAIL && rawOut != nullptr && src0 == a0;
     // the fused hash needs the whole chunk streamed (a scan that would stop at an early certificate end goes on:
     // what it finds beyond that end changes nothing) and rounds that are XXH3 blocks (aligned chunk)
-    bool const hashOn = cx.hashPool != nullptr && src0 == a0 && !(cx.dbg & 2) && !(tab0U & 2u); // (not in the second pass)
+    bool const hashOn = !TAIL && cx.hashPool != nullptr && src0 == a0 && !(cx.dbg & 2); // (not in the second pass)
     auto scanStop = [&]() -> u32 {
         u32 const ce = (blk1 != 0xFFFFFFFFu) ? certEnd1 : certEnd;
         return (ce < pEnd && !hashOn) ? ce : pEnd;
@@ -650,22 +699,16 @@ SQ_DEV void cert_lds_core(CertCtx& cx, FastLds* L, u8* rawOut) {
     // stream, and none of the level arithmetic below runs.
     const u16* const schedBits = (const u16*)wv_uni64((u64)(size_t)(cx.schedTab + SQZ_SCHEDBITS_OFF));
     auto loadLevels = [&](auto AL, auto HS, s32 rp, u32& wl) {
-        if constexpr (decltype(AL)::value && !decltype(HS)::value) {
-            if (tab0U & 2u) { // second pass: the "later" bitmap laid at base0U, any byte offset -- the two words around the
-                              // lane's first position (round() shifts them into place); lanes in front of base0U: word 0
-                s32 const r = rp + (s32)(16 * lane) - (s32)base0U;
-                u32 const wi = r > 0 ? (u32)r >> 4 : 0u;
-                wl = sq_grd32((const u8*)(schedBits + SQZ_SCHEDBITS_N + (wi < SQZ_SCHEDBITS_N ? wi : SQZ_SCHEDBITS_N - 1)));
-                return;
-            }
-        }
         if constexpr (decltype(AL)::value) {
             // (rounds in front of the first certified block -- the earlier blocks of a large chunk, base0Pos > the
             // chunk's start -- hold no scheduled position of THIS certificate: their word is loaded like any other, from
             // a clamped index, and dropped in round())
             bool const second = (blk1 != 0xFFFFFFFFu) && rp >= (s32)blk1;
             u32 const tabSel = second ? SQZ_SCHEDBITS_N : (tab0U ? SQZ_SCHEDBITS_N : 0u);
-            u32 const wi = (((u32)rp - (second ? blk1 : base0U)) >> 4) + lane;
+            // (per lane and signed: in the second pass base0U is an anchor at any byte offset, and the round that contains it
+            // has lanes on both sides -- those behind it need their own word, r >> 4 = the word around the lane's first position)
+            s32 const r = rp + (s32)(16 * lane) - (s32)(second ? blk1 : base0U);
+            u32 const wi = r > 0 ? (u32)r >> 4 : 0u;
             // (a 4-byte load of the 2-byte word: the upper half -- the next window's word -- never reaches the result,
             // the masks it is combined with have 16 bits; as a 2-byte load the value's zero extension became an
             // instruction of its own that hipcc placed at the loop's back edge, behind a wait for ALL loads in flight)
@@ -903,41 +946,6 @@ SQ_DEV void cert_lds_core(CertCtx& cx, FastLds* L, u8* rawOut) {
             l = l < 0 ? 0 : (l > 16 ? 16 : l);
             okMask = ((1u << l) - 1u) & ~((1u << f) - 1u);
         }
-        if constexpr (decltype(AL)::value && !decltype(HS)::value) {
-            if (tab0U & 2u) { // second pass (in front of the filter, whose 54 temporaries leave no room for anything else)
-                // the bucket check (FW_SH_WAKE): positions in front of the search that share its first byte are hashed
-                u32 const wLim = sh[FW_SH_WAKE];
-                if (wLim && (u32)pos < wLim) {
-                    u32 const wSkip = sh[FW_SH_WAKE + 2] & 0xFFFFFFu, wLog = sh[FW_SH_WAKE + 2] >> 24, wHB = sh[FW_SH_WAKE + 3];
-                    u32 const b4 = (wHB >> 24) * 0x01010101u;
-                    u32 const dd[4] = {w.x, w.y, w.z, w.w};
-                    u32 zm = 0;
-#pragma unroll
-                    for (u32 q = 0; q < 4; q++) { // (zero-byte test; a byte above a zero byte may be flagged too: rechecked below)
-                        u32 const x = dd[q] ^ b4;
-                        u32 const z = (x - 0x01010101u) & ~x & 0x80808080u;
-                        zm |= (((z >> 7) & 1u) | ((z >> 14) & 2u) | ((z >> 21) & 4u) | ((z >> 28) & 8u)) << (4 * q);
-                    }
-                    {
-                        s32 l = (s32)stop - lo; // (the positions the scan covers)
-                        l = l < 0 ? 0 : (l > 16 ? 16 : l);
-                        zm &= (1u << l) - 1u;
-                    }
-                    bool bad = false;
-                    while (wv_ballot(zm != 0)) {
-                        if (zm) {
-                            u32 const j = (u32)__builtin_ctz(zm);
-                            zm &= zm - 1;
-                            u32 const p = (u32)(lo + (s32)j), v = valAt(w, d4, j);
-                            if (p >= SQZ_WINDOW_START && p < wLim && p != wSkip && (v & 0xFFu) == (wHB >> 24) &&
-                                hash4(v, wLog) == (wHB & 0xFFFFFFu))
-                                bad = true;
-                        }
-                    }
-                    if (wv_ballot(bad) && lane == 0) __hip_atomic_fetch_or(&sh[FW_SH_FLAGS], 8u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                }
-            }
-        }
         u32 cm = filterBits(w, d4);
         if constexpr (decltype(AL)::value) {
             // the window's bitmap word; a block's searches stop 8 bytes before its end (a short last block
@@ -949,7 +957,7 @@ SQ_DEV void cert_lds_core(CertCtx& cx, FastLds* L, u8* rawOut) {
             // are the bitmap word as loaded (its upper half, the next window's word, lies above cm's 16 bits).  The test
             // is wave-uniform and the edge rounds are kept behind a real branch (the asm statement: hipcc would otherwise
             // turn the clipping into twelve selects that every round executes).
-            bool const tailPass = !decltype(HS)::value && (tab0U & 2u) != 0; // (second pass: every round is an edge round)
+            constexpr bool tailPass = TAIL; // (second pass: every general round is an edge round)
             bool const interior = active && !tailPass && (u32)pos + 1024 <= stop && (u32)pos + 1024 <= lim && (u32)pos >= base0U;
             if (interior)
                 cm &= ~wl;
@@ -963,12 +971,13 @@ SQ_DEV void cert_lds_core(CertCtx& cx, FastLds* L, u8* rawOut) {
                 }
                 u32 sm = (u32)pos >= base0U ? wl : 0u;
                 if constexpr (!decltype(HS)::value) {
-                    if (tailPass) {
+                    if constexpr (tailPass) {
                         // the schedule's bitmap starts at base0U, which is no multiple of 16 away from the lane's window:
                         // bit k of the window = bit k + r of the bitmap, r = lo - base0U (word r >> 4 and the one behind it
                         // are in wl; in front of base0U nothing is scheduled)
+                        // (a lane that straddles base0U: the schedule starts dense, its first 16 positions are all searched)
                         s32 const r = lo - (s32)base0U;
-                        sm = r >= 0 ? (wl >> (r & 15)) & 0xFFFFu : (r > -16 ? (wl << (u32)(-r)) & 0xFFFFu : 0u);
+                        sm = r >= 0 ? (wl >> (r & 15)) & 0xFFFFu : (r > -16 ? (0xFFFFu << (u32)(-r)) & 0xFFFFu : 0u);
                     }
                 }
                 if ((u32)pos + 1024 > lim) {
@@ -1033,6 +1042,9 @@ SQ_DEV void cert_lds_core(CertCtx& cx, FastLds* L, u8* rawOut) {
                 sq_gwr128((u8*)(size_t)dstp + lane16, w);
 #endif
             }
+            // (second pass: the schedule's bitmap starts at base0U, no multiple of 16 away from the lane's window -- the same
+            // shift for every lane and round; loadBitsU's four bytes hold the window's word and the one behind it)
+            if constexpr (TAIL) wl >>= ((u32)pos - base0U) & 15u;
             cm &= ~wl;
         }
         if (nCand == 0) pendFrom = pos;
@@ -1078,7 +1090,7 @@ SQ_DEV void cert_lds_core(CertCtx& cx, FastLds* L, u8* rawOut) {
     // 2 = rounds in front of them, with every round the step prefetches in front of them too (their bitmap words are not
     // loaded), 0 = neither (a general step)
     auto fastKindN = [&]() -> u32 {
-        if ((cx.dbg & 1024) || (tab0U & 2u) || (u32)pos + 1024u * (2u * SQZ_FAST_DEPTH - 1u) > loadEnd) return 0u;
+        if ((cx.dbg & 1024) || (u32)pos + 1024u * (2u * SQZ_FAST_DEPTH - 1u) > loadEnd) return 0u;
         u32 const stepEnd = (u32)pos + 1024u * SQZ_FAST_DEPTH;
         u32 const stp = scanStop();
         if (stepEnd > (u32)myStop || stepEnd > stp) return 0u;
@@ -1222,7 +1234,9 @@ SQ_DEV void cert_lds_core(CertCtx& cx, FastLds* L, u8* rawOut) {
         if constexpr (decltype(HS)::value) full = hsDead;
     };
     if (pos < myStop && !(cx.dbg & 2)) {
-        if (src0 == a0) {
+        if constexpr (TAIL) // (the caller only sends 16-byte aligned chunks here)
+            scan(std::true_type{}, std::false_type{});
+        else if (src0 == a0) {
             if (hashOn)
                 scan(std::true_type{}, std::true_type{});
             else
@@ -1281,20 +1295,26 @@ SQ_DEV void cert_lds_core(CertCtx& cx, FastLds* L, u8* rawOut) {
             return hash5(sq_grd64(base + p), cx.hashBits) == hash5(sq_grd64(base + s_), cx.hashBits);
         };
         u32 v0 = 0xFFFFFFFFu, v1 = 0xFFFFFFFFu;
+        bool wbad = false;
         for (u32 a = lo; a < hi; a++) { // (a bucket holds 3.4 values on average, SQZ_FAST_BUCKET_MAX at most)
             if (vals[a] != tag) continue;
+            if (idxs[a] >= 0xFF00u) { // second pass, a value of the bucket check: is p a position that check is about?
+                if (hp != 0 && pseudoVal(idxs[a] - 0xFF00u, sh[FW_SH_WAKE + 3]) == hv && hp < sh[FW_SH_WAKE] && hp != sh[FW_SH_WAKE + 2]) wbad = true;
+                continue;
+            }
             u32 const sa = posOf(idxs[a]), va = sq_grd32(base + sa);
             if (hp != 0) { // a scanned position p with the bytes hv: every scheduled s > p with those bytes
                 if (va == hv && sa > hp && reaches(hp, sa)) note(sa, v0, v1);
             } else { // two scheduled positions share bits 6..31: of two with equal bytes, the later search can succeed
                 for (u32 b = a + 1; b < hi; b++) {
-                    if (vals[b] != tag) continue;
+                    if (vals[b] != tag || idxs[b] >= 0xFF00u) continue;
                     u32 const sb = posOf(idxs[b]), vb = sq_grd32(base + sb);
                     if (va == vb && reaches(sa < sb ? sa : sb, sa > sb ? sa : sb)) note(sa > sb ? sa : sb, v0, v1);
                 }
             }
         }
         settle(v0, v1);
+        if (wv_ballot(wbad) && lane == 0) __hip_atomic_fetch_or(&sh[FW_SH_FLAGS], 8u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     }
     fw_sync();
     certEnd = sh[FW_SH_CERT0];
@@ -1387,6 +1407,61 @@ SQ_DEV void cert_lds_core(CertCtx& cx, FastLds* L, u8* rawOut) {
 //     data that is what makes the certificate hold at all (a 2 MiB chunk has ~6 four-byte coincidences at searched
 //     positions, 0.03 five-byte ones).  Blocks: 128 KiB each while every block so far was emitted raw -- libzstd's
 //     pre-block splitter only acts once `savings >= 3`, and a raw block contributes -3 (ZSTD_optimalBlockSize).
+// The second pass (see fastpath_blocks, "one short match") as a function of its own: its copy of the scan gets registers and
+// spill slots of its own instead of taking them from the first pass's loops, which are at the limit of both (inlined, its 70
+// extra scalar spills cost the kernel a fourth spill register and the first pass's tightest round its last free one).
+// Returns 1 when the tail certificate holds.  Every wave of the workgroup calls it with the same arguments.
+SQ_DEV u32 tail_pass_body(const u8* base, const u32* schedTab, FastLds* L, u32 anc, u32 nEntries, u32 repOff, u32 blkEnd, u32 tail,
+                          u32 wakeLim, u32 wakeSkip, u32 wakeHashByte, u32 hashLog, u32 eLog, u32 dbg) {
+    CertCtx cx;
+    cx.base = base;
+    cx.E = nullptr;
+    cx.eLog = eLog;
+    cx.genBits = 0;
+    cx.schedTab = schedTab;
+    cx.base0Pos = anc;
+    cx.tab0 = 3;
+    cx.tail = tail;
+    cx.hashBits = 0;
+    cx.certCnt0 = cx.nCert = nEntries; // (no second block)
+    cx.base1Pos = blkEnd;
+    cx.tabOff1 = 0;
+    cx.repOff = repOff;
+    cx.chunkEndPos = blkEnd;
+    cx.bloom = nullptr;
+    cx.cand = nullptr;
+    cx.ovf = nullptr;
+    cx.lvl = nullptr;
+    cx.certEnd = cx.certEnd1 = 0;
+    cx.nOvf = 0;
+    cx.hashPool = nullptr;
+    cx.hashedFlag = nullptr;
+    cx.hashDone = 0;
+    cx.dbg = dbg;
+    cx.wakeLim = wakeLim;
+    cx.wakeSkip = wakeSkip;
+    cx.wakeHash = wakeHashByte & 0xFFFFFFu;
+    cx.wakeByte = wakeHashByte >> 24;
+    cx.wakeHashLog = hashLog;
+    cx.wakeBad = 0;
+    cert_lds_core<true>(cx, L, nullptr);
+#if !SQ_ON_DEVICE && defined(SQ_SIM_TRACE)
+    fprintf(stderr, "[one match] second pass: certEnd %u ilim %u wakeBad %u nOvf %u anchor %u n %u\n", cx.certEnd, blkEnd - tail, cx.wakeBad, cx.nOvf, cx.base0Pos, cx.nCert);
+#endif
+    return (cx.certEnd >= blkEnd - tail && !cx.wakeBad && cx.nOvf == 0) ? 1u : 0u;
+}
+#if SQ_ON_DEVICE
+__device__ __noinline__ u32 tail_pass(const u8* base, const u32* schedTab, FastLds* L, u32 anc, u32 nEntries, u32 repOff, u32 blkEnd,
+                                      u32 tail, u32 wakeLim, u32 wakeSkip, u32 wakeHashByte, u32 hashLog, u32 eLog, u32 dbg) {
+    // (a function's arguments arrive in vector registers: back into scalar ones, where the scan's address arithmetic wants them)
+    return tail_pass_body((const u8*)wv_uni64((u64)(size_t)base), (const u32*)wv_uni64((u64)(size_t)schedTab), (FastLds*)wv_uni64((u64)(size_t)L),
+                          wv_uni(anc), wv_uni(nEntries), wv_uni(repOff), wv_uni(blkEnd), wv_uni(tail), wv_uni(wakeLim), wv_uni(wakeSkip),
+                          wv_uni(wakeHashByte), wv_uni(hashLog), wv_uni(eLog), wv_uni(dbg));
+}
+#else
+#define tail_pass tail_pass_body
+#endif
+
 #if !SQ_ON_DEVICE && defined(SQ_SIM_TRACE) // (tools/one_match_stats.py: why the second pass was not tried / did not hold)
 #define SQ_OM_BREAK { fprintf(stderr, "[one match] refused at line %d\n", __LINE__); break; }
 #else
@@ -1436,38 +1511,24 @@ SQ_DEV u32 fastpath_blocks(const u8* src, u32 n, u8* dst, u32 cap, u32 bA, const
     cx.hashedFlag = hashedFlag;
     cx.hashDone = 0;
     cx.wakeLim = cx.wakeSkip = cx.wakeHash = cx.wakeByte = cx.wakeBad = 0;
-    cx.wakeHashLog = cp.hashLog;
+    cx.wakeHashLog = 0;
     if (cx.nCert == 0 || cx.nCert > SQZ_FAST_VALS || lenA < 9) return 0;
     cx.dbg = dbg;
     u32 const nB = lenB ? 2u : 1u;
     bool const sized = lenA >= SQZ_FAST_MIN_BLOCK && (lenB == 0 || lenB >= SQZ_FAST_MIN_BLOCK);
     u32 const hdr = 5 + (n < 256 ? 1u : (n < 65536 + 256 ? 2u : 4u)); // = fast_frame_header()
     bool const room = cap >= n + hdr + 3 * nBlocksAll;
-    // ONE call site of the scan, in a loop of at most two turns (the scan is three instantiations of a long loop: a second
-    // copy of it no longer fits the instruction cache).  Turn 1: the certificate of the two blocks.  Turn 2 (chunks of the
-    // btlazy2 class, 16-byte aligned): see "one short match" below.
-    // What outlives the second turn is kept in LDS (L->keep: 0 / 1 the first pass's certificate ends, 2 its rawEnd, 3 the
+    // Two call sites of the scan: the first pass (its three instantiations: a second copy of THOSE no longer fits the
+    // instruction cache) and the second pass of a chunk of the btlazy2 class, 16-byte aligned, that "one short match" below
+    // keeps from being certified (cert_lds_core<true>: one instantiation of the aligned scan, run for ~7 % of random chunks).
+    // What outlives the second pass is kept in LDS (L->keep: 0 / 1 the first pass's certificate ends, 2 its rawEnd, 3 the
     // block that ends up with ONE sequence (2: none), 4 / 5 the bytes its match covers, 6 the verdict), not in registers: the
     // scan is at its limit of 128 vector registers.
     SQ_L u32* const keep = (SQ_L u32*)L->keep;
-#if SQ_ON_DEVICE
-#pragma clang loop unroll(disable)
-#endif
-    for (;;) {
-        bool const second = cx.tab0 == 3;
-        cert_lds_core(cx, L, (!second && sized && room && !(dbg & 4)) ? dst + hdr : nullptr);
-        if (second) { // the tail certificate's answer
-            u32 const ilimPos = cx.chunkEndPos - tail;
-            bool const holds = cx.certEnd >= ilimPos && !cx.wakeBad && cx.nOvf == 0;
-#if !SQ_ON_DEVICE && defined(SQ_SIM_TRACE)
-            fprintf(stderr, "[one match] second pass: certEnd %u ilim %u wakeBad %u nOvf %u anchor %u n %u\n", cx.certEnd, ilimPos, cx.wakeBad, cx.nOvf, cx.base0Pos, cx.nCert);
-#endif
-            if (fw_first()) {
-                keep[6] = holds ? 1u : 0u;
-                if (!holds) keep[3] = 2;
-            }
-            break;
-        }
+    cert_lds_core<false>(cx, L, (sized && room && !(dbg & 4)) ? dst + hdr : nullptr);
+    bool again = false;
+    u32 tpAnc = 0, tpN = 0, tpOff = 0, tpEnd = 0, tpLim = 0, tpSkip = 0, tpHB = 0; // the second pass's arguments
+    do {
         u32 const ce0 = cx.certEnd, ce1 = cx.certEnd1;
         // every search of the two blocks certainly fails?
         bool const fail0 = ce0 < cx.base0Pos + lenA - tail, fail1 = lenB && ce1 < cx.base1Pos + lenB - tail;
@@ -1538,22 +1599,28 @@ SQ_DEV u32 fastpath_blocks(const u8* src, u32 n, u8* dst, u32 cap, u32 bA, const
             // block and of what lies in front of it scanned; the bucket check for s*
             u32 const nLater = gld32(schedTab + 1);
             u32 const j1 = anc < ilimPos ? sched_count(schedTab + 2 + SQZ_SCHEDTAB_N, nLater, ilimPos - anc) : 0u;
-            cx.base0Pos = anc;
-            cx.tab0 = 3;
-            cx.certCnt0 = cx.nCert = j1 + 2; // (no second block)
-            cx.repOff = off;
-            cx.chunkEndPos = blkEnd;
-            cx.wakeLim = sS;
-            cx.wakeSkip = q;
-            cx.wakeHash = hash4(vS, cp.hashLog);
-            cx.wakeByte = vS & 0xFFu;
+            tpAnc = anc;
+            tpN = j1 + 2;
+            tpOff = off;
+            tpEnd = blkEnd;
+            tpLim = sS;
+            tpSkip = q;
+            tpHB = hash4(vS, cp.hashLog) | ((vS & 0xFFu) << 24);
             if (fw_first()) {
                 keep[3] = b;
                 keep[4] = start - blk;
                 keep[5] = anc - blk;
             }
         }
+        again = true;
+    } while (false);
+    if (again) {
         fw_sync(); // (the shared words and the list of hits are written again by the second pass)
+        bool const holds = tail_pass(cx.base, schedTab, L, tpAnc, tpN, tpOff, tpEnd, tail, tpLim, tpSkip, tpHB, cp.hashLog, cx.eLog, dbg) != 0;
+        if (fw_first()) {
+            keep[6] = holds ? 1u : 0u;
+            if (!holds) keep[3] = 2;
+        }
     }
     fw_sync();
     cx.certEnd = wv_uni(keep[0]); // what stage 2 is told is the first pass's answer

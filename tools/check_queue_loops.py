@@ -17,7 +17,11 @@ SGPR state from a vector register it saved with all lanes enabled.  This script 
                              leaves fast_sched_mask_rare / sched_count, which (5) have no call and no scratch access (no stack frame, no spill
                              of its own) and does not touch the vector registers that hold the kernel's spilled scalars, so
                              nothing of the queue loop's state passes through memory or through a callee's epilogue; (6) the
-                             queue's atomic is inside the lane-election s_and_saveexec / s_or_b64 exec pair(s) only.
+                             queue's atomic is inside the lane-election s_and_saveexec / s_or_b64 exec pair(s) only; (7) the
+                             second pass of a job (tail_pass, round 4) is the ONE call that is not a leaf: an ordinary function
+                             with a frame of its own (as compress_one is for the other kernel: its prologue / epilogue save and
+                             restore what it uses, EXEC is all ones at the call), which must not call anything itself and must
+                             not touch the registers that hold the kernel's spilled scalars.
 usage: python tools/check_queue_loops.py [extra hipcc flags]   (exit code 1 and a list of findings on failure)"""
 import os
 import re
@@ -132,9 +136,12 @@ def main():
     _, fb = body_of(lines, "_ZN3sqz22k_incompressible_batch")
     fcalls = call_targets(fb)
     LEAVES = ("fast_sched_mask_rare", "sched_count")
-    bad = [c[1] for c in fcalls if not c[1] or not any(x in c[1] for x in LEAVES)]
+    FRAMED = ("tail_pass",)
+    bad = [c[1] for c in fcalls if not c[1] or not any(x in c[1] for x in LEAVES + FRAMED)]
     if bad:
-        findings.append(f"k_incompressible_batch: calls other than the leaves {LEAVES} inside the persistent loop: {bad}")
+        findings.append(f"k_incompressible_batch: calls other than the leaves {LEAVES} and {FRAMED} inside the persistent loop: {bad}")
+    if sum(1 for c in fcalls if c[1] and "tail_pass" in c[1]) > 1:
+        findings.append("k_incompressible_batch: more than one call site of tail_pass")
     atomic_region_ok(fb, findings, "k_incompressible_batch")
     wl = re.findall(r"v_writelane_b32 (v\d+),", "\n".join(fb))
     spill_vgprs = {v for v in set(wl) if wl.count(v) >= 8}   # the registers hipcc spills scalars into (a lone v_writelane is ordinary code)
@@ -151,6 +158,19 @@ def main():
             for v in spill_vgprs:
                 if re.search(r"\b%s\b" % v, t.split(";")[0]):
                     findings.append(f"{leaf}: touches {v}, which holds spilled scalars of k_incompressible_batch: " + t)
+    try:
+        _, tb = body_of(lines, "_ZN3sqz9tail_pass")
+        for t in instrs(tb):
+            if t.startswith("s_swappc"):
+                findings.append("tail_pass: calls another function: " + t)
+            for v in spill_vgprs:
+                if re.search(r"\b%s\b" % v, t.split(";")[0]):
+                    findings.append(f"tail_pass: touches {v}, which holds spilled scalars of k_incompressible_batch: " + t)
+        if not any(t.startswith("s_setpc_b64 s[30:31]") for t in instrs(tb)):
+            findings.append("tail_pass: no ordinary return found")
+    except StopIteration:
+        if any(c[1] and "tail_pass" in c[1] for c in fcalls):
+            findings.append("k_incompressible_batch calls tail_pass, which this check cannot find")
     print(f"k_compress_batch: {n} instructions, calls {[c[1][:40] for c in calls if c[1]]}; "
           f"k_incompressible_batch: {len(fcalls)} call(s) to the leaf, spill registers {sorted(spill_vgprs)}; {len(findings)} finding(s)")
     for f in findings:
