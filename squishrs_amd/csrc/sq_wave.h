@@ -168,17 +168,43 @@ SQ_DEV void gld_pair(const u32* p, u32* a, u32* b) {
 #endif
 }
 
+// One step of a binary-tree walk: the node's two child words (p, 8-byte aligned) AND the first eight bytes of the two strings
+// it compares, issued together -- one trip to memory per step instead of two (the child words used to be waited for before
+// the bytes were even asked for: profiles/round4f_tree_step_loads.txt).  have8: the strings have eight bytes left.
+SQ_DEV void wv_tree_step_loads(const u32* p, const u8* a, const u8* b, bool have8, u32* c0, u32* c1, u64* wa, u64* wb) {
+#if SQ_ON_DEVICE
+    u64 const v = __hip_atomic_load((const SQ_G u64*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    u64 x = 0, y = 0;
+    if (have8) {
+        x = sq_grd64(a);
+        y = sq_grd64(b);
+    }
+    // (all three are in flight before the first of them is read back)
+    asm volatile("" : "+v"(x), "+v"(y));
+    *c0 = wv_uni((u32)v);
+    *c1 = wv_uni((u32)(v >> 32));
+    *wa = wv_uni64(x);
+    *wb = wv_uni64(y);
+#else
+    *c0 = p[0];
+    *c1 = p[1];
+    *wa = *wb = 0;
+    (void)a; (void)b; (void)have8;
+#endif
+}
+
 // wv_count plus the ordering of the first differing byte: *bLess = (b[len] < a[len]) when
 // len < maxLen (undefined otherwise).  Saves the separate byte-compare round trip of the tree walks.
-SQ_DEV u32 wv_count_cmp(const u8* a, const u8* b, u32 maxLen, u32* bLess) {
+// (pre: the strings' first eight bytes are in wa0 / wb0 already -- wv_tree_step_loads -- when maxLen >= 8)
+SQ_DEV u32 wv_count_cmp(const u8* a, const u8* b, u32 maxLen, u32* bLess, bool pre = false, u64 wa0 = 0, u64 wb0 = 0) {
 #if SQ_ON_DEVICE
     const u32 lane = wv_lane();
     if (maxLen >= 8) {
-        u64 const wa = srd64(a), wb = srd64(b);
+        u64 const wa = pre ? wa0 : srd64(a), wb = pre ? wb0 : srd64(b);
         u64 const x = wa ^ wb;
         if (x) {
             u32 const k = (u32)(__builtin_ctzll(x) >> 3);
-            *bLess = ((wb >> (8 * k)) & 0xFF) < ((wa >> (8 * k)) & 0xFF);
+            *bLess = (u32)((wb >> (8 * k)) & 0xFF) < (u32)((wa >> (8 * k)) & 0xFF); // (32-bit: a scalar compare)
             return k;
         }
     }
@@ -207,7 +233,7 @@ SQ_DEV u32 wv_count_cmp(const u8* a, const u8* b, u32 maxLen, u32* bLess) {
             u32 r = base + first * 8 + k;
             if (r >= maxLen) return maxLen;
             const u64 av = wv_readlane64(wa, first), bv = wv_readlane64(wb, first);
-            *bLess = ((bv >> (8 * k)) & 0xFF) < ((av >> (8 * k)) & 0xFF);
+            *bLess = (u32)((bv >> (8 * k)) & 0xFF) < (u32)((av >> (8 * k)) & 0xFF);
             return r;
         }
     }

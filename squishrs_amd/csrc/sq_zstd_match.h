@@ -1560,16 +1560,33 @@ SQ_DEVFN void dubt_update(MatchState& ms, u32 target) {
 
 // ZSTD_insertDUBT1 (noDict).  Per tree step ONE memory round trip: the node's two children are
 // fetched with one 8-byte load issued together with the match-extension loads.
-SQ_DEVFN void dubt_insert1(MatchState& ms, u32 curr, const u8* inputEnd, u32 nbCompares, u32 btLow) {
-    u32* const bt = ms.chainTable;
-    u32 const btMask = (1u << (ms.cp.chainLog - 1)) - 1;
+// (Everything the walk reads from the finder's state is copied into wave-uniform locals first: the state lives in the
+// caller's frame, and what hipcc loads from a frame it treats as different in every lane -- vector registers, exec-masked
+// regions and 64-bit vector address arithmetic for a walk that is the same in all 64 lanes.  Node slots are indices into the
+// tree table, not pointers; SQZ_BT_DUMMY stands for ms.dummy.  SQ counters of 256 KiB text chunks before this: 65 VALU + 69
+// SALU instructions per tree step, 30 % of a wave's time spent issuing, profiles/round4f_text256k_sq_counters.txt.)
+#define SQZ_BT_DUMMY 0xFFFFFFFFu
+// have: what the slot is known to hold (the child word the walk loaded when it passed the slot's node; SQZ_BT_UNKNOWN for the
+// new root's own two slots).  A walk that keeps to one side writes every child word back unchanged -- half of a walk's stores,
+// each a dirty 64-byte line of a 2 MiB table that the L2 then has to write out (1.15 writes to HBM per tree step measured,
+// profiles/round4f_text256k_mem_counters.txt): those are skipped.
+#define SQZ_BT_UNKNOWN 0xFFFFFFFEu
+SQ_DEV void bt_store(u32* bt, u32* dummy, u32 slot, u32 v, u32 have = SQZ_BT_UNKNOWN) {
+    if (have != v) gst32(slot == SQZ_BT_DUMMY ? dummy : bt + slot, v);
+}
+SQ_DEVFN void dubt_insert1(MatchState& ms, u32 curr_, const u8* inputEnd, u32 nbCompares_, u32 btLow_) {
+    u32* const bt = (u32*)wv_uni64((u64)(size_t)ms.chainTable);
+    u32* const dummy = (u32*)wv_uni64((u64)(size_t)ms.dummy);
+    u32 const btMask = (1u << (wv_uni(ms.cp.chainLog) - 1)) - 1;
+    u32 const curr = wv_uni(curr_), btLow = wv_uni(btLow_);
+    u32 nbCompares = wv_uni(nbCompares_);
     u32 commonLengthSmaller = 0, commonLengthLarger = 0;
-    const u8* const base = ms.base;
+    const u8* const base = (const u8*)wv_uni64((u64)(size_t)ms.base);
     const u8* const ip = base + curr;
-    u32 const ipRoom = (u32)(inputEnd - ip);
-    u32* smallerPtr = bt + 2 * (curr & btMask);
-    u32* largerPtr = smallerPtr + 1;
-    u32 matchIndex = gld32(smallerPtr);
+    u32 const ipRoom = wv_uni((u32)(inputEnd - ip));
+    u32 smallerSlot = 2 * (curr & btMask), largerSlot = smallerSlot + 1;
+    u32 smallerHas = SQZ_BT_UNKNOWN, largerHas = SQZ_BT_UNKNOWN; // what those slots are known to hold (bt_store)
+    u32 matchIndex = gld32(bt + smallerSlot);
     u32 const windowLow = SQZ_WINDOW_START; // window always covers the whole chunk (see get_cparams)
     for (; nbCompares && (matchIndex > windowLow); --nbCompares) {
         if (matchIndex >= curr) {
@@ -1578,93 +1595,101 @@ SQ_DEVFN void dubt_insert1(MatchState& ms, u32 curr, const u8* inputEnd, u32 nbC
             SQ_TRACE(17, matchIndex);
             SQ_TRACE(18, curr);
             SQ_TRACE(19, nbCompares);
-            SQ_TRACE(20, (u32)(smallerPtr - bt));
-            SQ_TRACE(21, (u32)(largerPtr - bt));
+            SQ_TRACE(20, smallerSlot);
+            SQ_TRACE(21, largerSlot);
             break;
         }
-        u32* const nextPtr = bt + 2 * (matchIndex & btMask);
+        u32 const nextSlot = 2 * (matchIndex & btMask);
         u32 child0, child1, mLess = 0;
-        gld_pair(nextPtr, &child0, &child1);
         u32 matchLength = commonLengthSmaller < commonLengthLarger ? commonLengthSmaller : commonLengthLarger;
         const u8* const match = base + matchIndex;
-        matchLength += wv_count_cmp(ip + matchLength, match + matchLength, ipRoom - matchLength, &mLess);
+        u64 wa8, wb8;
+        wv_tree_step_loads(bt + nextSlot, ip + matchLength, match + matchLength, ipRoom - matchLength >= 8, &child0, &child1, &wa8, &wb8);
+        matchLength += wv_count_cmp(ip + matchLength, match + matchLength, ipRoom - matchLength, &mLess, SQ_ON_DEVICE != 0, wa8, wb8);
+        matchLength = wv_uni(matchLength);
+        mLess = wv_uni(mLess);
         if (matchLength == ipRoom) break;
         if (mLess) {
-            gst32(smallerPtr, matchIndex);
+            bt_store(bt, dummy, smallerSlot, matchIndex, smallerHas);
             commonLengthSmaller = matchLength;
             if (matchIndex <= btLow) {
-                smallerPtr = ms.dummy;
+                smallerSlot = SQZ_BT_DUMMY;
+                smallerHas = SQZ_BT_UNKNOWN;
                 break;
             }
-            smallerPtr = nextPtr + 1;
+            smallerSlot = nextSlot + 1;
+            smallerHas = child1;
             matchIndex = child1;
         } else {
-            gst32(largerPtr, matchIndex);
+            bt_store(bt, dummy, largerSlot, matchIndex, largerHas);
             commonLengthLarger = matchLength;
             if (matchIndex <= btLow) {
-                largerPtr = ms.dummy;
+                largerSlot = SQZ_BT_DUMMY;
+                largerHas = SQZ_BT_UNKNOWN;
                 break;
             }
-            largerPtr = nextPtr;
+            largerSlot = nextSlot;
+            largerHas = child0;
             matchIndex = child0;
         }
     }
-    gst32(smallerPtr, 0);
-    gst32(largerPtr, 0);
+    bt_store(bt, dummy, smallerSlot, 0, smallerHas);
+    bt_store(bt, dummy, largerSlot, 0, largerHas);
     wv_mem_sync();
 }
 
 // Body of ZSTD_DUBT_findBestMatch (noDict, mls 4) for the position `curr`, given the bucket head
 // as it was when `curr` was reached: sorts the unsorted candidates, walks the tree, makes `curr`
 // the root.  Does not touch the hash table.
-SQ_DEVFN u32 dubt_search_core(MatchState& ms, u32 curr, const u8* const iend, u32 const headIndex, u32* offBasePtr,
+SQ_DEVFN u32 dubt_search_core(MatchState& ms, u32 curr_, const u8* const iend, u32 const headIndex_, u32* offBasePtr,
                               u32* matchEndIdxOut) {
-    const u8* const base = ms.base;
+    // (wave-uniform copies of what the walk reads from the finder's state: see dubt_insert1)
+    const u8* const base = (const u8*)wv_uni64((u64)(size_t)ms.base);
+    u32 const curr = wv_uni(curr_), headIndex = wv_uni(headIndex_);
     const u8* const ip = base + curr;
     u32 matchIndex = headIndex;
     u32 const windowLow = SQZ_WINDOW_START;
-    u32* const bt = ms.chainTable;
-    u32 const btMask = (1u << (ms.cp.chainLog - 1)) - 1;
+    u32* const bt = (u32*)wv_uni64((u64)(size_t)ms.chainTable);
+    u32* const dummy = (u32*)wv_uni64((u64)(size_t)ms.dummy);
+    u32 const btMask = (1u << (wv_uni(ms.cp.chainLog) - 1)) - 1;
     u32 const btLow = (btMask >= curr) ? 0 : curr - btMask;
     u32 const unsortLimit = btLow > windowLow ? btLow : windowLow;
-    u32* nextCandidate = bt + 2 * (matchIndex & btMask);
-    u32* unsortedMark = bt + 2 * (matchIndex & btMask) + 1;
-    u32 nbCompares = 1U << ms.cp.searchLog;
+    u32 candSlot = 2 * (matchIndex & btMask); // (next candidate, sort mark) of the visited candidate
+    u32 nbCompares = 1U << wv_uni(ms.cp.searchLog);
     u32 nbCandidates = nbCompares;
     u32 previousCandidate = 0;
-    u32 const ipRoom = (u32)(iend - ip);
+    u32 const ipRoom = wv_uni((u32)(iend - ip));
     {
         // one 8-byte load per visited candidate: (next candidate, sort mark)
         u32 nextC = 0, mark = 0;
-        if (matchIndex > unsortLimit) gld_pair(nextCandidate, &nextC, &mark);
+        if (matchIndex > unsortLimit) gld_pair(bt + candSlot, &nextC, &mark);
         while ((matchIndex > unsortLimit) && (mark == SQZ_DUBT_UNSORTED) && (nbCandidates > 1)) {
-            gst32(unsortedMark, previousCandidate);
+            gst32(bt + candSlot + 1, previousCandidate);
             previousCandidate = matchIndex;
             matchIndex = nextC;
-            nextCandidate = bt + 2 * (matchIndex & btMask);
-            unsortedMark = bt + 2 * (matchIndex & btMask) + 1;
+            candSlot = 2 * (matchIndex & btMask);
             nbCandidates--;
-            if (matchIndex > unsortLimit) gld_pair(nextCandidate, &nextC, &mark);
+            if (matchIndex > unsortLimit) gld_pair(bt + candSlot, &nextC, &mark);
         }
         if ((matchIndex > unsortLimit) && (mark == SQZ_DUBT_UNSORTED)) {
-            gst32(nextCandidate, 0);
-            gst32(unsortedMark, 0);
+            gst32(bt + candSlot, 0);
+            gst32(bt + candSlot + 1, 0);
         }
     }
     wv_mem_sync();
     matchIndex = previousCandidate;
     while (matchIndex) {
-        u32* const nextCandidateIdxPtr = bt + 2 * (matchIndex & btMask) + 1;
-        u32 const nextCandidateIdx = gld32(nextCandidateIdxPtr);
+        u32 const nextCandidateIdx = gld32(bt + 2 * (matchIndex & btMask) + 1);
         dubt_insert1(ms, matchIndex, iend, nbCandidates, unsortLimit);
         matchIndex = nextCandidateIdx;
         nbCandidates++;
     }
     u32 commonLengthSmaller = 0, commonLengthLarger = 0;
-    u32* smallerPtr = bt + 2 * (curr & btMask);
-    u32* largerPtr = bt + 2 * (curr & btMask) + 1;
+    u32 smallerSlot = 2 * (curr & btMask), largerSlot = smallerSlot + 1;
+    u32 smallerHas = SQZ_BT_UNKNOWN, largerHas = SQZ_BT_UNKNOWN; // what those slots are known to hold (bt_store)
     u32 matchEndIdx = curr + 8 + 1;
     u32 bestLength = 0;
+    u32 offBase = wv_uni(*offBasePtr);
     matchIndex = headIndex;
     for (; nbCompares && (matchIndex > windowLow); --nbCompares) {
         if (matchIndex >= curr) {
@@ -1676,44 +1701,52 @@ SQ_DEVFN u32 dubt_search_core(MatchState& ms, u32 curr, const u8* const iend, u3
             SQ_TRACE(20, headIndex);
             break;
         }
-        u32* const nextPtr = bt + 2 * (matchIndex & btMask);
+        u32 const nextSlot = 2 * (matchIndex & btMask);
         u32 child0, child1, mLess = 0;
-        gld_pair(nextPtr, &child0, &child1);
         u32 matchLength = commonLengthSmaller < commonLengthLarger ? commonLengthSmaller : commonLengthLarger;
         const u8* const match = base + matchIndex;
-        matchLength += wv_count_cmp(ip + matchLength, match + matchLength, ipRoom - matchLength, &mLess);
+        u64 wa8, wb8;
+        wv_tree_step_loads(bt + nextSlot, ip + matchLength, match + matchLength, ipRoom - matchLength >= 8, &child0, &child1, &wa8, &wb8);
+        matchLength += wv_count_cmp(ip + matchLength, match + matchLength, ipRoom - matchLength, &mLess, SQ_ON_DEVICE != 0, wa8, wb8);
+        matchLength = wv_uni(matchLength);
+        mLess = wv_uni(mLess);
         if (matchLength > bestLength) {
             if (matchLength > matchEndIdx - matchIndex) matchEndIdx = matchIndex + matchLength;
             if ((4 * (int)(matchLength - bestLength)) >
-                (int)(sq_highbit32(curr - matchIndex + 1) - sq_highbit32(*offBasePtr))) {
+                (int)(sq_highbit32(curr - matchIndex + 1) - sq_highbit32(offBase))) {
                 bestLength = matchLength;
-                *offBasePtr = OFFSET_TO_OFFBASE(curr - matchIndex);
+                offBase = OFFSET_TO_OFFBASE(curr - matchIndex);
             }
             if (matchLength == ipRoom) break;
         }
         if (mLess) {
-            gst32(smallerPtr, matchIndex);
+            bt_store(bt, dummy, smallerSlot, matchIndex, smallerHas);
             commonLengthSmaller = matchLength;
             if (matchIndex <= btLow) {
-                smallerPtr = ms.dummy;
+                smallerSlot = SQZ_BT_DUMMY;
+                smallerHas = SQZ_BT_UNKNOWN;
                 break;
             }
-            smallerPtr = nextPtr + 1;
+            smallerSlot = nextSlot + 1;
+            smallerHas = child1;
             matchIndex = child1;
         } else {
-            gst32(largerPtr, matchIndex);
+            bt_store(bt, dummy, largerSlot, matchIndex, largerHas);
             commonLengthLarger = matchLength;
             if (matchIndex <= btLow) {
-                largerPtr = ms.dummy;
+                largerSlot = SQZ_BT_DUMMY;
+                largerHas = SQZ_BT_UNKNOWN;
                 break;
             }
-            largerPtr = nextPtr;
+            largerSlot = nextSlot;
+            largerHas = child0;
             matchIndex = child0;
         }
     }
-    gst32(smallerPtr, 0);
-    gst32(largerPtr, 0);
+    bt_store(bt, dummy, smallerSlot, 0, smallerHas);
+    bt_store(bt, dummy, largerSlot, 0, largerHas);
     wv_mem_sync();
+    *offBasePtr = offBase;
     *matchEndIdxOut = matchEndIdx;
     return bestLength;
 }

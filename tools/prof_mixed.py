@@ -27,8 +27,11 @@ def one(seed):
 
 if __name__ == "__main__":
     t0 = time.time()
-    with mp.get_context("fork").Pool(min(32, len(os.sched_getaffinity(0)))) as pool:
-        chunks = pool.map(one, range(41000, 41000 + k))
+    if os.environ.get("SQ_NO_FORK"):   # under rocprofv3 --pmc the GPU is initialised before main(): no fork then
+        chunks = [one(s) for s in range(41000, 41000 + k)]
+    else:
+        with mp.get_context("fork").Pool(min(32, len(os.sched_getaffinity(0)))) as pool:
+            chunks = pool.map(one, range(41000, 41000 + k))
     print(f"generated {k} x {L} B {kind} chunks in {time.time() - t0:.1f} s", flush=True)
     import torch
     import oracle_lib
