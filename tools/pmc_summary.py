@@ -58,7 +58,7 @@ for k, ck in out["kernels"].items():
                          "write_bytes_per_chunk": ck["WRITE_SIZE"] * 1024 / n,
                          "stream_read_bytes_per_chunk": STREAM.get(k, 0),
                          "measured_on_chunks": n, "source": f"profiles/{tag}_pmc.json",
-                         "note": "per chunk of the BATCH (stage 2 handles ~7 % of them); corrected traffic = fetch + "
+                         "note": "per chunk of the BATCH (stage 2 handles the chunks stage 1 leaves undecided: 0.7 % of random ones since round 4); corrected traffic = fetch + "
                                  "stream_read/2 + write (FETCH_SIZE tallies a coalesced streaming read at half on gfx950)"}
         print(k, json.dumps(t[f"{k}@{L}"]))
 json.dump(t, open(os.path.join(ROOT, "profiles", "pmc_traffic.json"), "w"), indent=1)
