@@ -264,6 +264,11 @@ int sq_last_timings(sq_ctx* ctx, sq_timings* out);
  * entries, *n_out = entries written (0 when that stage did not run).  bench.py draws its oracle sample from it. */
 int sq_debug_stage2_list(sq_ctx* ctx, uint32_t* h_out, uint32_t cap, uint32_t* n_out);
 
+/* Test / measurement hook: *loaded = the second build of the compressor kernel (squish_s2_w3.co beside the library: 3 waves per
+ * SIMD, 11 per CU) is available; *used_last = the most recent compress stage ran it (chosen per batch: the batch before it left
+ * more than a quarter of its chunks to stage 2). */
+int sq_debug_stage2_kernel(sq_ctx* ctx, uint32_t* loaded, uint32_t* used_last);
+
 const char* sq_strerror(int err);
 uint32_t sq_abi_version(void);
 

@@ -22,7 +22,7 @@ EXPORTS = [
     "sq_calibrate_read_bw", "sq_last_timings", "sq_dedup_reset", "sq_compress_batch_slots", "sq_slots_bound",
     "sq_host_alloc", "sq_host_free", "sq_debug_stage2_list", "sq_pack_submit", "sq_pack_wait", "sq_calibrate_gather", "sq_calibrate_gather2",
     "sq_shard_submit_hash", "sq_shard_wait_hash", "sq_shard_submit_rest", "sq_shard_submit_rest_idx",
-    "sq_decompress_batch", "sq_decompress_strerror",
+    "sq_decompress_batch", "sq_decompress_strerror", "sq_debug_stage2_kernel",
 ]
 
 
@@ -99,6 +99,7 @@ def load():
     L.sq_shard_submit_rest.argtypes = [vp, u8p, ctypes.c_uint64, ctypes.c_uint64, u8p, u8p, ctypes.c_uint64, ctypes.c_uint32]
     L.sq_shard_submit_rest_idx.argtypes = [vp, u8p, ctypes.c_uint64, vp, u8p, u8p, ctypes.c_uint64, ctypes.c_uint32]
     L.sq_debug_stage2_list.argtypes = [vp, vp, ctypes.c_uint32, ctypes.POINTER(ctypes.c_uint32)]
+    L.sq_debug_stage2_kernel.argtypes = [vp, ctypes.POINTER(ctypes.c_uint32), ctypes.POINTER(ctypes.c_uint32)]
     L.sq_decompress_batch.argtypes = [vp, u8p, vp, vp, ctypes.c_uint32, u8p, vp, vp, vp, vp]
     L.sq_decompress_strerror.restype = ctypes.c_char_p
     L.sq_decompress_strerror.argtypes = [ctypes.c_uint32]

@@ -244,6 +244,13 @@ class ChunkStore:
         raw = out.raw
         return [raw[int(o):int(o) + int(l)] if s == 0 else None for o, l, s in zip(ooff, out_len, status)]
 
+    def stage2_kernel(self):
+        """(loaded, used_last): is the second build of the compressor kernel (squish_s2_w3.co) available, and did the most
+        recent compress stage run it (include/squish_gpu.h sq_debug_stage2_kernel)"""
+        a, b = ctypes.c_uint32(0), ctypes.c_uint32(0)
+        check(self._L.sq_debug_stage2_kernel(self._h, ctypes.byref(a), ctypes.byref(b)))
+        return bool(a.value), bool(b.value)
+
     def stage2_list(self, cap: int = 1 << 20) -> np.ndarray:
         """Indices of the chunks the last compress launch's first stage left to the compressor proper."""
         out = np.zeros(cap, dtype=np.uint32)

@@ -16,6 +16,8 @@
 #include <cstring>
 #include <ctime>
 #include <unistd.h>
+#include <dlfcn.h>
+#include <string>
 #include <mutex>
 #include <new>
 #include <vector>
@@ -131,6 +133,7 @@ struct sq_lane {
     size_t h_len_cap = 0;
     u32 job_max_len = 0;
     u32 job_waves = 0, job_fwaves = 0;
+    bool job_s2w3 = false; // this batch's stage 2 runs the 3-waves-per-SIMD build of the kernel (sq_ctx::f_s2w3)
     size_t job_ws_each = 0, job_etab_bytes = 0;
     bool job_fast = false, job_in_place = false, job_fused = false;
     bool job_sharded = false; // enqueued through sq_shard_submit_rest[_idx] (sq_pack_wait: no duplicate-ratio note)
@@ -167,6 +170,14 @@ struct sq_ctx {
     u32 submitted = 0, collected = 0; // sq_pack_submit / sq_pack_wait tickets (submitted - collected <= 2)
     float dup_ratio_last = 0.f;       // duplicates / chunks of the batch collected last (chooses the fused form)
     bool shard_pending = false;       // sq_shard_submit_hash called, sq_shard_submit_rest not yet
+    // k_compress_batch exists twice: in this library at 2 waves per SIMD (256 registers, 8 waves per CU) and in the code
+    // object squish_s2_w3.co beside it at 3 (168 registers, 11 per CU; same source, SQZ_STAGE2_WAVES_PER_SIMD=3).  Compressible
+    // batches run 5-13 % faster on the second (more chains of dependent trips in flight); batches that stage 1 mostly decides
+    // run 5 % SLOWER with it (its spills take bandwidth from stage 1's stream: profiles/round4f_stage2_register_bound_ab.txt).
+    // s2_dense: the batch collected last left more than a quarter of its new chunks to stage 2.
+    hipModule_t mod_s2w3 = nullptr;
+    hipFunction_t f_s2w3 = nullptr;
+    bool s2_dense = false, s2_w3_last = false;
 };
 
 static bool is_device_ptr(const void* p) {
@@ -281,6 +292,22 @@ int sq_ctx_create(const sq_config* cfg_in, sq_ctx** out) {
         }
     }
 #endif
+#ifndef SQ_NO_COMPRESS
+    if (!getenv("SQ_NO_S2_W3")) { // the second build of the compressor kernel (optional: without it every batch takes the first)
+        Dl_info di;
+        if (dladdr((const void*)&sq_ctx_create, &di) && di.dli_fname) {
+            std::string path(di.dli_fname);
+            size_t const slash = path.find_last_of('/');
+            path = (slash == std::string::npos ? std::string(".") : path.substr(0, slash)) + "/squish_s2_w3.co";
+            if (hipModuleLoad(&c->mod_s2w3, path.c_str()) == hipSuccess) {
+                if (hipModuleGetFunction(&c->f_s2w3, c->mod_s2w3, SQZ_K_COMPRESS_BATCH_SYMBOL) != hipSuccess) c->f_s2w3 = nullptr;
+            } else
+                c->mod_s2w3 = nullptr;
+            (void)hipGetLastError();
+            if (!c->f_s2w3 && g_env.debug) fprintf(stderr, "[squish_gpu] %s not loaded: compressible batches use the 8-waves-per-CU kernel\n", path.c_str());
+        }
+    }
+#endif
     *out = c;
     return SQ_OK;
 }
@@ -311,6 +338,7 @@ void sq_ctx_destroy(sq_ctx* c) {
     if (c->d_keys) (void)hipFree(c->d_keys);
     if (c->d_unique) (void)hipFree(c->d_unique);
     if (c->d_sched_tab) (void)hipFree(c->d_sched_tab);
+    if (c->mod_s2w3) (void)hipModuleUnload(c->mod_s2w3);
     delete c;
 }
 
@@ -554,13 +582,19 @@ static int compress_prepare(sq_ctx* c, sq_lane* L, const u32* h_len, u32 n, u8* 
     L->job_slots = in_place ? d_comp : (u8*)L->b_slots.p;
 
     // persistent compressor waves, one private workspace each
-    u32 waves = c->cfg.compress_waves ? c->cfg.compress_waves : (u32)c->num_cu * 8;
+    bool const w3 = c->f_s2w3 != nullptr && c->s2_dense && !c->cfg.compress_waves && !g_env.stage2_waves_per_cu;
+    L->job_s2w3 = w3;
+    u32 waves = c->cfg.compress_waves ? c->cfg.compress_waves : (u32)c->num_cu * (w3 ? SQZ_STAGE2_WAVES_PER_CU : 8u);
     if (g_env.stage2_waves_per_cu >= 1 && g_env.stage2_waves_per_cu <= 8 && !c->cfg.compress_waves) // experiment: leave wave slots to the other lane's kernels
         waves = (u32)c->num_cu * (u32)g_env.stage2_waves_per_cu;
     waves = std::min(waves, n);
     const size_t ws_each = sqz::workspace_bytes(max_len);
-    // keep the workspace pool within ~96 GiB
-    while (waves > 64 && (u64)waves * ws_each > (96ull << 30)) waves /= 2;
+    // The pool is sized for the larger of the two builds' grids, so that a change of build between batches does not
+    // reallocate it (12 GB and more); keep it within ~96 GiB
+    u32 pool_waves = (c->f_s2w3 != nullptr && !c->cfg.compress_waves && !g_env.stage2_waves_per_cu)
+                         ? std::min((u32)c->num_cu * SQZ_STAGE2_WAVES_PER_CU, n) : waves;
+    while (pool_waves > 64 && (u64)pool_waves * ws_each > (96ull << 30)) pool_waves /= 2;
+    waves = std::min(waves, pool_waves);
     // Stage 1, the incompressible-chunk kernel (sq_zstd_fast.h): as many workgroups as fit (its state is all
     // in LDS).  It only applies to chunks of 16 KiB < len <= 256 KiB.
     const bool fast = max_len > (16u << 10) && !g_env.no_fastpath;
@@ -595,7 +629,7 @@ static int compress_prepare(sq_ctx* c, sq_lane* L, const u32* h_len, u32 n, u8* 
             if ((r = L->b_hpool.ensure((size_t)n * SQZ_FAST_HPOOL_BYTES))) return r;
         }
     }
-    if ((r = L->b_ws.ensure((size_t)waves * ws_each + 256))) return r;
+    if ((r = L->b_ws.ensure((size_t)pool_waves * ws_each + 256))) return r;
     if (fast && (r = L->b_etab.ensure((size_t)fwaves * (etab_bytes + 256)))) return r;
     if ((r = L->b_misc.ensure(256))) return r;
     if (in_place && L->h_len_cap < (size_t)n * 4) {
@@ -610,7 +644,8 @@ static int compress_prepare(sq_ctx* c, sq_lane* L, const u32* h_len, u32 n, u8* 
         L->h_len_cap = want;
     }
     // the pools keep their generation tags from launch to launch as long as nothing about them changes
-    L->job_ws_persist = (L->b_ws.p == L->ws_ptr_last && ws_each == L->ws_each_last && waves == L->ws_waves_last && fast) ? 1u : 0u;
+    // (the saved table states of slots [0, ws_waves_last) are good: a launch of at most that many waves continues from them)
+    L->job_ws_persist = (L->b_ws.p == L->ws_ptr_last && ws_each == L->ws_each_last && waves <= L->ws_waves_last && fast) ? 1u : 0u;
     L->job_etab_persist = (fast && L->b_etab.p == L->etab_ptr_last && etab_bytes == L->etab_bytes_last && fwaves == L->etab_waves_last) ? 1u : 0u;
     L->ws_ptr_last = nullptr; // becomes valid again when this launch has completed
     L->etab_ptr_last = nullptr;
@@ -687,14 +722,30 @@ static int compress_stage2(sq_ctx* c, sq_lane* L, const u8* d_data, const u8* d_
     HIPCHK(hipEventRecord(L->ev[4], L->stream));
     {
         dim3 block(64), grid(L->job_waves);
-        hipLaunchKernelGGL(sqz::k_compress_batch, grid, block, 0, L->stream, d_data, (const u64*)L->b_off.p,
-                           (const u32*)L->b_len.p, d_take, n, L->job_slots,
-                           (const u64*)L->b_slot_off.p, (u32*)L->b_frame_len.p, (u8*)L->b_ws.p,
-                           (u64)L->job_ws_each, (u32*)L->b_misc.p /*queue*/, (u32*)L->b_misc.p + 16 /*err*/,
-                           (const u32*)c->d_sched_tab, fast ? (const u32*)L->b_cert.p : (const u32*)nullptr, L->job_ws_persist,
-                           fast ? (const u32*)L->b_work.p : (const u32*)nullptr,
-                           (fast && !L->job_list.empty()) ? (const u32*)L->b_pair.p : (const u32*)nullptr);
-        HIPCHK(hipGetLastError());
+        const u64* a_off = (const u64*)L->b_off.p;
+        const u32* a_len = (const u32*)L->b_len.p;
+        u32 a_n = n;
+        u8* a_slots = L->job_slots;
+        const u64* a_slot_off = (const u64*)L->b_slot_off.p;
+        u32* a_frame_len = (u32*)L->b_frame_len.p;
+        u8* a_ws = (u8*)L->b_ws.p;
+        u64 a_ws_each = (u64)L->job_ws_each;
+        u32* a_queue = (u32*)L->b_misc.p;
+        u32* a_err = (u32*)L->b_misc.p + 16;
+        const u32* a_sched = (const u32*)c->d_sched_tab;
+        const u32* a_cert = fast ? (const u32*)L->b_cert.p : (const u32*)nullptr;
+        u32 a_persist = L->job_ws_persist;
+        const u32* a_work = fast ? (const u32*)L->b_work.p : (const u32*)nullptr;
+        const u32* a_pair = (fast && !L->job_list.empty()) ? (const u32*)L->b_pair.p : (const u32*)nullptr;
+        if (L->job_s2w3) { // the same kernel from squish_s2_w3.co (see sq_ctx::f_s2w3)
+            void* args[] = {(void*)&d_data, &a_off, &a_len, (void*)&d_take, &a_n, &a_slots, &a_slot_off, &a_frame_len, &a_ws, &a_ws_each,
+                            &a_queue, &a_err, &a_sched, &a_cert, &a_persist, &a_work, &a_pair};
+            HIPCHK(hipModuleLaunchKernel(c->f_s2w3, grid.x, 1, 1, 64, 1, 1, 0, L->stream, args, nullptr));
+        } else {
+            hipLaunchKernelGGL(sqz::k_compress_batch, grid, block, 0, L->stream, d_data, a_off, a_len, d_take, a_n, a_slots, a_slot_off,
+                               a_frame_len, a_ws, a_ws_each, a_queue, a_err, a_sched, a_cert, a_persist, a_work, a_pair);
+            HIPCHK(hipGetLastError());
+        }
     }
     HIPCHK(hipEventRecord(L->ev[5], L->stream));
     if (late_drop) {
@@ -747,6 +798,7 @@ static int compress_stage2(sq_ctx* c, sq_lane* L, const u8* d_data, const u8* d_
     u32* h_err = (u32*)L->h_pinned;
     HIPCHK(hipMemcpyAsync(h_err, (u32*)L->b_misc.p + 16, 4, hipMemcpyDeviceToHost, L->stream));
     HIPCHK(hipMemcpyAsync(h_err + 1, (u32*)L->b_misc.p + 33, 4, hipMemcpyDeviceToHost, L->stream));
+    if (L->job_fast) HIPCHK(hipMemcpyAsync(h_err + 2, L->b_work.p, 8, hipMemcpyDeviceToHost, L->stream)); // lengths of stage 2's two lists
     return SQ_OK;
 }
 
@@ -782,11 +834,14 @@ static int compress_finish(sq_ctx* c, sq_lane* L, u8* d_comp, u64 comp_cap, u64*
     if (fast) HIPCHK(hipEventElapsedTime(&L->last.fast_ms, L->ev[8], L->ev[9]));
     L->last.fast_decided = fast ? h_err[1] : 0;
     L->last.fused = L->job_fused ? 1u : 0u;
+    c->s2_w3_last = L->job_s2w3;
+    // (chooses the next batch's build of the kernel: stage 2's lists against what stage 1 decided -- duplicates are in neither)
+    c->s2_dense = !fast || (u64)(h_err[2] + h_err[3]) * 3 > (u64)L->last.fast_decided;
     L->work_n = fast ? n : 0;
     if (!*h_err) { // both kernels ran to completion: their saved table states are good for the next launch
         L->ws_ptr_last = L->b_ws.p;
         L->ws_each_last = ws_each;
-        L->ws_waves_last = waves;
+        if (!L->job_ws_persist) L->ws_waves_last = waves; // (a launch that continued from saved states left the slots above its own as they were)
         if (fast) {
             L->etab_ptr_last = L->b_etab.p;
             L->etab_bytes_last = etab_bytes;
@@ -961,6 +1016,13 @@ int sq_compress_batch_slots(sq_ctx* c, const uint8_t* d_data, const uint64_t* h_
     if ((r = upload_off_len(c, L, h_off, h_len, n))) return r;
     return compress_async(c, L, d_data, h_off, h_len, n, d_select, d_comp, comp_cap, h_comp_off, h_comp_len);
 #endif
+}
+
+int sq_debug_stage2_kernel(sq_ctx* c, uint32_t* loaded, uint32_t* used_last) {
+    if (!c || !loaded || !used_last) return SQ_E_INVAL;
+    *loaded = c->f_s2w3 != nullptr;
+    *used_last = c->s2_w3_last;
+    return SQ_OK;
 }
 
 int sq_debug_stage2_list(sq_ctx* c, uint32_t* h_out, uint32_t cap, uint32_t* n_out) {

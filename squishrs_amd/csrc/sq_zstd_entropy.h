@@ -49,7 +49,9 @@ struct SeqDef {
     u16 litLength, mlBase;
 };
 
-// Everything a wave keeps in LDS (~19.5 KiB): 8 waves per CU fit in the 160 KiB of a CU.
+// Everything a wave keeps in LDS (14.4 KB since round 4: the two sets of entropy tables -- previous and next block's, 9.8 KB --
+// moved to the wave's workspace in HBM, where the encoders read them through the L1 / L2; what they borrowed out to the match
+// finder as scratch is `scr`): 11 waves per CU fit in the 160 KB of a CU.
 struct EntropyScratch { // live only inside the entropy stage of a block
     u32 count[256];
     NodeElt huffNodeTbl[2 * 256 + 2];
@@ -75,7 +77,8 @@ struct RbLds {
     u8 be[SQZ_RB_PAIRS];              // per pair: equal bytes in front of position and candidate (0..8)
 };
 struct LdsState {
-    Entropy ent[2];
+    Entropy* entp; // the two sets of entropy tables (in the wave's workspace: WsLayout::ent)
+    u32 scr[1024]; // match finder: survivors of an insertion super-batch (3 x 256 words) / the certificate's overflow list
     union {
         EntropyScratch es;
         u32 bloom[SQZ_BLOOM_WORDS];
@@ -920,8 +923,8 @@ SQ_DEVFN u32 huf_compress1X(u8* dst, u32 cap, const u8* src, u32 n, const HufCT*
 #if SQ_ON_DEVICE
     WvBitOut o;
     wvb_init(o, dst, cap);
-    const SQ_L u8* const nbT = (const SQ_L u8*)ct->nbBits;
-    const SQ_L u16* const valT = (const SQ_L u16*)ct->val;
+    const u8* const nbT = (const u8*)ct->nbBits; // (the table is in LDS -- a block's new one -- or in the workspace -- the previous block's)
+    const u16* const valT = (const u16*)ct->val;
     u32 const lane = wv_lane();
     // tiles of 256 symbols from the end; lane l owns the 4 symbols at hi-4l-4 .. hi-4l-1 (written last-first)
     s32 a = (s32)n - 4 * (s32)(lane + 1);
@@ -1339,7 +1342,7 @@ SQ_DEVFN u32 encodeSequences(u8* dst, u32 dstCap, const FseCT* ctML, const u8* m
     u32 finalValue = 0, tableLog = 0;
     if (lane < 3) {
         const FseCT* const ctg = lane == 0 ? ctOF : lane == 1 ? ctML : ctLL;
-        const SQ_L FseCT* const ct = (const SQ_L FseCT*)ctg;
+        const FseCT* const ct = (const FseCT*)ctg;
         const u8* const codes = lane == 0 ? ofCodeTable : lane == 1 ? mlCodeTable : llCodeTable;
         tableLog = ct->tableLog;
         u32 value;

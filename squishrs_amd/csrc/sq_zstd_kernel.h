@@ -24,9 +24,11 @@ struct Fingerprint {
     u32 pad[3];
 };
 
+#define SQZ_STAGE2_WAVES_PER_CU 11u // resident compressor waves per CU: 14.4 KB of LDS and <= 168 registers each (k_compress_batch)
+
 struct WsLayout {
     size_t hashTable, table2, hashTable3, seqs, lits, llCode, ofCode, mlCode, stBits, optState, fp, sched, liveList,
-        skipList, blockTab, certTab, dummy, total;
+        skipList, blockTab, certTab, ent, dummy, total;
 };
 
 #if SQ_ON_DEVICE
@@ -106,6 +108,8 @@ SQ_HD WsLayout ws_layout(u32 max_len) {
     o += ws_align((size_t)SQZ_BLOCKTAB_CAP * 8);
     L.certTab = o;
     o += ws_align(certBytes);
+    L.ent = o; // the two sets of entropy tables (previous / next block's)
+    o += ws_align(2 * sizeof(Entropy));
     L.dummy = o;
     o += 256;
     L.total = o;
@@ -218,7 +222,7 @@ SQ_DEV u32 optimalBlockSize(const u8* src, u32 srcSize, s64 savings, Fingerprint
 }
 
 // ---------------------------------------------------------------- one frame, one wave
-struct BlockState { // entropy tables are g_lds.ent[idx]
+struct BlockState { // entropy tables are g_lds.entp[idx]
     u32 rep[2][SQZ_REP_NUM];
     u32 prevIdx;
     u32 isFirstBlock;
@@ -316,14 +320,14 @@ SQ_DEVFN u32 compressBlock_internal(MatchState& ms, SeqStore& ss, BlockState& bs
             whole.nlits = srcSize;
             ss.nlits = srcSize;
             wv_mem_sync_inv();
-            cSize = entropy_compress_seqstore(whole, &g_lds.ent[p], &g_lds.ent[nx], ms.cp.strategy, dst, dstCap, srcSize);
+            cSize = entropy_compress_seqstore(whole, &g_lds.entp[p], &g_lds.entp[nx], ms.cp.strategy, dst, dstCap, srcSize);
         } else {
             PROF_T0(t_ll);
             if (lastLLSize) wv_memcpy(ss.lits + ss.nlits, src + srcSize - lastLLSize, lastLLSize);
             PROF_ADD(7, t_ll);
             ss.nlits += lastLLSize;
             wv_mem_sync_inv(); // sequence records / literals written by other lanes have landed
-            cSize = entropy_compress_seqstore(ss, &g_lds.ent[p], &g_lds.ent[nx], ms.cp.strategy, dst, dstCap, srcSize);
+            cSize = entropy_compress_seqstore(ss, &g_lds.entp[p], &g_lds.entp[nx], ms.cp.strategy, dst, dstCap, srcSize);
         }
         SQ_TRACE(0, 9);
         SQ_TRACE(5, cSize);
@@ -361,7 +365,10 @@ SQ_DEVFN u32 compress_frame_wave(const u8* src, u32 n, u8* dst, u32 cap, u8* ws,
     CParams const cp = get_cparams(n);
     u8* op = dst;
     u8* const oend = dst + cap;
-    WV_SERIAL { g_lds.trace = (u32*)(ws + L.dummy) + 8; }
+    WV_SERIAL {
+        g_lds.trace = (u32*)(ws + L.dummy) + 8;
+        g_lds.entp = (Entropy*)(ws + L.ent);
+    }
     wv_mem_sync_inv(); // previous chunk's traffic fully landed; no L1 line survives from it
     SQ_TRACE(0, 1);
     SQ_TRACE(1, n);
@@ -470,8 +477,8 @@ SQ_DEVFN u32 compress_frame_wave(const u8* src, u32 n, u8* dst, u32 cap, u8* ws,
     ss.nseq = ss.nlits = 0;
     ss.longLengthType = ss.longLengthPos = 0;
     WV_SERIAL {
-        entropy_reset(&g_lds.ent[0]);
-        entropy_reset(&g_lds.ent[1]);
+        entropy_reset(&g_lds.entp[0]);
+        entropy_reset(&g_lds.entp[1]);
     }
     for (int k = 0; k < 2; k++) {
         bs.rep[k][0] = 1;
@@ -613,7 +620,16 @@ __device__ __noinline__ void compress_one(const u8* data, const u64* off, const 
 
 // Persistent compressor: grid = number of workspaces, block = one wave.  Each wave pulls chunk
 // indices from *queue until exhausted; every wave reaches the exit condition (idx >= n).
-__global__ void __launch_bounds__(64, 2) // 2 waves per SIMD: <= 256 registers, 8 waves per CU (LDS: 8 x 19 KiB)
+// (the kernel's symbol, for the copy of it that sq_api.hip loads from squish_s2_w3.co; tests/test_abi_cpu.py checks it against the build)
+#define SQZ_K_COMPRESS_BATCH_SYMBOL "_ZN3sqz16k_compress_batchEPKhPKmPKjS1_jPhS3_PjS6_mS7_S7_S5_S5_jS5_S5_"
+#ifndef SQZ_STAGE2_WAVES_PER_SIMD
+#define SQZ_STAGE2_WAVES_PER_SIMD 2 // the library's copy: 256 registers, 8 waves per CU; squish_s2_w3.co is built with 3 (168, 11 per CU)
+#endif
+// Two builds of this kernel exist (sq_ctx::f_s2w3 in sq_api.hip says which batch takes which).  Measured (round 4,
+// profiles/round4f_tree_step_loads.txt, round4f_stage2_register_bound_ab.txt): at 168 registers and 8 waves per CU the code runs as fast as
+// at 256, and 11 per CU are +13 % on 64 KiB text, +9 % on 2 MiB mixed chunks -- but beside stage 1 on the headline the 168-register
+// build costs the step 5 %
+__global__ void __launch_bounds__(64, SQZ_STAGE2_WAVES_PER_SIMD)
 k_compress_batch(const u8* data, const u64* off, const u32* len, const u8* select, u32 n, u8* slots,
                  const u64* slot_off, u32* frame_len, u8* ws_pool, u64 ws_each, u32* queue, u32* err,
                  const u32* schedTab, const u32* certHint, u32 persist, const u32* work, const u32* pair_state) {

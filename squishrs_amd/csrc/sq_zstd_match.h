@@ -323,7 +323,7 @@ SQ_DEVFN void dubt_insert_range(MatchState& ms, u32 from, u32 to) {
         // staging: candidates (idx, h) in the wv_group scratch, survivors (idx, h, head) in the
         // "next" entropy-table slot, which is dead until the entropy stage of this block
         SQ_L u32* const stage = (SQ_L u32*)g_lds.grp;
-        SQ_L u32* const surv = (SQ_L u32*)&g_lds.ent[ms.nxEnt & 1];
+        SQ_L u32* const surv = (SQ_L u32*)g_lds.scr;
         bool pendingStores = false;
         // ranges of <= 128 positions (the updates between two exact searches) go straight to the
         // per-64 loop below; everything longer is cut into super-batches of up to 2048 positions
@@ -1451,7 +1451,7 @@ SQ_DEVFN void cert_compute(MatchState& ms) {
     cx.chunkEndPos = ms.chunkEndPos;
     cx.bloom = (SQ_L u32*)g_lds.u.bloom;
     cx.cand = (SQ_L u32*)g_lds.grp;
-    cx.ovf = (SQ_L u32*)&g_lds.ent[ms.nxEnt & 1];
+    cx.ovf = (SQ_L u32*)g_lds.scr;
     cx.lvl = nullptr; // no LDS to spare here
     cx.dbg = 0;
     cert_compute_core(cx);
@@ -1493,7 +1493,7 @@ SQ_DEVFN bool tail_certify(MatchState& ms, u32 ipPos, u32 anc, u32 off1, u32 ili
     cx.chunkEndPos = ms.chunkEndPos;
     cx.bloom = (SQ_L u32*)g_lds.u.bloom;
     cx.cand = (SQ_L u32*)g_lds.grp;
-    cx.ovf = (SQ_L u32*)&g_lds.ent[ms.nxEnt & 1];
+    cx.ovf = (SQ_L u32*)g_lds.scr;
     cx.lvl = nullptr;
     cx.dbg = 0;
     // The table must hold no entry with this chunk's tag: first use in this launch (or after a change of

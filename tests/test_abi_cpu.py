@@ -75,3 +75,15 @@ def test_queue_loops_keep_the_shape_that_has_never_hung():
     holding the kernel's spilled scalars."""
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "check_queue_loops.py")], capture_output=True, text=True)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+
+
+def test_second_build_of_the_compressor_kernel_carries_the_symbol_the_library_asks_for():
+    """sq_api.hip loads squish_s2_w3.co (the compressor kernel at 3 waves per SIMD) and looks k_compress_batch up by its mangled
+    name (SQZ_K_COMPRESS_BATCH_SYMBOL): the name in the header must be the name in the build."""
+    import re
+    hdr = open(os.path.join(ROOT, "squishrs_amd", "csrc", "sq_zstd_kernel.h")).read()
+    sym = re.search(r'#define SQZ_K_COMPRESS_BATCH_SYMBOL "(\w+)"', hdr).group(1)
+    co = os.path.join(ROOT, "squishrs_amd", "squish_s2_w3.co")
+    assert os.path.exists(co), "build() did not produce squish_s2_w3.co"
+    assert sym.encode() in open(co, "rb").read()
+    assert sym.encode() in open(os.path.join(ROOT, "squishrs_amd", "libsquish_gpu.so"), "rb").read()

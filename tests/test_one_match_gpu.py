@@ -39,3 +39,27 @@ def test_one_short_match_chunks_split_and_fused_forms(oracle):
     bad2 = [(i, kinds[i]) for i, r in enumerate(res) if r.compressed_data != want[i] or r.hash != oracle.hash_chunk(chunks[i])]
     assert not bad2, bad2[:10]
     st.close()
+
+
+def test_compressible_batches_take_the_second_build_of_the_compressor_kernel(oracle):
+    """k_compress_batch exists at 2 and at 3 waves per SIMD (squish_s2_w3.co); a batch runs the second when the batch before it
+    left more than a quarter of its chunks to stage 2 (sq_api.hip, sq_ctx::f_s2w3).  Both must give the oracle's frames."""
+    import corpus
+    import squishrs_amd
+    from test_compress_gpu import _batch_compress
+    st = squishrs_amd.ChunkStore(device=0, dedup_capacity=1 << 12)
+    loaded, _ = st.stage2_kernel()
+    assert loaded, "squish_s2_w3.co was not loaded"
+    text = [corpus.make("text", 900 + i, n) for i, n in enumerate([70000, 262144, 20000, 131073, 9000, 200000] * 4)]
+    rnd = [corpus.make("random", 950 + i, 262144) for i in range(24)]
+    want_text = [oracle.compress_chunk(c) for c in text]
+    want_rnd = [oracle.compress_chunk(c) for c in rnd]
+    assert _batch_compress(st, rnd) == want_rnd          # incompressible: stage 1 decides (nearly) all
+    assert _batch_compress(st, text) == want_text        # first compressible batch: still the first build
+    assert st.stage2_kernel()[1] is False
+    assert _batch_compress(st, text) == want_text        # the batch before was compressible: the second build
+    assert st.stage2_kernel()[1] is True
+    assert _batch_compress(st, rnd) == want_rnd          # (history says compressible: the second build, on random chunks)
+    assert _batch_compress(st, rnd) == want_rnd
+    assert st.stage2_kernel()[1] is False
+    st.close()
