@@ -65,6 +65,10 @@ void sq_ctx_destroy(sq_ctx* ctx);
 /* Run all subsequent work of this ctx on an existing hipStream_t (e.g. torch's current stream). */
 int sq_ctx_set_stream(sq_ctx* ctx, void* hip_stream);
 int sq_ctx_synchronize(sq_ctx* ctx);
+/* Gives the context's cached device buffers back to the device (the compressor's workspace pools -- up to 65 GB per lane for
+ * 2 MiB chunks --, staging and slot buffers); the dedup set and everything observable stay.  They are allocated again on
+ * demand; the next compress stage clears its tables once.  SQ_E_INVAL while batches of sq_pack_submit are in flight. */
+int sq_ctx_trim(sq_ctx* ctx);
 
 /* == hash_chunk (src/util/chunk.rs:46-49): out = xxh3_128(chunk).to_le_bytes().
  * Stateless convenience form (host pointers, runs one tiny launch on device 0).  Thread-safe: the

@@ -244,6 +244,10 @@ class ChunkStore:
         raw = out.raw
         return [raw[int(o):int(o) + int(l)] if s == 0 else None for o, l, s in zip(ooff, out_len, status)]
 
+    def trim(self):
+        """give the context's cached device buffers (workspace pools, staging) back to the device (sq_ctx_trim)"""
+        check(self._L.sq_ctx_trim(self._h))
+
     def stage2_kernel(self):
         """(loaded, used_last): is the second build of the compressor kernel (squish_s2_w3.co) available, and did the most
         recent compress stage run it (include/squish_gpu.h sq_debug_stage2_kernel)"""

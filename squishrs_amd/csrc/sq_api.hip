@@ -361,6 +361,22 @@ int sq_ctx_synchronize(sq_ctx* c) {
     return SQ_OK;
 }
 
+int sq_ctx_trim(sq_ctx* c) {
+    if (!c) return SQ_E_INVAL;
+    if (c->submitted != c->collected || c->shard_pending) return SQ_E_INVAL; // batches in flight hold these buffers
+    HIPCHK(hipSetDevice(c->device));
+    for (sq_lane& ln : c->ln) {
+        HIPCHK(hipStreamSynchronize(ln.stream));
+        if (ln.aux) HIPCHK(hipStreamSynchronize(ln.aux));
+        for (DevBuf* b : {&ln.b_ws, &ln.b_slots, &ln.b_stage_in, &ln.b_stage_out, &ln.b_hpool, &ln.b_etab, &ln.b_dz_in, &ln.b_dz_out, &ln.b_dz_lit})
+            b->release();
+        ln.ws_ptr_last = nullptr; // (the saved table states went with the pool: the next launch clears its tables)
+        ln.ws_waves_last = 0;
+        ln.etab_ptr_last = nullptr;
+    }
+    return SQ_OK;
+}
+
 uint64_t sq_unique_count(const sq_ctx* c) {
     if (!c) return 0;
     unsigned long long v = 0;

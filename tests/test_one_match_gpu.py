@@ -63,3 +63,25 @@ def test_compressible_batches_take_the_second_build_of_the_compressor_kernel(ora
     assert _batch_compress(st, rnd) == want_rnd
     assert st.stage2_kernel()[1] is False
     st.close()
+
+
+def test_trim_gives_the_pools_back_and_the_next_batch_is_unchanged(oracle):
+    """sq_ctx_trim (include/squish_gpu.h): cached device buffers released, dedup set kept, frames of the next batch unchanged."""
+    import corpus
+    import squishrs_amd
+    import torch
+    st = squishrs_amd.ChunkStore(device=0, dedup_capacity=1 << 12)
+    chunks = [corpus.make(k, 1300 + i, n) for i, (k, n) in enumerate([("text", 100000), ("random", 262144), ("mixed", 300000), ("records", 50000)] * 3)]
+    want = [oracle.compress_chunk(c) for c in chunks]
+    res = st.insert_batch(chunks)
+    assert [r.compressed_data for r in res[:4]] == want[:4]
+    free0 = torch.cuda.mem_get_info()[0]
+    st.trim()
+    assert torch.cuda.mem_get_info()[0] > free0 + (64 << 20)     # (12 chunks: a pool of 12 workspaces of ~14 MB)
+    assert st.len() == 12
+    res2 = st.insert_batch(chunks)                                   # all duplicates now: the set survived
+    assert all(r.compressed_data is None for r in res2)
+    st.reset()
+    res3 = st.insert_batch(chunks)
+    assert [r.compressed_data for r in res3[:4]] == want[:4]
+    st.close()
