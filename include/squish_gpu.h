@@ -69,6 +69,12 @@ int sq_ctx_synchronize(sq_ctx* ctx);
  * 2 MiB chunks --, staging and slot buffers); the dedup set and everything observable stay.  They are allocated again on
  * demand; the next compress stage clears its tables once.  SQ_E_INVAL while batches of sq_pack_submit are in flight. */
 int sq_ctx_trim(sq_ctx* ctx);
+/* Device memory for a driver that keeps its batches on the device (the sq_shard_* calls take device pointers only) without
+ * linking the HIP runtime itself: allocation on the context's device (NULL on failure), release, and a synchronous copy
+ * (to_device != 0: host -> device, else device -> host).  `squishrs pack --gpus N` (host/squishrs_main.cpp) is built on them. */
+void* sq_dev_alloc(sq_ctx* ctx, uint64_t bytes);
+void sq_dev_free(sq_ctx* ctx, void* p);
+int sq_dev_copy(sq_ctx* ctx, void* dst, const void* src, uint64_t bytes, int to_device);
 
 /* == hash_chunk (src/util/chunk.rs:46-49): out = xxh3_128(chunk).to_le_bytes().
  * Stateless convenience form (host pointers, runs one tiny launch on device 0).  Thread-safe: the

@@ -22,7 +22,7 @@ EXPORTS = [
     "sq_calibrate_read_bw", "sq_last_timings", "sq_dedup_reset", "sq_compress_batch_slots", "sq_slots_bound",
     "sq_host_alloc", "sq_host_free", "sq_debug_stage2_list", "sq_pack_submit", "sq_pack_wait", "sq_calibrate_gather", "sq_calibrate_gather2",
     "sq_shard_submit_hash", "sq_shard_wait_hash", "sq_shard_submit_rest", "sq_shard_submit_rest_idx",
-    "sq_decompress_batch", "sq_decompress_strerror", "sq_debug_stage2_kernel", "sq_ctx_trim",
+    "sq_decompress_batch", "sq_decompress_strerror", "sq_debug_stage2_kernel", "sq_ctx_trim", "sq_dev_alloc", "sq_dev_free", "sq_dev_copy",
 ]
 
 

@@ -361,6 +361,27 @@ int sq_ctx_synchronize(sq_ctx* c) {
     return SQ_OK;
 }
 
+void* sq_dev_alloc(sq_ctx* c, uint64_t bytes) {
+    if (!c || hipSetDevice(c->device) != hipSuccess) return nullptr;
+    void* p = nullptr;
+    if (hipMalloc(&p, bytes ? bytes : 1) != hipSuccess) {
+        (void)hipGetLastError();
+        return nullptr;
+    }
+    return p;
+}
+void sq_dev_free(sq_ctx* c, void* p) {
+    if (!c || !p) return;
+    (void)hipSetDevice(c->device);
+    (void)hipFree(p);
+}
+int sq_dev_copy(sq_ctx* c, void* dst, const void* src, uint64_t bytes, int to_device) {
+    if (!c || (bytes && (!dst || !src))) return SQ_E_INVAL;
+    HIPCHK(hipSetDevice(c->device));
+    if (bytes) HIPCHK(hipMemcpy(dst, src, bytes, to_device ? hipMemcpyHostToDevice : hipMemcpyDeviceToHost));
+    return SQ_OK;
+}
+
 int sq_ctx_trim(sq_ctx* c) {
     if (!c) return SQ_E_INVAL;
     if (c->submitted != c->collected || c->shard_pending) return SQ_E_INVAL; // batches in flight hold these buffers

@@ -21,8 +21,12 @@
 
 #include <dirent.h>
 #include <fcntl.h>
+#include <pthread.h>
+#include <signal.h>
+#include <sys/mman.h>
 #include <sys/stat.h>
 #include <sys/uio.h>
+#include <sys/wait.h>
 #include <unistd.h>
 
 #include <cerrno>
@@ -534,6 +538,336 @@ static uint64_t pack(const std::string& input, const std::string& output, int de
     return total;
 }
 
+// ---- pack on N GPUs (the reference's counterpart is the Rayon fan-out of ArchiveWriter::pack,
+// writer.rs:153-195, with the one DashMap all workers share, chunk.rs:52-56,83, and the single ordered writer thread,
+// fsutil/writer.rs:17-39).  One PROCESS per GPU, forked before anything touches a GPU.  The chunk plan (files in walk order,
+// 2 MiB chunks) is cut into super-batches; inside one the chunks go to the ranks in block-cyclic stripes of 16 (the
+// first occurrences -- the compression work -- spread evenly).  Per super-batch every rank
+//   1. reads and hashes ITS chunks (sq_shard_submit_hash), puts the hashes into a table all ranks share (host memory:
+//      the exchange -- 16 bytes per chunk -- is the path's only communication),
+//   2. after a barrier hands the hashes of ALL ranks, in global order, to sq_shard_submit_rest_idx: every rank's replica of
+//      the dedup set resolves "first occurrence in global order" identically, and the rank compresses only its own new chunks,
+//   3. publishes its records' sizes; after a second barrier every rank knows where each of its records goes (a prefix sum
+//      over the global order) and writes them itself with pwritev: no funnel, the archive is byte-identical to the one-GPU one.
+// Rank 0 writes the chunk count and the manifest at the end.  (Synchronous per super-batch; the pipelined form -- two
+// super-batches in flight -- is what squishrs_amd/sharded_pack.py does with the same calls over RCCL.)
+struct MultiShared {
+    pthread_barrier_t bar;
+    std::atomic<int> failed;
+    char msg[480];
+};
+static uint64_t pack_multi(const std::string& input, const std::string& output, const std::vector<int>& devices, uint32_t batch_chunks,
+                           long max_threads) {
+    std::string trimmed = input;
+    while (!trimmed.empty() && (trimmed.back() == '/' || trimmed.back() == '\\')) trimmed.pop_back();
+    std::vector<std::string> files = walk_dir(trimmed);
+    std::vector<uint64_t> sizes(files.size());
+    struct Chunk {
+        uint32_t file;
+        uint32_t len;
+        uint64_t foff;
+    };
+    std::vector<Chunk> plan;
+    std::vector<uint32_t> first_chunk(files.size() + 1, 0);
+    for (size_t f = 0; f < files.size(); f++) {
+        struct stat st;
+        if (stat(files[f].c_str(), &st) != 0) throw AppError{std::string("I/O error: ") + strerror(errno)};
+        sizes[f] = (uint64_t)st.st_size;
+        first_chunk[f] = (uint32_t)plan.size();
+        for (uint64_t o = 0; o < sizes[f]; o += SQ_CHUNK_SIZE)
+            plan.push_back({(uint32_t)f, (uint32_t)std::min<uint64_t>(SQ_CHUNK_SIZE, sizes[f] - o), o});
+    }
+    first_chunk[files.size()] = (uint32_t)plan.size();
+    uint64_t const total = plan.size();
+    int const world = (int)devices.size();
+    uint32_t const stripe = 16, B = std::max<uint32_t>(batch_chunks, stripe * (uint32_t)world);
+
+    {   // preamble (header.rs:10-14,55-63; writer.rs:83-84), by the parent: one timestamp
+        FILE* out = fopen(output.c_str(), "wb");
+        if (!out) throw AppError{std::string("I/O error: ") + strerror(errno)};
+        std::string pre = "squish";
+        pre += kVersion;
+        put_u64(pre, (uint64_t)time(nullptr));
+        put_u64(pre, 0);
+        fwrite(pre.data(), 1, pre.size(), out);
+        fclose(out);
+    }
+    // shared between the ranks: barrier + failure word, every chunk's hash, every chunk's record size (0: duplicate)
+    size_t const sh_bytes = sizeof(MultiShared) + (size_t)total * 16 + (size_t)total * 4 + 64;
+    void* const shm = mmap(nullptr, sh_bytes, PROT_READ | PROT_WRITE, MAP_SHARED | MAP_ANONYMOUS, -1, 0);
+    if (shm == MAP_FAILED) throw AppError{std::string("I/O error: ") + strerror(errno)};
+    MultiShared* const sh = new (shm) MultiShared();
+    uint8_t* const all_hashes = (uint8_t*)shm + sizeof(MultiShared);
+    uint32_t* const csize = (uint32_t*)(all_hashes + (size_t)total * 16);
+    sh->failed = 0;
+    sh->msg[0] = 0;
+    {
+        pthread_barrierattr_t ba;
+        pthread_barrierattr_init(&ba);
+        pthread_barrierattr_setpshared(&ba, PTHREAD_PROCESS_SHARED);
+        pthread_barrier_init(&sh->bar, &ba, (unsigned)world);
+        pthread_barrierattr_destroy(&ba);
+    }
+    auto rank_main = [&](int rank) -> int {
+        auto fail = [&](const std::string& m) {
+            int expect = 0;
+            if (sh->failed.compare_exchange_strong(expect, 1)) snprintf(sh->msg, sizeof(sh->msg), "%s", m.c_str());
+        };
+        sq_ctx* ctx = nullptr;
+        uint8_t *h_in = nullptr, *h_comp = nullptr;
+        uint8_t *d_data = nullptr, *d_hashes = nullptr, *d_all = nullptr, *d_isnew = nullptr, *d_comp = nullptr;
+        uint32_t* d_idx = nullptr;
+        size_t cap_in = 0, cap_comp = 0, cap_n = 0;
+        int out_fd = -1;
+        uint64_t file_pos = 27, unique = 0; // (every rank computes the same values)
+        try {
+            sq_config cfg;
+            memset(&cfg, 0, sizeof(cfg));
+            cfg.abi_version = SQ_ABI_VERSION;
+            cfg.device = devices[(size_t)rank];
+            cfg.dedup_capacity = total + 1024;
+            check(sq_ctx_create(&cfg, &ctx), "sq_ctx_create");
+            out_fd = open(output.c_str(), O_WRONLY);
+            if (out_fd < 0) throw AppError{std::string("I/O error: ") + strerror(errno)};
+        } catch (const AppError& e) {
+            fail(e.msg);
+        }
+        std::vector<uint32_t> mine;           // global indices of this rank's chunks of the super-batch, ascending
+        std::vector<uint64_t> off, woff;      // their places in the input buffer; their slots' offsets
+        std::vector<uint32_t> len, wlen;
+        std::vector<uint8_t> isnew, hashes;
+        for (uint64_t g0 = 0; g0 < total; g0 += B) {
+            uint32_t const nb = (uint32_t)std::min<uint64_t>(B, total - g0);
+            try {
+                if (sh->failed) throw AppError{""};
+                mine.clear(); off.clear(); len.clear();
+                size_t used = 0;
+                uint64_t comp_need = 64;
+                for (uint32_t j = 0; j < nb; j++)
+                    if ((int)((j / stripe) % (uint32_t)world) == rank) {
+                        Chunk const& c = plan[(size_t)(g0 + j)];
+                        size_t const pos = (used + 255) & ~(size_t)255;
+                        mine.push_back(j);
+                        off.push_back(pos);
+                        len.push_back(c.len);
+                        used = pos + c.len;
+                        comp_need += sq_compress_bound(c.len) + 64;
+                    }
+                uint32_t const n = (uint32_t)mine.size();
+                if (used + 4096 > cap_in) { // (buffers grow to the largest super-batch and stay)
+                    if (h_in) sq_host_free(h_in);
+                    sq_dev_free(ctx, d_data);
+                    cap_in = used + (used >> 3) + 4096;
+                    h_in = (uint8_t*)sq_host_alloc(cap_in);
+                    d_data = (uint8_t*)sq_dev_alloc(ctx, cap_in);
+                    if (!h_in || !d_data) throw AppError{"I/O error: out of memory"};
+                }
+                if (comp_need > cap_comp) {
+                    if (h_comp) sq_host_free(h_comp);
+                    sq_dev_free(ctx, d_comp);
+                    cap_comp = comp_need + (comp_need >> 3);
+                    h_comp = (uint8_t*)sq_host_alloc(cap_comp);
+                    d_comp = (uint8_t*)sq_dev_alloc(ctx, cap_comp);
+                    if (!h_comp || !d_comp) throw AppError{"I/O error: out of memory"};
+                }
+                if ((size_t)n + 16 > cap_n || !d_all) {
+                    sq_dev_free(ctx, d_hashes); sq_dev_free(ctx, d_isnew); sq_dev_free(ctx, d_idx); sq_dev_free(ctx, d_all);
+                    cap_n = (size_t)n + (n >> 3) + 64;
+                    d_hashes = (uint8_t*)sq_dev_alloc(ctx, cap_n * 16);
+                    d_isnew = (uint8_t*)sq_dev_alloc(ctx, cap_n);
+                    d_idx = (uint32_t*)sq_dev_alloc(ctx, cap_n * 4);
+                    d_all = (uint8_t*)sq_dev_alloc(ctx, (size_t)B * 16);
+                    if (!d_hashes || !d_isnew || !d_idx || !d_all) throw AppError{"I/O error: out of memory"};
+                }
+                {   // this rank's chunks: up to -j reader threads, pread straight into the page-locked buffer
+                    std::atomic<size_t> next{0};
+                    std::string rerr;
+                    std::mutex rmu;
+                    auto work = [&]() {
+                        int fd = -1;
+                        uint32_t cur = 0xFFFFFFFFu;
+                        for (;;) {
+                            size_t const i = next.fetch_add(1);
+                            if (i >= n) break;
+                            Chunk const& c = plan[(size_t)(g0 + mine[i])];
+                            if (c.file != cur) {
+                                if (fd >= 0) close(fd);
+                                fd = open(files[c.file].c_str(), O_RDONLY);
+                                cur = c.file;
+                            }
+                            size_t done = 0;
+                            ssize_t got = fd < 0 ? -1 : 0;
+                            if (fd >= 0)
+                                for (; done < c.len; done += (size_t)got) {
+                                    got = pread(fd, h_in + off[i] + done, c.len - done, (off_t)(c.foff + done));
+                                    if (got <= 0) break;
+                                }
+                            if (fd < 0 || got < 0 || done != c.len) { // (a file that changed size under the pack: the one-GPU path packs what is there, this one stops)
+                                std::lock_guard<std::mutex> lk(rmu);
+                                if (rerr.empty()) rerr = std::string("I/O error: ") + (fd < 0 || got < 0 ? strerror(errno) : "file changed while packing") + " (" + files[c.file] + ")";
+                                break;
+                            }
+                        }
+                        if (fd >= 0) close(fd);
+                    };
+                    size_t const nt = (size_t)std::max<long>(1, std::min<long>(std::min<long>(max_threads, 16), (long)n));
+                    std::vector<std::thread> pool;
+                    for (size_t t = 1; t < nt; t++) pool.emplace_back(work);
+                    work();
+                    for (auto& t : pool) t.join();
+                    if (!rerr.empty()) throw AppError{rerr};
+                }
+                check(sq_dev_copy(ctx, d_data, h_in, used, 1), "copy to the device");
+                check(sq_shard_submit_hash(ctx, d_data, off.data(), len.data(), n, d_hashes), "sq_shard_submit_hash");
+                check(sq_shard_wait_hash(ctx), "sq_shard_wait_hash");
+                hashes.resize((size_t)n * 16 + 16);
+                check(sq_dev_copy(ctx, hashes.data(), d_hashes, (size_t)n * 16, 0), "copy from the device");
+                for (uint32_t i = 0; i < n; i++) memcpy(all_hashes + (size_t)(g0 + mine[i]) * 16, &hashes[(size_t)16 * i], 16);
+            } catch (const AppError& e) {
+                if (!e.msg.empty()) fail(e.msg);
+            }
+            pthread_barrier_wait(&sh->bar); // every rank's hashes of the super-batch are in the table
+            uint32_t const n = (uint32_t)mine.size();
+            bool submitted = false;
+            try {
+                if (sh->failed) throw AppError{""};
+                check(sq_dev_copy(ctx, d_all, all_hashes + (size_t)g0 * 16, (size_t)nb * 16, 1), "copy to the device");
+                check(sq_dev_copy(ctx, d_idx, mine.data(), (size_t)n * 4, 1), "copy to the device");
+                check(sq_shard_submit_rest_idx(ctx, d_all, nb, n ? d_idx : nullptr, d_isnew, d_comp, cap_comp, 0), "sq_shard_submit_rest_idx");
+                submitted = true;
+                woff.resize((size_t)n + 1);
+                wlen.resize((size_t)n + 1);
+                check(sq_pack_wait(ctx, woff.data(), wlen.data()), "sq_pack_wait");
+                isnew.resize((size_t)n + 16);
+                check(sq_dev_copy(ctx, isnew.data(), d_isnew, n, 0), "copy from the device");
+                uint64_t end = 0;
+                for (uint32_t i = 0; i < n; i++) {
+                    csize[(size_t)(g0 + mine[i])] = isnew[i] ? wlen[i] : 0u;
+                    if (isnew[i]) end = std::max<uint64_t>(end, woff[i] + wlen[i]);
+                }
+                check(sq_dev_copy(ctx, h_comp, d_comp, end, 0), "copy from the device");
+            } catch (const AppError& e) {
+                if (!e.msg.empty()) fail(e.msg);
+                (void)submitted;
+            }
+            pthread_barrier_wait(&sh->bar); // every record's size is known to every rank
+            try {
+                if (sh->failed) throw AppError{""};
+                // where the records go: a prefix sum over the global order (fsutil/writer.rs:21-36: hash || original_size ||
+                // compressed_size || frame); this rank writes its own
+                uint32_t k = 0;
+                for (uint32_t j = 0; j < nb; j++) {
+                    uint32_t const cs = csize[(size_t)(g0 + j)];
+                    bool const is_mine = k < n && mine[k] == j;
+                    if (cs) {
+                        if (is_mine) {
+                            uint64_t const osz = SQ_CHUNK_SIZE /* chunk_buf.len(), writer.rs:255 */, csz = cs;
+                            uint8_t hdr[32];
+                            memcpy(hdr, all_hashes + (size_t)(g0 + j) * 16, 16);
+                            memcpy(hdr + 16, &osz, 8);
+                            memcpy(hdr + 24, &csz, 8);
+                            struct iovec iov[2] = {{hdr, 32}, {h_comp + woff[k], (size_t)csz}};
+                            struct iovec* v = iov;
+                            int cnt = 2;
+                            uint64_t at = file_pos;
+                            size_t left = 32 + (size_t)csz;
+                            while (left) {
+                                ssize_t const w = pwritev(out_fd, v, cnt, (off_t)at);
+                                if (w <= 0) throw AppError{std::string("I/O error: ") + strerror(errno)};
+                                left -= (size_t)w;
+                                at += (uint64_t)w;
+                                size_t adv = (size_t)w;
+                                while (cnt && adv >= v->iov_len) {
+                                    adv -= v->iov_len;
+                                    v++;
+                                    cnt--;
+                                }
+                                if (cnt && adv) {
+                                    v->iov_base = (char*)v->iov_base + adv;
+                                    v->iov_len -= adv;
+                                }
+                            }
+                        }
+                        file_pos += 32 + (uint64_t)cs;
+                        unique++;
+                    }
+                    if (is_mine) k++;
+                }
+            } catch (const AppError& e) {
+                if (!e.msg.empty()) fail(e.msg);
+            }
+        }
+        pthread_barrier_wait(&sh->bar); // every record is written
+        if (rank == 0 && !sh->failed) {
+            try { // writer.rs:177-184 (chunk count), 292-329 (manifest)
+                std::string m;
+                put_u32(m, (uint32_t)files.size());
+                for (size_t f = 0; f < files.size(); f++) {
+                    std::string const rel = strip_prefix(files[f], input);
+                    put_u32(m, (uint32_t)rel.size());
+                    m += rel;
+                    put_u64(m, sizes[f]);
+                    uint32_t const nc = first_chunk[f + 1] - first_chunk[f];
+                    put_u32(m, nc);
+                    m.append((const char*)all_hashes + (size_t)first_chunk[f] * 16, (size_t)nc * 16);
+                }
+                if (pwrite(out_fd, &unique, 8, 19) != 8) throw AppError{std::string("I/O error: ") + strerror(errno)};
+                size_t done = 0;
+                while (done < m.size()) {
+                    ssize_t const w = pwrite(out_fd, m.data() + done, m.size() - done, (off_t)(file_pos + done));
+                    if (w <= 0) throw AppError{std::string("I/O error: ") + strerror(errno)};
+                    done += (size_t)w;
+                }
+                if (ftruncate(out_fd, (off_t)(file_pos + m.size())) != 0) throw AppError{std::string("I/O error: ") + strerror(errno)};
+            } catch (const AppError& e) {
+                fail(e.msg);
+            }
+        }
+        if (out_fd >= 0) close(out_fd);
+        if (ctx) {
+            for (void* p : {(void*)d_data, (void*)d_hashes, (void*)d_all, (void*)d_isnew, (void*)d_comp, (void*)d_idx}) sq_dev_free(ctx, p);
+            if (h_in) sq_host_free(h_in);
+            if (h_comp) sq_host_free(h_comp);
+            sq_ctx_destroy(ctx);
+        }
+        return sh->failed ? 1 : 0;
+    };
+    fflush(stdout);
+    fflush(stderr);
+    std::vector<pid_t> kids;
+    for (int r = 0; r < world; r++) {
+        pid_t const pid = fork(); // (before this process has touched a GPU: it never does)
+        if (pid < 0) throw AppError{std::string("I/O error: fork: ") + strerror(errno)};
+        if (pid == 0) _exit(rank_main(r));
+        kids.push_back(pid);
+    }
+    bool bad = false;
+    for (size_t left = kids.size(); left;) { // a rank that dies (not: fails) would leave the others at the barrier: they are ended then
+        int st = 0;
+        pid_t const k = waitpid(-1, &st, 0);
+        if (k < 0) break;
+        auto it = std::find(kids.begin(), kids.end(), k);
+        if (it == kids.end()) continue;
+        *it = -1;
+        left--;
+        if (!WIFEXITED(st)) {
+            bad = true;
+            for (pid_t o : kids)
+                if (o > 0) kill(o, SIGKILL);
+        } else if (WEXITSTATUS(st) != 0)
+            bad = true;
+    }
+    std::string const msg = sh->msg;
+    bool const failed = sh->failed != 0;
+    pthread_barrier_destroy(&sh->bar);
+    munmap(shm, sh_bytes);
+    if (failed) throw AppError{msg.empty() ? std::string("Unknown error: a rank failed") : msg};
+    if (bad) throw AppError{"Unknown error: a rank ended abnormally"};
+    struct stat st;
+    if (stat(output.c_str(), &st) != 0) throw AppError{std::string("I/O error: ") + strerror(errno)};
+    return (uint64_t)st.st_size;
+}
+
 // ---- list (archive/reader.rs:46-118,155-219; cmd/mod.rs:60-158) --------------------------------
 struct Summary {
     uint64_t archive_size = 0, total_orig = 0, unique_chunks = 0, timestamp = 0;
@@ -852,7 +1186,9 @@ static int help_for(const std::string& cmd) {
     if (cmd == "pack")
         printf("Compress and deduplicate a directory into a .squish archive file\n\nUsage: squishrs pack [OPTIONS] <INPUT>\n\n"
                "Arguments:\n  <INPUT>  \n\nOptions:\n  -o, --output <OUTPUT>            \n"
-               "  -j, --max-threads <MAX_THREADS>  Maximum number of threads to use [default: 25]\n  -h, --help                       Print help\n");
+               "  -j, --max-threads <MAX_THREADS>  Maximum number of threads to use [default: 25]\n"
+               "      --gpus <N>                   Pack on GPUs 0..N-1, one process each (this implementation)\n"
+               "      --devices <A,B,...>          ... on these GPU ordinals\n  -h, --help                       Print help\n");
     else if (cmd == "list")
         printf("Display the contents of a .squish archive\n\nUsage: squishrs list [OPTIONS] <SQUISH>\n\n"
                "Arguments:\n  <SQUISH>  \n\nOptions:\n      --simple                     \n"
@@ -876,6 +1212,7 @@ int main(int argc, char** argv) {
     std::string output;
     bool simple = false, have_output = false, want_help = false;
     int device = 0;
+    std::vector<int> devices; // pack --gpus N / --devices a,b,...: one process per entry (pack_multi)
     long max_threads = 25; // cmd/mod.rs:16 (host worker count; the GPU path does not use Rayon)
     auto usage_of = [&]() -> std::string {
         if (pos.empty()) return "squishrs [OPTIONS] <COMMAND>";
@@ -911,6 +1248,20 @@ int main(int argc, char** argv) {
             simple = true;
         else if (a == "--device")
             device = atoi(value("--device <ORDINAL>"));
+        else if (a == "--gpus" && !pos.empty() && pos[0] == "pack") {
+            int const n = atoi(value("--gpus <N>"));
+            devices.clear();
+            for (int d = 0; d < n; d++) devices.push_back(d);
+        } else if (a == "--devices" && !pos.empty() && pos[0] == "pack") { // (explicit ordinals; one may repeat: ranks that share a GPU)
+            devices.clear();
+            std::string const v = value("--devices <A,B,...>");
+            for (size_t i = 0; i < v.size();) {
+                size_t j = v.find(',', i);
+                if (j == std::string::npos) j = v.size();
+                devices.push_back(atoi(v.substr(i, j - i).c_str()));
+                i = j + 1;
+            }
+        }
         else if (a == "-h" || a == "--help")
             want_help = true;
         else if ((a == "-V" || a == "--version") && !pos.empty()) {
@@ -936,7 +1287,10 @@ int main(int argc, char** argv) {
             if (!have_output) output = input + ".squish"; // lib.rs:31 (untrimmed input)
             uint64_t batch = 4ull << 30; // 2,048 chunks of 2 MiB: one per compressor wave (an eighth of the input at most, see pack())
             if (const char* e = getenv("SQUISH_BATCH_BYTES")) batch = strtoull(e, nullptr, 10);
-            uint64_t sz = pack(input, output, device, batch, max_threads);
+            uint32_t super = 4096; // chunks per super-batch of the N-GPU path (all ranks together)
+            if (const char* e = getenv("SQUISH_SUPER_BATCH_CHUNKS")) super = (uint32_t)std::max(1, atoi(e));
+            if (devices.size() > 64 || (devices.empty() && false)) return cli_error("invalid value for '--gpus <N>'", usage_of());
+            uint64_t sz = devices.size() >= 1 ? pack_multi(input, output, devices, super, max_threads) : pack(input, output, device, batch, max_threads);
             std::string shown = output.rfind("./", 0) == 0 ? output.substr(2) : output;
             printf("%s\nCompressed to %s\n%s: %s\n", green("Packing complete!").c_str(), shown.c_str(),
                    blue("Final archive size").c_str(), format_bytes(sz).c_str()); // lib.rs:49-55

@@ -274,3 +274,38 @@ def test_bench_config4_three_ranks_on_one_gpu_rehearsal():
         pr = line["per_rank"]["ranks"]
         assert len(pr) == 3 and all(r["ms_per_step"] > 0 and r["kernels_ms"]["stage1"] > 0 and r["host_ms_per_step"]["all_gather_of_hashes"] >= 0 for r in pr)
         assert max(r["ms_per_step"] for r in pr) <= line["ms_per_step"] * 1.0001
+
+
+def test_pack_on_three_ranks_in_the_product_binary_equals_the_one_gpu_archive(tmp_path, oracle):
+    """`squishrs pack --devices 0,0,0`: the N-GPU path of the C++ driver (pack_multi: one process per rank forked before any GPU
+    call, hashes exchanged through shared host memory, sq_shard_submit_hash / sq_shard_submit_rest_idx, every rank writes its own
+    records) rehearsed with three ranks on ONE GPU, with super-batches small enough that stripes, cross-rank duplicates and
+    duplicates across super-batches all occur.  The archive must equal the one-GPU archive (and the oracle's) except the timestamp.
+    Reference: the Rayon fan-out + shared DashMap + ordered writer of /root/reference/src/archive/writer.rs:153-195."""
+    tree = tmp_path / "in"
+    files = {}
+    for i in range(40):
+        kind = ["random", "text", "mixed", "records"][i % 4]
+        files[f"d{i % 5}/f{i:02d}.bin"] = corpus.make(kind, 700 + (i % 23), 100000 + 37000 * (i % 7))     # i % 23: duplicates of whole files
+    files["big/a.bin"] = corpus.mixed(9, 3 * 2097152 + 777)
+    files["big/b.bin"] = corpus.mixed(9, 3 * 2097152 + 777)[:2 * 2097152] + corpus.random_bytes(3, 5, 2097152 + 5)  # shares two chunks with a.bin
+    files["empty"] = b""
+    for rel, data in files.items():
+        p = tree / rel
+        p.parent.mkdir(parents=True, exist_ok=True)
+        p.write_bytes(data)
+    one = tmp_path / "one.squish"
+    r = _run("pack", str(tree), "-o", str(one))
+    assert r.returncode == 0, r.stderr
+    for devs, super_chunks in (("0,0,0", "48"), ("0,0", "4096")):
+        multi = tmp_path / f"multi_{devs.count(',') + 1}.squish"
+        r = subprocess.run([CLI, "pack", "--devices", devs, str(tree), "-o", str(multi)], capture_output=True, text=True, timeout=600,
+                           env=dict(os.environ, SQUISH_SUPER_BATCH_CHUNKS=super_chunks))
+        assert r.returncode == 0, r.stdout + r.stderr
+        a, b = one.read_bytes(), multi.read_bytes()
+        assert a[:11] == b[:11] and a[19:] == b[19:], f"--devices {devs}: archive differs from the one-GPU archive"
+    order = _manifest_order(one.read_bytes())
+    exp = oracle.pack_archive([(rel, files[rel]) for rel in order], timestamp=0)
+    assert one.read_bytes()[19:] == exp[19:]
+    r = _run("pack", "--gpus", "0", str(tree), "-o", str(tmp_path / "x.squish"))     # --gpus 0: no rank, the one-GPU path
+    assert r.returncode == 0
