@@ -290,7 +290,7 @@ SQ_DEVFN u32 compressBlock_internal(MatchState& ms, SeqStore& ss, BlockState& bs
                 os.longLengthType = 0;
                 os.longLengthPos = 0;
                 u32 rr[3] = {r0, r1, r2};
-                u32 const last = (u32)opt::compressBlock_btopt(&om, &os, rr, src, srcSize);
+                u32 const last = (u32)opt::compressBlock_btopt(&om, &os, rr, src, srcSize, (void*)&g_lds.u);
                 g_lds.ret[0] = last;
                 g_lds.ret[1] = os.nseq;
                 g_lds.ret[2] = os.nlits;

@@ -37,10 +37,12 @@ struct seqstore {
 
 SQ_DEV u32 highbit32(u32 v) { return sq_highbit32(v); }
 SQ_DEV u32 rd32(const u8* p) { return sq_rd32(p); }
-SQ_DEV u32 zs_LLcode(u32 v) { return LLcode(v); }
-SQ_DEV u32 zs_MLcode(u32 v) { return MLcode(v); }
-#define zs_LL_bits LL_bits
-#define zs_ML_bits ML_bits
+// (codes below 16 / 32 are the value itself and carry no extra bits -- nearly every length the parser prices: two table loads
+// per price less, on a lane whose every load is a trip of its own)
+SQ_DEV u32 zs_LLcode(u32 v) { return v < 16 ? v : LLcode(v); }
+SQ_DEV u32 zs_MLcode(u32 v) { return v < 32 ? v : MLcode(v); }
+SQ_DEV u32 zs_LL_bits_of(u32 code) { return code < 16 ? 0u : LL_bits[code]; }
+SQ_DEV u32 zs_ML_bits_of(u32 code) { return code < 32 ? 0u : ML_bits[code]; }
 SQ_DEV size_t count_match(const u8* pIn, const u8* pMatch, const u8* const pInLimit) {
     const u8* const pStart = pIn;
     while (pIn + 8 <= pInLimit) {
@@ -102,18 +104,35 @@ typedef struct {
 } match_t;
 
 typedef struct {
+    // the statistics every price comes from (1.5 KB): while a block is parsed they live in LDS (OptLds below)
     u32 litFreq[O_MaxLit + 1], litLengthFreq[O_MaxLL + 1], matchLengthFreq[O_MaxML + 1],
         offCodeFreq[O_MaxOff + 1];
-    match_t matchTable[OPT_SIZE];
-    opt_t priceTable[OPT_SIZE];
     u32 litSum, litLengthSum, matchLengthSum, offCodeSum;
     u32 litSumBasePrice, litLengthSumBasePrice, matchLengthSumBasePrice, offCodeSumBasePrice;
     int predef; /* priceType == zop_predef */
+    // (in the wave's workspace only)
+    match_t matchTable[OPT_SIZE];
+    opt_t priceTable[OPT_SIZE];
 } optstate;
+// The parse is one serial region on lane 0, and 74 of its loads per input byte went to these tables in the wave's workspace
+// (SQ counters of 12 KiB text chunks, round 4: 65 % of the wave's cycles waiting for them).  The statistics, the matches of
+// the position at hand (at most 1 << searchLog + 4 = 20 at this size class) and the first OPT_LDS_N entries of the price table
+// -- the series of positions the parser is working on rarely grows beyond them -- are kept in LDS for the duration of
+// compressBlock_btopt (the 8 KB the entropy stage and the other finders use otherwise); entries beyond stay in the workspace.
+#define OPT_HOT_WORDS ((O_MaxLit + 1) + (O_MaxLL + 1) + (O_MaxML + 1) + (O_MaxOff + 1) + 4 + 4 + 1)
+#define OPT_LDS_N 224u
+#define OPT_LDS_MATCHES 32u
+typedef struct {
+    u32 hot[OPT_HOT_WORDS];
+    match_t matches[OPT_LDS_MATCHES];
+    opt_t win[OPT_LDS_N];
+} OptLds;
+static_assert(sizeof(OptLds) <= 8192, "fits the union of LdsState");
+static_assert(sizeof(opt_t) == 28 && offsetof(optstate, matchTable) == 4 * OPT_HOT_WORDS, "layout of the statistics");
 
 
 /* optLevel 0 => WEIGHT == ZSTD_bitWeight */
-SQ_DEVFN u32 opt_weight(u32 stat) { return highbit32(stat + 1) * BITCOST_MULTIPLIER; }
+SQ_DEV u32 opt_weight(u32 stat) { return highbit32(stat + 1) * BITCOST_MULTIPLIER; }
 
 SQ_DEVFN void opt_setBasePrices(optstate* o) {
     o->litSumBasePrice = opt_weight(o->litSum);
@@ -174,7 +193,7 @@ SQ_DEVFN void opt_rescaleFreqs(optstate* o, const u8* src, size_t srcSize) { /* 
     opt_setBasePrices(o);
 }
 
-SQ_DEVFN u32 opt_rawLiteralsCost(const u8* literals, u32 litLength, const optstate* o) {
+SQ_DEV u32 opt_rawLiteralsCost(const u8* literals, u32 litLength, const optstate* o) {
     if (litLength == 0) return 0;
     if (o->predef) return (litLength * 6) * BITCOST_MULTIPLIER;
     {
@@ -188,17 +207,20 @@ SQ_DEVFN u32 opt_rawLiteralsCost(const u8* literals, u32 litLength, const optsta
         return price;
     }
 }
-SQ_DEVFN u32 opt_litLengthPrice(u32 litLength, const optstate* o) {
+SQ_DEV u32 opt_litLengthPrice(u32 litLength, const optstate* o) {
     if (o->predef) return opt_weight(litLength);
-    if (litLength == BLOCKSIZE_MAX)
-        return BITCOST_MULTIPLIER + opt_litLengthPrice(BLOCKSIZE_MAX - 1, o);
+    u32 extra = 0;
+    if (litLength == BLOCKSIZE_MAX) { // (ZSTD_litLengthPrice prices 128 KiB as one bit more than 128 KiB - 1)
+        extra = BITCOST_MULTIPLIER;
+        litLength = BLOCKSIZE_MAX - 1;
+    }
     {
         u32 const llCode = zs_LLcode(litLength);
-        return (zs_LL_bits[llCode] * BITCOST_MULTIPLIER) + o->litLengthSumBasePrice -
+        return extra + (zs_LL_bits_of(llCode) * BITCOST_MULTIPLIER) + o->litLengthSumBasePrice -
                opt_weight(o->litLengthFreq[llCode]);
     }
 }
-SQ_DEVFN u32 opt_getMatchPrice(u32 offBase, u32 matchLength, const optstate* o) {
+SQ_DEV u32 opt_getMatchPrice(u32 offBase, u32 matchLength, const optstate* o) {
     u32 price;
     u32 const offCode = highbit32(offBase);
     u32 const mlBase = matchLength - MINMATCH;
@@ -208,7 +230,7 @@ SQ_DEVFN u32 opt_getMatchPrice(u32 offBase, u32 matchLength, const optstate* o) 
     if (offCode >= 20) price += (offCode - 19) * 2 * BITCOST_MULTIPLIER; /* optLevel < 2 */
     {
         u32 const mlCode = zs_MLcode(mlBase);
-        price += (zs_ML_bits[mlCode] * BITCOST_MULTIPLIER) +
+        price += (zs_ML_bits_of(mlCode) * BITCOST_MULTIPLIER) +
                  (o->matchLengthSumBasePrice - opt_weight(o->matchLengthFreq[mlCode]));
     }
     price += BITCOST_MULTIPLIER / 5;
@@ -459,8 +481,11 @@ SQ_DEVFN void opt_newRep(u32 out[REP_NUM], const u32 rep[REP_NUM], u32 offBase, 
 #endif
 
 /* ZSTD_compressBlock_opt_generic, optLevel 0, noDict */
-SQ_DEVFN size_t compressBlock_btopt(mstate* ms, seqstore* ss, u32 rep[REP_NUM], const u8* src, size_t srcSize) {
-    optstate* const o = (optstate*)ms->opt;
+SQ_DEVFN size_t compressBlock_btopt(mstate* ms, seqstore* ss, u32 rep[REP_NUM], const u8* src, size_t srcSize, void* ldsArea) {
+    optstate* const og = (optstate*)ms->opt; // (workspace)
+    OptLds* const lds = (OptLds*)ldsArea;
+    for (u32 i_ = 0; i_ < OPT_HOT_WORDS; i_++) lds->hot[i_] = ((const u32*)og)[i_];
+    optstate* const o = (optstate*)lds->hot; // (only the statistics: matchTable / priceTable are reached through og)
     const u8* const istart = src;
     const u8* ip = istart;
     const u8* anchor = istart;
@@ -472,8 +497,10 @@ SQ_DEVFN size_t compressBlock_btopt(mstate* ms, seqstore* ss, u32 rep[REP_NUM], 
     u32 const mls = ms->cp.minMatch < 3 ? 3 : (ms->cp.minMatch > 6 ? 6 : ms->cp.minMatch);
     u32 const minMatch = (ms->cp.minMatch == 3) ? 3 : 4;
     u32 nextToUpdate3 = ms->nextToUpdate;
-    opt_t* const opt = o->priceTable;
-    match_t* const matches = o->matchTable;
+    opt_t* const gopt = og->priceTable;
+    opt_t* const lopt = lds->win;
+#define OPTE(i_) (*(((u32)(i_)) < OPT_LDS_N ? &lopt[(i_)] : &gopt[(i_)]))
+    match_t* const matches = lds->matches;
     opt_t lastStretch;
     lastStretch.price = 0; lastStretch.off = lastStretch.mlen = lastStretch.litlen = 0; lastStretch.rep[0] = lastStretch.rep[1] = lastStretch.rep[2] = 0;
 
@@ -494,10 +521,10 @@ SQ_DEVFN size_t compressBlock_btopt(mstate* ms, seqstore* ss, u32 rep[REP_NUM], 
                 ip++;
                 continue;
             }
-            opt[0].mlen = 0;
-            opt[0].litlen = litlen;
-            opt[0].price = LL_PRICE(litlen);
-            opt[0].rep[0] = rep[0]; opt[0].rep[1] = rep[1]; opt[0].rep[2] = rep[2];
+            OPTE(0).mlen = 0;
+            OPTE(0).litlen = litlen;
+            OPTE(0).price = LL_PRICE(litlen);
+            OPTE(0).rep[0] = rep[0]; OPTE(0).rep[1] = rep[1]; OPTE(0).rep[2] = rep[2];
             {
                 u32 const maxML = matches[nbMatches - 1].len;
                 u32 const maxOffBase = matches[nbMatches - 1].off;
@@ -513,49 +540,49 @@ SQ_DEVFN size_t compressBlock_btopt(mstate* ms, seqstore* ss, u32 rep[REP_NUM], 
             {
                 u32 pos, matchNb;
                 for (pos = 1; pos < minMatch; pos++) {
-                    opt[pos].price = OPT_MAX_PRICE;
-                    opt[pos].mlen = 0;
-                    opt[pos].litlen = litlen + pos;
+                    OPTE(pos).price = OPT_MAX_PRICE;
+                    OPTE(pos).mlen = 0;
+                    OPTE(pos).litlen = litlen + pos;
                 }
                 for (matchNb = 0; matchNb < nbMatches; matchNb++) {
                     u32 const offBase = matches[matchNb].off;
                     u32 const end = matches[matchNb].len;
                     for (; pos <= end; pos++) {
                         int const matchPrice = (int)opt_getMatchPrice(offBase, pos, o);
-                        int const sequencePrice = opt[0].price + matchPrice;
-                        opt[pos].mlen = pos;
-                        opt[pos].off = offBase;
-                        opt[pos].litlen = 0;
-                        opt[pos].price = sequencePrice + LL_PRICE(0);
+                        int const sequencePrice = OPTE(0).price + matchPrice;
+                        OPTE(pos).mlen = pos;
+                        OPTE(pos).off = offBase;
+                        OPTE(pos).litlen = 0;
+                        OPTE(pos).price = sequencePrice + LL_PRICE(0);
                     }
                 }
                 last_pos = pos - 1;
-                opt[pos].price = OPT_MAX_PRICE;
+                OPTE(pos).price = OPT_MAX_PRICE;
             }
         }
         for (cur = 1; cur <= last_pos; cur++) {
             const u8* const inr = ip + cur;
             {
-                u32 const litlen = opt[cur - 1].litlen + 1;
-                int const price = opt[cur - 1].price + LIT_PRICE(ip + cur - 1) + LL_INCPRICE(litlen);
-                if (price <= opt[cur].price) {
-                    opt[cur] = opt[cur - 1];
-                    opt[cur].litlen = litlen;
-                    opt[cur].price = price;
+                u32 const litlen = OPTE(cur - 1).litlen + 1;
+                int const price = OPTE(cur - 1).price + LIT_PRICE(ip + cur - 1) + LL_INCPRICE(litlen);
+                if (price <= OPTE(cur).price) {
+                    OPTE(cur) = OPTE(cur - 1);
+                    OPTE(cur).litlen = litlen;
+                    OPTE(cur).price = price;
                 }
             }
-            if (opt[cur].litlen == 0) {
-                u32 const prev = cur - opt[cur].mlen;
-                opt_newRep(opt[cur].rep, opt[prev].rep, opt[cur].off, opt[prev].litlen == 0);
+            if (OPTE(cur).litlen == 0) {
+                u32 const prev = cur - OPTE(cur).mlen;
+                opt_newRep(OPTE(cur).rep, OPTE(prev).rep, OPTE(cur).off, OPTE(prev).litlen == 0);
             }
             if (inr > ilimit) continue;
             if (cur == last_pos) break;
-            if (opt[cur + 1].price <= opt[cur].price + (BITCOST_MULTIPLIER / 2)) continue;
+            if (OPTE(cur + 1).price <= OPTE(cur).price + (BITCOST_MULTIPLIER / 2)) continue;
             {
-                u32 const ll0 = (opt[cur].litlen == 0);
-                int const previousPrice = opt[cur].price;
+                u32 const ll0 = (OPTE(cur).litlen == 0);
+                int const previousPrice = OPTE(cur).price;
                 int const basePrice = previousPrice + LL_PRICE(0);
-                u32 nbMatches = btGetAllMatches(matches, ms, &nextToUpdate3, inr, iend, opt[cur].rep,
+                u32 nbMatches = btGetAllMatches(matches, ms, &nextToUpdate3, inr, iend, OPTE(cur).rep,
                                                 ll0, minMatch, mls);
                 u32 matchNb;
                 if (!nbMatches) continue;
@@ -578,25 +605,25 @@ SQ_DEVFN size_t compressBlock_btopt(mstate* ms, seqstore* ss, u32 rep[REP_NUM], 
                     for (mlen = lastML; mlen >= startML; mlen--) {
                         u32 const pos = cur + mlen;
                         int const price = basePrice + (int)opt_getMatchPrice(offset, mlen, o);
-                        if ((pos > last_pos) || (price < opt[pos].price)) {
+                        if ((pos > last_pos) || (price < OPTE(pos).price)) {
                             while (last_pos < pos) {
                                 last_pos++;
-                                opt[last_pos].price = OPT_MAX_PRICE;
-                                opt[last_pos].litlen = !0;
+                                OPTE(last_pos).price = OPT_MAX_PRICE;
+                                OPTE(last_pos).litlen = !0;
                             }
-                            opt[pos].mlen = mlen;
-                            opt[pos].off = offset;
-                            opt[pos].litlen = 0;
-                            opt[pos].price = price;
+                            OPTE(pos).mlen = mlen;
+                            OPTE(pos).off = offset;
+                            OPTE(pos).litlen = 0;
+                            OPTE(pos).price = price;
                         } else {
                             break; /* optLevel == 0 */
                         }
                     }
                 }
             }
-            opt[last_pos + 1].price = OPT_MAX_PRICE;
+            OPTE(last_pos + 1).price = OPT_MAX_PRICE;
         }
-        lastStretch = opt[last_pos];
+        lastStretch = OPTE(last_pos);
         cur = last_pos - lastStretch.mlen;
 
     _shortestPath:
@@ -606,7 +633,7 @@ SQ_DEVFN size_t compressBlock_btopt(mstate* ms, seqstore* ss, u32 rep[REP_NUM], 
         }
         if (lastStretch.litlen == 0) {
             u32 reps[REP_NUM];
-            opt_newRep(reps, opt[cur].rep, lastStretch.off, opt[cur].litlen == 0);
+            opt_newRep(reps, OPTE(cur).rep, lastStretch.off, OPTE(cur).litlen == 0);
             rep[0] = reps[0]; rep[1] = reps[1]; rep[2] = reps[2];
         } else {
             rep[0] = lastStretch.rep[0]; rep[1] = lastStretch.rep[1]; rep[2] = lastStretch.rep[2];
@@ -617,30 +644,30 @@ SQ_DEVFN size_t compressBlock_btopt(mstate* ms, seqstore* ss, u32 rep[REP_NUM], 
             u32 storeStart = storeEnd;
             u32 stretchPos = cur;
             if (lastStretch.litlen > 0) {
-                opt[storeEnd].litlen = lastStretch.litlen;
-                opt[storeEnd].mlen = 0;
+                OPTE(storeEnd).litlen = lastStretch.litlen;
+                OPTE(storeEnd).mlen = 0;
                 storeStart = storeEnd - 1;
-                opt[storeStart] = lastStretch;
+                OPTE(storeStart) = lastStretch;
             }
 #if SQZ_OPT_LASTSTRETCH_ELSE
             else
 #endif
             {
-                opt[storeEnd] = lastStretch;
+                OPTE(storeEnd) = lastStretch;
                 storeStart = storeEnd;
             }
             while (1) {
-                opt_t nextStretch = opt[stretchPos];
-                opt[storeStart].litlen = nextStretch.litlen;
+                opt_t nextStretch = OPTE(stretchPos);
+                OPTE(storeStart).litlen = nextStretch.litlen;
                 if (nextStretch.mlen == 0) break;
                 storeStart--;
-                opt[storeStart] = nextStretch;
+                OPTE(storeStart) = nextStretch;
                 stretchPos -= nextStretch.litlen + nextStretch.mlen;
             }
             for (u32 storePos = storeStart; storePos <= storeEnd; storePos++) {
-                u32 const llen = opt[storePos].litlen;
-                u32 const mlen = opt[storePos].mlen;
-                u32 const offBase = opt[storePos].off;
+                u32 const llen = OPTE(storePos).litlen;
+                u32 const mlen = OPTE(storePos).mlen;
+                u32 const offBase = OPTE(storePos).off;
                 u32 const advance = llen + mlen;
                 if (mlen == 0) {
                     ip = anchor + llen;
@@ -657,6 +684,8 @@ SQ_DEVFN size_t compressBlock_btopt(mstate* ms, seqstore* ss, u32 rep[REP_NUM], 
 #undef LIT_PRICE
 #undef LL_PRICE
 #undef LL_INCPRICE
+#undef OPTE
+    for (u32 i_ = 0; i_ < OPT_HOT_WORDS; i_++) ((u32*)og)[i_] = lds->hot[i_]; // (a later block of the chunk goes on from them)
     return (size_t)(iend - anchor);
 }
 
@@ -665,7 +694,5 @@ SQ_DEVFN size_t compressBlock_btopt(mstate* ms, seqstore* ss, u32 rep[REP_NUM], 
 #undef REP_NUM
 #undef WINDOW_START_INDEX
 #undef REPCODE_TO_OFFBASE
-#undef zs_LL_bits
-#undef zs_ML_bits
 } // namespace opt
 } // namespace sqz
