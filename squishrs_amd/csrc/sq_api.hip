@@ -177,7 +177,8 @@ struct sq_ctx {
     // s2_dense: the batch collected last left more than a quarter of its new chunks to stage 2.
     hipModule_t mod_s2w3 = nullptr;
     hipFunction_t f_s2w3 = nullptr;
-    bool s2_dense = false, s2_w3_last = false;
+    bool s2_dense = false, s2_w3_last = false, s2w3_tried = false;
+    bool s2w3_avail = false; // the file is there (checked at sq_ctx_create; the module itself is loaded when a batch first turns out compressible)
 };
 
 static bool is_device_ptr(const void* p) {
@@ -212,6 +213,31 @@ const char* sq_strerror(int err) {
 size_t sq_compress_bound(size_t n) {
     return n + (n >> 8) + ((n < (128u << 10)) ? (((128u << 10) - n) >> 11) : 0);
 }
+
+#ifndef SQ_NO_COMPRESS
+// The second build of the compressor kernel (squish_s2_w3.co beside the library; optional: without it every batch takes the
+// first).  Loaded when a batch first wants it, not in sq_ctx_create: hipModuleLoad costs ~0.1 s, which a small pack never
+// needs to pay.
+static std::string s2w3_path() {
+    Dl_info di;
+    if (getenv("SQ_NO_S2_W3") || !dladdr((const void*)&sq_ctx_create, &di) || !di.dli_fname) return std::string();
+    std::string path(di.dli_fname);
+    size_t const slash = path.find_last_of('/');
+    return (slash == std::string::npos ? std::string(".") : path.substr(0, slash)) + "/squish_s2_w3.co";
+}
+static void load_s2w3(sq_ctx* c) {
+    if (c->s2w3_tried) return;
+    c->s2w3_tried = true;
+    std::string const path = s2w3_path();
+    if (path.empty()) return;
+    if (hipModuleLoad(&c->mod_s2w3, path.c_str()) == hipSuccess) {
+        if (hipModuleGetFunction(&c->f_s2w3, c->mod_s2w3, SQZ_K_COMPRESS_BATCH_SYMBOL) != hipSuccess) c->f_s2w3 = nullptr;
+    } else
+        c->mod_s2w3 = nullptr;
+    (void)hipGetLastError();
+    if (!c->f_s2w3 && g_env.debug) fprintf(stderr, "[squish_gpu] %s not loaded: compressible batches use the 8-waves-per-CU kernel\n", path.c_str());
+}
+#endif
 
 int sq_ctx_create(const sq_config* cfg_in, sq_ctx** out) {
     if (!out) return SQ_E_INVAL;
@@ -293,19 +319,9 @@ int sq_ctx_create(const sq_config* cfg_in, sq_ctx** out) {
     }
 #endif
 #ifndef SQ_NO_COMPRESS
-    if (!getenv("SQ_NO_S2_W3")) { // the second build of the compressor kernel (optional: without it every batch takes the first)
-        Dl_info di;
-        if (dladdr((const void*)&sq_ctx_create, &di) && di.dli_fname) {
-            std::string path(di.dli_fname);
-            size_t const slash = path.find_last_of('/');
-            path = (slash == std::string::npos ? std::string(".") : path.substr(0, slash)) + "/squish_s2_w3.co";
-            if (hipModuleLoad(&c->mod_s2w3, path.c_str()) == hipSuccess) {
-                if (hipModuleGetFunction(&c->f_s2w3, c->mod_s2w3, SQZ_K_COMPRESS_BATCH_SYMBOL) != hipSuccess) c->f_s2w3 = nullptr;
-            } else
-                c->mod_s2w3 = nullptr;
-            (void)hipGetLastError();
-            if (!c->f_s2w3 && g_env.debug) fprintf(stderr, "[squish_gpu] %s not loaded: compressible batches use the 8-waves-per-CU kernel\n", path.c_str());
-        }
+    {
+        std::string const path = s2w3_path();
+        c->s2w3_avail = !path.empty() && access(path.c_str(), R_OK) == 0;
     }
 #endif
     *out = c;
@@ -619,6 +635,7 @@ static int compress_prepare(sq_ctx* c, sq_lane* L, const u32* h_len, u32 n, u8* 
     L->job_slots = in_place ? d_comp : (u8*)L->b_slots.p;
 
     // persistent compressor waves, one private workspace each
+    if (c->s2_dense && !c->cfg.compress_waves && !g_env.stage2_waves_per_cu) load_s2w3(c);
     bool const w3 = c->f_s2w3 != nullptr && c->s2_dense && !c->cfg.compress_waves && !g_env.stage2_waves_per_cu;
     L->job_s2w3 = w3;
     u32 waves = c->cfg.compress_waves ? c->cfg.compress_waves : (u32)c->num_cu * (w3 ? SQZ_STAGE2_WAVES_PER_CU : 8u);
@@ -628,7 +645,7 @@ static int compress_prepare(sq_ctx* c, sq_lane* L, const u32* h_len, u32 n, u8* 
     const size_t ws_each = sqz::workspace_bytes(max_len);
     // The pool is sized for the larger of the two builds' grids, so that a change of build between batches does not
     // reallocate it (12 GB and more); keep it within ~96 GiB
-    u32 pool_waves = (c->f_s2w3 != nullptr && !c->cfg.compress_waves && !g_env.stage2_waves_per_cu)
+    u32 pool_waves = ((c->s2w3_avail && (!c->s2w3_tried || c->f_s2w3 != nullptr)) && !c->cfg.compress_waves && !g_env.stage2_waves_per_cu)
                          ? std::min((u32)c->num_cu * SQZ_STAGE2_WAVES_PER_CU, n) : waves;
     while (pool_waves > 64 && (u64)pool_waves * ws_each > (96ull << 30)) pool_waves /= 2;
     waves = std::min(waves, pool_waves);
@@ -874,6 +891,7 @@ static int compress_finish(sq_ctx* c, sq_lane* L, u8* d_comp, u64 comp_cap, u64*
     c->s2_w3_last = L->job_s2w3;
     // (chooses the next batch's build of the kernel: stage 2's lists against what stage 1 decided -- duplicates are in neither)
     c->s2_dense = !fast || (u64)(h_err[2] + h_err[3]) * 3 > (u64)L->last.fast_decided;
+    if (c->s2_dense && !c->cfg.compress_waves && !g_env.stage2_waves_per_cu) load_s2w3(c); // (here, behind a collected batch: not on the next batch's way)
     L->work_n = fast ? n : 0;
     if (!*h_err) { // both kernels ran to completion: their saved table states are good for the next launch
         L->ws_ptr_last = L->b_ws.p;
@@ -1057,6 +1075,7 @@ int sq_compress_batch_slots(sq_ctx* c, const uint8_t* d_data, const uint64_t* h_
 
 int sq_debug_stage2_kernel(sq_ctx* c, uint32_t* loaded, uint32_t* used_last) {
     if (!c || !loaded || !used_last) return SQ_E_INVAL;
+    load_s2w3(c);
     *loaded = c->f_s2w3 != nullptr;
     *used_last = c->s2_w3_last;
     return SQ_OK;
