@@ -614,6 +614,14 @@ static uint64_t pack_multi(const std::string& input, const std::string& output, 
             if (sh->failed.compare_exchange_strong(expect, 1)) snprintf(sh->msg, sizeof(sh->msg), "%s", m.c_str());
         };
         sq_ctx* ctx = nullptr;
+        double t_ctx = 0, t_alloc = 0, t_read = 0, t_h2d = 0, t_hash = 0, t_rest = 0, t_d2h = 0, t_write = 0, t_bar = 0; // SQUISH_TIMING=1
+        // (page-locking costs ~0.2 s per GiB and only pays on large inputs: as in the one-GPU path)
+        uint64_t total_bytes = 0;
+        for (uint64_t z : sizes) total_bytes += z;
+        bool pin = total_bytes / (uint64_t)world >= (16ull << 30);
+        if (const char* e = getenv("SQUISH_PINNED")) pin = atoi(e) != 0;
+        auto host_alloc = [&](size_t n) -> uint8_t* { return pin ? (uint8_t*)sq_host_alloc(n) : (uint8_t*)malloc(n); };
+        auto host_free = [&](uint8_t* q) { if (!q) return; if (pin) sq_host_free(q); else free(q); };
         uint8_t *h_in = nullptr, *h_comp = nullptr;
         uint8_t *d_data = nullptr, *d_hashes = nullptr, *d_all = nullptr, *d_isnew = nullptr, *d_comp = nullptr;
         uint32_t* d_idx = nullptr;
@@ -626,7 +634,9 @@ static uint64_t pack_multi(const std::string& input, const std::string& output, 
             cfg.abi_version = SQ_ABI_VERSION;
             cfg.device = devices[(size_t)rank];
             cfg.dedup_capacity = total + 1024;
+            double const tc0 = now_s();
             check(sq_ctx_create(&cfg, &ctx), "sq_ctx_create");
+            t_ctx = now_s() - tc0;
             out_fd = open(output.c_str(), O_WRONLY);
             if (out_fd < 0) throw AppError{std::string("I/O error: ") + strerror(errno)};
         } catch (const AppError& e) {
@@ -654,19 +664,20 @@ static uint64_t pack_multi(const std::string& input, const std::string& output, 
                         comp_need += sq_compress_bound(c.len) + 64;
                     }
                 uint32_t const n = (uint32_t)mine.size();
+                double const ta0 = now_s();
                 if (used + 4096 > cap_in) { // (buffers grow to the largest super-batch and stay)
-                    if (h_in) sq_host_free(h_in);
+                    host_free(h_in);
                     sq_dev_free(ctx, d_data);
                     cap_in = used + (used >> 3) + 4096;
-                    h_in = (uint8_t*)sq_host_alloc(cap_in);
+                    h_in = host_alloc(cap_in);
                     d_data = (uint8_t*)sq_dev_alloc(ctx, cap_in);
                     if (!h_in || !d_data) throw AppError{"I/O error: out of memory"};
                 }
                 if (comp_need > cap_comp) {
-                    if (h_comp) sq_host_free(h_comp);
+                    host_free(h_comp);
                     sq_dev_free(ctx, d_comp);
                     cap_comp = comp_need + (comp_need >> 3);
-                    h_comp = (uint8_t*)sq_host_alloc(cap_comp);
+                    h_comp = host_alloc(cap_comp);
                     d_comp = (uint8_t*)sq_dev_alloc(ctx, cap_comp);
                     if (!h_comp || !d_comp) throw AppError{"I/O error: out of memory"};
                 }
@@ -679,7 +690,9 @@ static uint64_t pack_multi(const std::string& input, const std::string& output, 
                     d_all = (uint8_t*)sq_dev_alloc(ctx, (size_t)B * 16);
                     if (!d_hashes || !d_isnew || !d_idx || !d_all) throw AppError{"I/O error: out of memory"};
                 }
-                {   // this rank's chunks: up to -j reader threads, pread straight into the page-locked buffer
+                t_alloc += now_s() - ta0;
+                double const tr0 = now_s();
+                {   // this rank's chunks: up to -j reader threads, pread straight into the input buffer
                     std::atomic<size_t> next{0};
                     std::string rerr;
                     std::mutex rmu;
@@ -717,20 +730,26 @@ static uint64_t pack_multi(const std::string& input, const std::string& output, 
                     for (auto& t : pool) t.join();
                     if (!rerr.empty()) throw AppError{rerr};
                 }
+                t_read += now_s() - tr0;
+                double const th0 = now_s();
                 check(sq_dev_copy(ctx, d_data, h_in, used, 1), "copy to the device");
+                t_h2d += now_s() - th0;
+                double const tk0 = now_s();
                 check(sq_shard_submit_hash(ctx, d_data, off.data(), len.data(), n, d_hashes), "sq_shard_submit_hash");
                 check(sq_shard_wait_hash(ctx), "sq_shard_wait_hash");
+                t_hash += now_s() - tk0;
                 hashes.resize((size_t)n * 16 + 16);
                 check(sq_dev_copy(ctx, hashes.data(), d_hashes, (size_t)n * 16, 0), "copy from the device");
                 for (uint32_t i = 0; i < n; i++) memcpy(all_hashes + (size_t)(g0 + mine[i]) * 16, &hashes[(size_t)16 * i], 16);
             } catch (const AppError& e) {
                 if (!e.msg.empty()) fail(e.msg);
             }
-            pthread_barrier_wait(&sh->bar); // every rank's hashes of the super-batch are in the table
+            { double const tb0 = now_s(); pthread_barrier_wait(&sh->bar); t_bar += now_s() - tb0; } // every rank's hashes of the super-batch are in the table
             uint32_t const n = (uint32_t)mine.size();
             bool submitted = false;
             try {
                 if (sh->failed) throw AppError{""};
+                double const tr1 = now_s();
                 check(sq_dev_copy(ctx, d_all, all_hashes + (size_t)g0 * 16, (size_t)nb * 16, 1), "copy to the device");
                 check(sq_dev_copy(ctx, d_idx, mine.data(), (size_t)n * 4, 1), "copy to the device");
                 check(sq_shard_submit_rest_idx(ctx, d_all, nb, n ? d_idx : nullptr, d_isnew, d_comp, cap_comp, 0), "sq_shard_submit_rest_idx");
@@ -738,6 +757,8 @@ static uint64_t pack_multi(const std::string& input, const std::string& output, 
                 woff.resize((size_t)n + 1);
                 wlen.resize((size_t)n + 1);
                 check(sq_pack_wait(ctx, woff.data(), wlen.data()), "sq_pack_wait");
+                t_rest += now_s() - tr1;
+                double const td0 = now_s();
                 isnew.resize((size_t)n + 16);
                 check(sq_dev_copy(ctx, isnew.data(), d_isnew, n, 0), "copy from the device");
                 uint64_t end = 0;
@@ -746,11 +767,13 @@ static uint64_t pack_multi(const std::string& input, const std::string& output, 
                     if (isnew[i]) end = std::max<uint64_t>(end, woff[i] + wlen[i]);
                 }
                 check(sq_dev_copy(ctx, h_comp, d_comp, end, 0), "copy from the device");
+                t_d2h += now_s() - td0;
             } catch (const AppError& e) {
                 if (!e.msg.empty()) fail(e.msg);
                 (void)submitted;
             }
-            pthread_barrier_wait(&sh->bar); // every record's size is known to every rank
+            { double const tb0 = now_s(); pthread_barrier_wait(&sh->bar); t_bar += now_s() - tb0; } // every record's size is known to every rank
+            double const tw0 = now_s();
             try {
                 if (sh->failed) throw AppError{""};
                 // where the records go: a prefix sum over the global order (fsutil/writer.rs:21-36: hash || original_size ||
@@ -796,8 +819,12 @@ static uint64_t pack_multi(const std::string& input, const std::string& output, 
             } catch (const AppError& e) {
                 if (!e.msg.empty()) fail(e.msg);
             }
+            t_write += now_s() - tw0;
         }
         pthread_barrier_wait(&sh->bar); // every record is written
+        if (getenv("SQUISH_TIMING"))
+            fprintf(stderr, "[squishrs timing] rank %d of %d: ctx_create %.3f s, buffers %.3f, file reads %.3f, to the device %.3f, hash %.3f, dedup + compress %.3f, "
+                            "from the device %.3f, record writes %.3f, at barriers %.3f\n", rank, world, t_ctx, t_alloc, t_read, t_h2d, t_hash, t_rest, t_d2h, t_write, t_bar);
         if (rank == 0 && !sh->failed) {
             try { // writer.rs:177-184 (chunk count), 292-329 (manifest)
                 std::string m;
@@ -826,8 +853,8 @@ static uint64_t pack_multi(const std::string& input, const std::string& output, 
         if (out_fd >= 0) close(out_fd);
         if (ctx) {
             for (void* p : {(void*)d_data, (void*)d_hashes, (void*)d_all, (void*)d_isnew, (void*)d_comp, (void*)d_idx}) sq_dev_free(ctx, p);
-            if (h_in) sq_host_free(h_in);
-            if (h_comp) sq_host_free(h_comp);
+            host_free(h_in);
+            host_free(h_comp);
             sq_ctx_destroy(ctx);
         }
         return sh->failed ? 1 : 0;
