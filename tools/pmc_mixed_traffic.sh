@@ -1,6 +1,6 @@
 #!/bin/bash
 # HBM traffic of the compress kernel on 2 MiB mixed / text chunks (rocprofv3 FETCH_SIZE and WRITE_SIZE in separate
-# passes, release library, tools/prof_mixed.py: two launches on the same lane, the LAST one = steady state).  GPU box.
+# passes, release library, tools/prof_mixed.py: three launches on the same lane, the LAST one = steady state).  GPU box.
 # Writes gpurun_out/pmc_mixed_traffic/summary.json (copy to profiles/pmc_traffic_mixed.json: bench.py quotes it in the
 # configs[3] leg as traffic_ratio = (fetched + written) / algorithmic bytes).
 set -u
@@ -12,7 +12,8 @@ cd /tmp && export TMPDIR=/tmp
 for kind in ${PMC_MIXED_KINDS:-mixed text}; do
   for C in FETCH_SIZE WRITE_SIZE; do
     rm -rf $O/${kind}_$C
-    rocprofv3 --pmc $C --kernel-include-regex "sqz::k_compress" --output-format csv -d $O/${kind}_$C -- python3 $R/tools/prof_mixed.py $N 64 $kind > $O/${kind}_$C.log 2> $O/${kind}_$C.err
+    echo "$kind $C ..." >> $O/progress.log
+    SQ_NO_FORK=1 PROF_WARMUPS=2 timeout -k 10 300 rocprofv3 --pmc $C --kernel-include-regex "sqz::k_compress" --output-format csv -d $O/${kind}_$C -- python3 $R/tools/prof_mixed.py $N 64 $kind > $O/${kind}_$C.log 2> $O/${kind}_$C.err
     echo "$kind $C rc=$?" >> $O/progress.log
   done
 done
