@@ -32,7 +32,7 @@ def make_case(rng):
     sched = corpus.lazy_schedule(n)
     t = rng.choice(sched[len(sched) // 16:])
     ln = rng.choice([4, 4, 4, 4, 4, 4, 5, 6, 8, 12])
-    kind = rng.choice(["plain", "plain", "plain", "back", "second", "behind", "depth", "bucket", "rep1", "late"])
+    kind = rng.choice(["plain", "plain", "plain", "back", "second", "behind", "behind4", "behind4", "depth", "bucket", "rep1", "late"])
     if t < 200 or t + ln + 16 > n:
         return None, kind
     src = rng.randrange(2, t - ln - 8)
@@ -49,6 +49,16 @@ def make_case(rng):
         s3 = rng.randrange(2, t - 8)
         if u + 6 < n:
             b[u:u + 5] = b[s3:s3 + 5]
+    elif kind == "behind4":  # ONE more short match on the new schedule's dense start (stage 1's third pass), sometimes a third
+        u = t + ln + rng.randrange(0, 200)
+        s3 = rng.randrange(2, t - 8)
+        if u + 8 < n:
+            b[u:u + 4] = b[s3:s3 + 4]
+            if rng.random() < 0.25:
+                u2 = u + 4 + rng.randrange(0, 100)
+                s7 = rng.randrange(2, t - 8)
+                if u2 + 8 < n:
+                    b[u2:u2 + 4] = b[s7:s7 + 4]
     elif kind == "depth":    # the depth searches at t + 1 / t + 2 find something
         s4 = rng.randrange(2, t - 16)
         d = rng.choice([1, 2])
