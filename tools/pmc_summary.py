@@ -57,7 +57,7 @@ for k, ck in out["kernels"].items():
         t[f"{k}@{L}"] = {"fetch_bytes_per_chunk": ck["FETCH_SIZE"] * 1024 / n,
                          "write_bytes_per_chunk": ck["WRITE_SIZE"] * 1024 / n,
                          "stream_read_bytes_per_chunk": STREAM.get(k, 0),
-                         "measured_on_chunks": n, "source": f"profiles/{tag}_pmc.json",
+                         "measured_on_chunks": n, "source": f"profiles/{name_out}_pmc.json",
                          "note": "per chunk of the BATCH (stage 2 handles the chunks stage 1 leaves undecided: 0.7 % of random ones since round 4); corrected traffic = fetch + "
                                  "stream_read/2 + write (FETCH_SIZE tallies a coalesced streaming read at half on gfx950)"}
         print(k, json.dumps(t[f"{k}@{L}"]))
