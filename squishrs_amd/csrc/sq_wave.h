@@ -52,7 +52,11 @@ SQ_DEV void wv_mem_sync_inv() {
 SQ_DEV u32 wv_uni(u32 v) { return v; }
 SQ_DEV u64 wv_uni64(u64 v) { return v; }
 SQ_DEV void wv_fence() {}
+#ifdef SQ_SIM_TRIPS
+SQ_DEV void wv_mem_sync();
+#else
 SQ_DEV void wv_mem_sync() {}
+#endif
 SQ_DEV void wv_mem_sync_inv() {}
 #endif
 
@@ -65,6 +69,26 @@ SQ_DEV void wv_mem_sync_inv() {}
 #define WV_SERIAL if (1)
 #endif
 
+// (simulator build with -DSQ_SIM_TRIPS: count the dependent trips to memory -- a uniform load the wave waits for, a drain --
+// by the phase the match finder says it is in: tools/sim_trips.py)
+#if !SQ_ON_DEVICE && defined(SQ_SIM_TRIPS)
+static thread_local unsigned long long g_sim_trips[16];
+static thread_local int g_sim_phase;
+struct SimPhase {
+    int old;
+    explicit SimPhase(int p) : old(g_sim_phase) { g_sim_phase = p; }
+    ~SimPhase() { g_sim_phase = old; }
+};
+#define SQ_TRIP() (g_sim_trips[g_sim_phase]++)
+#define SQ_TRIP_EXT() (g_sim_trips[7]++) // (a tree step's second trip: the strings agree in the eight bytes read with the node)
+#define SQ_TRIP_PHASE(p) SimPhase sq_trip_phase_##p(p)
+SQ_DEV void wv_mem_sync() { g_sim_trips[8 + (g_sim_phase & 7)]++; } // (drains: counted apart, 8 + phase)
+#else
+#define SQ_TRIP() ((void)0)
+#define SQ_TRIP_EXT() ((void)0)
+#define SQ_TRIP_PHASE(p) ((void)0)
+#endif
+
 // ---- uniform global memory access: all lanes read one address; lane 0 alone writes ------------
 // The loads are relaxed agent-scope ATOMIC loads on purpose: a plain load from a wave-uniform
 // address is turned into s_load_dword by hipcc, and the scalar data cache is not coherent with
@@ -74,6 +98,7 @@ SQ_DEV u32 gld32(const u32* p) {
 #if SQ_ON_DEVICE
     return wv_uni(__hip_atomic_load((const SQ_G u32*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
 #else
+    SQ_TRIP();
     return *p;
 #endif
 }
@@ -113,8 +138,8 @@ SQ_DEV void gst8(u8* p, u32 v) {
 #endif
 }
 // uniform unaligned source reads (chunk bytes are never written by the kernel)
-SQ_DEV u32 srd32(const u8* p) { return wv_uni(sq_grd32(p)); }
-SQ_DEV u64 srd64(const u8* p) { return wv_uni64(sq_grd64(p)); }
+SQ_DEV u32 srd32(const u8* p) { SQ_TRIP(); return wv_uni(sq_grd32(p)); }
+SQ_DEV u64 srd64(const u8* p) { SQ_TRIP(); return wv_uni64(sq_grd64(p)); }
 SQ_DEV u32 srd16(const u8* p) { return wv_uni(sq_grd16(p)); }
 SQ_DEV u32 srd8(const u8* p) { return wv_uni(sq_grd8(p)); }
 
@@ -152,6 +177,9 @@ SQ_DEV u32 wv_count(const u8* a, const u8* b, u32 maxLen) {
 #else
     u32 n = 0;
     while (n < maxLen && a[n] == b[n]) n++;
+    SQ_TRIP();
+    if (maxLen >= 8 && n >= 8)
+        for (u32 base = 0; base <= n && base < maxLen; base += 512) SQ_TRIP();
     return n;
 #endif
 }
@@ -163,6 +191,7 @@ SQ_DEV void gld_pair(const u32* p, u32* a, u32* b) {
     *a = wv_uni((u32)v);
     *b = wv_uni((u32)(v >> 32));
 #else
+    SQ_TRIP();
     *a = p[0];
     *b = p[1];
 #endif
@@ -186,6 +215,7 @@ SQ_DEV void wv_tree_step_loads(const u32* p, const u8* a, const u8* b, bool have
     *wa = wv_uni64(x);
     *wb = wv_uni64(y);
 #else
+    SQ_TRIP();
     *c0 = p[0];
     *c1 = p[1];
     *wa = *wb = 0;
@@ -242,6 +272,10 @@ SQ_DEV u32 wv_count_cmp(const u8* a, const u8* b, u32 maxLen, u32* bLess, bool p
     u32 n = 0;
     while (n < maxLen && a[n] == b[n]) n++;
     if (n < maxLen) *bLess = b[n] < a[n];
+    if (!pre && maxLen >= 8) SQ_TRIP();
+    if (n >= 8 || maxLen < 8)
+        for (u32 base = 0; base <= n && base < maxLen; base += 512) SQ_TRIP_EXT();
+    (void)wa0; (void)wb0;
     return n;
 #endif
 }

@@ -1554,6 +1554,7 @@ SQ_DEVFN u32 cert_rep_recheck(MatchState& ms, u32 off1, u32 limit) {
 
 // ZSTD_updateDUBT
 SQ_DEVFN void dubt_update(MatchState& ms, u32 target) {
+    SQ_TRIP_PHASE(6);
     dubt_insert_range<0>(ms, ms.nextToUpdate, target);
     ms.nextToUpdate = target;
 }
@@ -1574,7 +1575,33 @@ SQ_DEVFN void dubt_update(MatchState& ms, u32 target) {
 SQ_DEV void bt_store(u32* bt, u32* dummy, u32 slot, u32 v, u32 have = SQZ_BT_UNKNOWN) {
     if (have != v) gst32(slot == SQZ_BT_DUMMY ? dummy : bt + slot, v);
 }
-SQ_DEVFN void dubt_insert1(MatchState& ms, u32 curr_, const u8* inputEnd, u32 nbCompares_, u32 btLow_) {
+// The unsorted chain of a bucket as the search's first pass over it (dubt_materialize) saw it: (index, next, mark) per node,
+// oldest last.  The pass that threads the candidates (dubt_search_core) and the insertions that follow read the same words
+// again -- one trip to memory each, 3k + 1 trips for k candidates on a path whose whole cost is trips -- so they
+// are kept in LDS instead (the last quarter of g_lds.scr; lane 0 writes, every lane reads the same word).
+#define SQZ_SCAN_CACHE 64u
+SQ_DEV void scan_cache_put(u32 i, u32 idx, u32 nx, u32 mk) {
+    if (i >= SQZ_SCAN_CACHE) return;
+    SQ_L u32* const c = (SQ_L u32*)g_lds.scr + 768 + 3 * i;
+#if SQ_ON_DEVICE
+    if (wv_lane() == 0)
+#endif
+    {
+        c[0] = idx;
+        c[1] = nx;
+        c[2] = mk;
+    }
+}
+SQ_DEV void scan_cache_get(u32 i, u32* idx, u32* nx, u32* mk) {
+    SQ_L u32* const c = (SQ_L u32*)g_lds.scr + 768 + 3 * i;
+    wv_fence();
+    *idx = wv_uni(c[0]);
+    *nx = wv_uni(c[1]);
+    *mk = wv_uni(c[2]);
+}
+
+// (first_, link_: what curr's two slots hold -- its bucket's older head, the thread to the next candidate)
+SQ_DEVFN void dubt_insert1(MatchState& ms, u32 curr_, const u8* inputEnd, u32 nbCompares_, u32 btLow_, u32 first_, u32 link_) {
     u32* const bt = (u32*)wv_uni64((u64)(size_t)ms.chainTable);
     u32* const dummy = (u32*)wv_uni64((u64)(size_t)ms.dummy);
     u32 const btMask = (1u << (wv_uni(ms.cp.chainLog) - 1)) - 1;
@@ -1585,8 +1612,9 @@ SQ_DEVFN void dubt_insert1(MatchState& ms, u32 curr_, const u8* inputEnd, u32 nb
     const u8* const ip = base + curr;
     u32 const ipRoom = wv_uni((u32)(inputEnd - ip));
     u32 smallerSlot = 2 * (curr & btMask), largerSlot = smallerSlot + 1;
-    u32 smallerHas = SQZ_BT_UNKNOWN, largerHas = SQZ_BT_UNKNOWN; // what those slots are known to hold (bt_store)
-    u32 matchIndex = gld32(bt + smallerSlot);
+    SQ_TRIP_PHASE(4);
+    u32 matchIndex = wv_uni(first_);
+    u32 smallerHas = matchIndex, largerHas = wv_uni(link_); // what those slots are known to hold (bt_store)
     u32 const windowLow = SQZ_WINDOW_START; // window always covers the whole chunk (see get_cparams)
     for (; nbCompares && (matchIndex > windowLow); --nbCompares) {
         if (matchIndex >= curr) {
@@ -1641,8 +1669,10 @@ SQ_DEVFN void dubt_insert1(MatchState& ms, u32 curr_, const u8* inputEnd, u32 nb
 // Body of ZSTD_DUBT_findBestMatch (noDict, mls 4) for the position `curr`, given the bucket head
 // as it was when `curr` was reached: sorts the unsorted candidates, walks the tree, makes `curr`
 // the root.  Does not touch the hash table.
+// nCached: the bucket's first nodes as dubt_materialize's last pass left them in the scan cache (0: none)
 SQ_DEVFN u32 dubt_search_core(MatchState& ms, u32 curr_, const u8* const iend, u32 const headIndex_, u32* offBasePtr,
-                              u32* matchEndIdxOut) {
+                              u32* matchEndIdxOut, u32 nCached_ = 0, bool drain = true) {
+    SQ_TRIP_PHASE(5);
     // (wave-uniform copies of what the walk reads from the finder's state: see dubt_insert1)
     const u8* const base = (const u8*)wv_uni64((u64)(size_t)ms.base);
     u32 const curr = wv_uni(curr_), headIndex = wv_uni(headIndex_);
@@ -1660,29 +1690,60 @@ SQ_DEVFN u32 dubt_search_core(MatchState& ms, u32 curr_, const u8* const iend, u
     u32 previousCandidate = 0;
     u32 const ipRoom = wv_uni((u32)(iend - ip));
     {
-        // one 8-byte load per visited candidate: (next candidate, sort mark)
-        u32 nextC = 0, mark = 0;
-        if (matchIndex > unsortLimit) gld_pair(bt + candSlot, &nextC, &mark);
+        // one 8-byte load per visited candidate: (next candidate, sort mark) -- from the scan cache where the pass before
+        // this one has read it already, and into the cache otherwise: the insertions below start from it
+        SQ_TRIP_PHASE(3);
+        u32 const nCached = wv_uni(nCached_);
+        u32 nextC = 0, mark = 0, nVisited = 0, nCand = 0;
+        auto visit = [&]() {
+            u32 at = 0;
+            if (nVisited < nCached)
+                scan_cache_get(nVisited, &at, &nextC, &mark);
+            else {
+                gld_pair(bt + candSlot, &nextC, &mark);
+                scan_cache_put(nVisited, matchIndex, nextC, mark);
+                at = matchIndex;
+            }
+            if (at != matchIndex) ms.fault = 1; // (cannot happen: the cache is this bucket's chain, in order)
+            nVisited++;
+        };
+        if (matchIndex > unsortLimit) visit();
         while ((matchIndex > unsortLimit) && (mark == SQZ_DUBT_UNSORTED) && (nbCandidates > 1)) {
             gst32(bt + candSlot + 1, previousCandidate);
             previousCandidate = matchIndex;
             matchIndex = nextC;
             candSlot = 2 * (matchIndex & btMask);
             nbCandidates--;
-            if (matchIndex > unsortLimit) gld_pair(bt + candSlot, &nextC, &mark);
+            nCand++;
+            if (matchIndex > unsortLimit) visit();
         }
+        bool reread = nCand > SQZ_SCAN_CACHE; // (the threads of the candidates beyond the cache are read back below)
         if ((matchIndex > unsortLimit) && (mark == SQZ_DUBT_UNSORTED)) {
             gst32(bt + candSlot, 0);
             gst32(bt + candSlot + 1, 0);
+            reread = true; // (the oldest candidate's walk starts at this node)
         }
-    }
-    wv_mem_sync();
-    matchIndex = previousCandidate;
-    while (matchIndex) {
-        u32 const nextCandidateIdx = gld32(bt + 2 * (matchIndex & btMask) + 1);
-        dubt_insert1(ms, matchIndex, iend, nbCandidates, unsortLimit);
-        matchIndex = nextCandidateIdx;
-        nbCandidates++;
+        if (reread) wv_mem_sync(); // (otherwise nothing written above is loaded again: the waits are the walks' own)
+        // the candidates, oldest first: node nCand - 1 of the scan down to node 0; each one's slots hold (the node after it
+        // in the scan, the node before it: the thread written above)
+        matchIndex = previousCandidate;
+        for (u32 i = nCand; i-- > 0;) {
+            u32 first, link;
+            if (i < SQZ_SCAN_CACHE) {
+                u32 at, mk;
+                scan_cache_get(i, &at, &first, &mk);
+                if (at != matchIndex) ms.fault = 1;
+                link = 0;
+                if (i > 0) {
+                    u32 f2;
+                    scan_cache_get(i - 1, &link, &f2, &mk);
+                }
+            } else
+                gld_pair(bt + 2 * (matchIndex & btMask), &first, &link);
+            dubt_insert1(ms, matchIndex, iend, nbCandidates, unsortLimit, first, link);
+            matchIndex = link;
+            nbCandidates++;
+        }
     }
     u32 commonLengthSmaller = 0, commonLengthLarger = 0;
     u32 smallerSlot = 2 * (curr & btMask), largerSlot = smallerSlot + 1;
@@ -1745,7 +1806,7 @@ SQ_DEVFN u32 dubt_search_core(MatchState& ms, u32 curr_, const u8* const iend, u
     }
     bt_store(bt, dummy, smallerSlot, 0, smallerHas);
     bt_store(bt, dummy, largerSlot, 0, largerHas);
-    wv_mem_sync();
+    if (drain) wv_mem_sync(); // (dubt_find has one more word to write and waits for all of them once)
     *offBasePtr = offBase;
     *matchEndIdxOut = matchEndIdx;
     return bestLength;
@@ -1764,15 +1825,19 @@ SQ_DEV u32 block_end_of(const MatchState& ms, u32 pos) {
 // SQZ_DUBT_SEARCHED and whose `next` is the bucket head at their time.  Before an exact search may
 // use the bucket they are replayed, oldest first, with the very same search body: replaying the
 // search of node s only touches nodes older than s, so the result is the state libzstd would hold.
-SQ_DEVFN void dubt_materialize(MatchState& ms, u32 headIndex) {
+// Returns how many of the bucket's first nodes its last pass -- the one that found nothing left to replay -- has put into
+// the scan cache.
+SQ_DEVFN u32 dubt_materialize(MatchState& ms, u32 headIndex) {
+    SQ_TRIP_PHASE(2);
     u32* const bt = ms.chainTable;
     u32 const btMask = (1u << (ms.cp.chainLog - 1)) - 1;
     for (;;) {
-        u32 found = 0, foundNext = 0;
+        u32 found = 0, foundNext = 0, n = 0;
         u32 idx = headIndex;
         while (idx > SQZ_WINDOW_START) {
             u32 nx, mk;
             gld_pair(bt + 2 * (idx & btMask), &nx, &mk);
+            scan_cache_put(n++, idx, nx, mk);
             if (mk == SQZ_DUBT_SEARCHED) {
                 found = idx;
                 foundNext = nx;
@@ -1780,20 +1845,21 @@ SQ_DEVFN void dubt_materialize(MatchState& ms, u32 headIndex) {
                 break; // sorted node: nothing deferred below it
             if (nx >= idx) { // cannot happen in a well-formed chain
                 ms.fault = 1;
-                return;
+                return 0;
             }
             idx = nx;
         }
-        if (!found) return;
+        if (!found) return n < SQZ_SCAN_CACHE ? n : SQZ_SCAN_CACHE;
         u32 off = 999999999, mend = 0;
         ms.nReplay++;
         (void)dubt_search_core(ms, found, ms.base + block_end_of(ms, found), foundNext, &off, &mend);
-        if (ms.fault) return;
+        if (ms.fault) return 0;
     }
 }
 
 // ZSTD_DUBT_findBestMatch (noDict, mls 4)
 SQ_DEVFN u32 dubt_find(MatchState& ms, const u8* const ip, const u8* const iend, u32* offBasePtr) {
+    SQ_TRIP_PHASE(1);
     u32* const hashTable = ms.hashTable;
     u32 const h = hash4(srd32(ip), ms.cp.hashLog);
     u32 const curr = (u32)(ip - ms.base);
@@ -1804,9 +1870,9 @@ SQ_DEVFN u32 dubt_find(MatchState& ms, const u8* const ip, const u8* const iend,
         headWord = ht_dec(ms, gld32(hashTable + h));
     }
     u32 const headIndex = headWord & SQZ_HT_IDX;
-    dubt_materialize(ms, headIndex);
+    u32 const nCached = dubt_materialize(ms, headIndex);
     u32 matchEndIdx = curr + 9;
-    u32 const bestLength = dubt_search_core(ms, curr, iend, headIndex, offBasePtr, &matchEndIdx);
+    u32 const bestLength = dubt_search_core(ms, curr, iend, headIndex, offBasePtr, &matchEndIdx, nCached, false);
     gst32(hashTable + h, ht_enc(ms, curr | (headWord & ~SQZ_HT_IDX)));
     wv_mem_sync();
     if (matchEndIdx - 8 > curr + 1) filter_add_skip(ms, curr + 1, matchEndIdx - 8);

@@ -142,3 +142,12 @@ extern "C" void sim_rb_stats(unsigned long long* out) {
         sqz::g_sim_rb_stats[k] = 0;
     }
 }
+#ifdef SQ_SIM_TRIPS
+// (tools/sim_trips.py) dependent trips to memory counted by the simulator since the last call: 8 load counts by phase, then 8 drain counts
+extern "C" void sim_trip_counts(unsigned long long* out) {
+    for (int i = 0; i < 16; i++) {
+        out[i] = g_sim_trips[i];
+        g_sim_trips[i] = 0;
+    }
+}
+#endif
