@@ -31,6 +31,9 @@ struct sq_env {
                              // the lane's second stream (pack_enqueue).  Built and measured in round 4: the step is the same 18.0-18.1 ms
                              // either way (profiles/round4c_s2_early_ab.txt) -- it is the sum of the kernels' work, not a gap -- so the
                              // plain order stays the default
+    bool aux_prio = false;   // SQ_AUX_PRIO=1 (experiment, with SQ_S2_EARLY=1): the lanes' second streams are created at the device's highest
+                             // stream priority, so that the hash finish / dedup kernels on them are dispatched ahead of the next batch's
+                             // stage 1 when both become ready at the end of this batch's stage 1
     int stage1_grid = -1; // SQ_STAGE1_GRID: 1 = one workgroup per chunk instead of persistent workgroups (experiment)
     int fuse_hash = -1; // SQ_FUSE_HASH: 0 never, 1 always, unset: chosen per batch from the previous batch's duplicate ratio
     bool allow_any_arch = false;
@@ -54,6 +57,7 @@ static void sq_env_read_once() {
     if (const char* e = getenv("SQ_STAGE1_GRID")) g_env.stage1_grid = atoi(e);
     if (const char* e = getenv("SQ_S1_AFTER_S2")) g_env.s1_after_s2 = atoi(e) != 0;
     if (const char* e = getenv("SQ_S2_EARLY")) g_env.s2_early = atoi(e) != 0;
+    if (const char* e = getenv("SQ_AUX_PRIO")) g_env.aux_prio = atoi(e) != 0;
 }
 
 #define HIPCHK(x)                                                                                  \
@@ -268,6 +272,8 @@ int sq_ctx_create(const sq_config* cfg_in, sq_ctx** out) {
     c->cfg = cfg;
     c->device = cfg.device;
     c->num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    int prio_least = 0, prio_greatest = 0;
+    if (g_env.aux_prio) (void)hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest);
     for (sq_lane& ln : c->ln) {
         sq_lane* const L = &ln;
         if (hipStreamCreateWithFlags(&L->stream, hipStreamNonBlocking) != hipSuccess) {
@@ -283,7 +289,8 @@ int sq_ctx_create(const sq_config* cfg_in, sq_ctx** out) {
         if (hipEventCreateWithFlags(&L->dedup_done, hipEventDisableTiming) != hipSuccess ||
             hipEventCreateWithFlags(&L->pre_s2, hipEventDisableTiming) != hipSuccess ||
             hipEventCreateWithFlags(&L->s1_done, hipEventDisableTiming) != hipSuccess ||
-            hipStreamCreateWithFlags(&L->aux, hipStreamNonBlocking) != hipSuccess ||
+            (g_env.aux_prio ? hipStreamCreateWithPriority(&L->aux, hipStreamNonBlocking, prio_greatest)
+                            : hipStreamCreateWithFlags(&L->aux, hipStreamNonBlocking)) != hipSuccess ||
             hipHostMalloc(&L->h_pinned, 4096, hipHostMallocDefault) != hipSuccess) {
             sq_ctx_destroy(c);
             return SQ_E_NOMEM;

@@ -223,3 +223,21 @@ def test_sim_one_short_match_second_pass(sim):
     import re
     m = re.search(r"blocks decided by the second pass (\d+)", r.stdout)
     assert m and int(m.group(1)) >= 15, r.stdout
+
+
+def test_gpu_test_helpers_need_no_simulator_library():
+    """tests/test_one_match_gpu.py imports tools/fuzz_one_match_sim.py for its make_case on the GPU box, where nothing has
+    built tests/sim/libsq_sim.so (the CPU tests build it, build() does not): the import must not load the library."""
+    import subprocess
+    import sys
+    code = ("import sys; sys.path.insert(0, %r); sys.path.insert(0, %r); import ctypes; real = ctypes.CDLL\n"
+            "def guard(name, *a, **k):\n"
+            "    assert 'libsq_sim' not in str(name), name\n"
+            "    return real(name, *a, **k)\n"
+            "ctypes.CDLL = guard\n"
+            "import random, fuzz_one_match_sim as f\n"
+            "assert f._sim is None\n"
+            "got = sum(f.make_case(random.Random(i))[0] is not None for i in range(20))\n"
+            "assert got >= 10 and f._sim is None, got\n") % (os.path.join(ROOT, "tools"), os.path.join(ROOT, "tests"))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr

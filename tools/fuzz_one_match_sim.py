@@ -8,12 +8,23 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT + '/tools'); sys.path.insert(0, ROOT + '/tests')
 import corpus, oracle_lib
 o = oracle_lib.load()
-s = ctypes.CDLL(ROOT + '/tests/sim/libsq_sim.so')
-s.sim_compress_two_stage.restype = ctypes.c_size_t
-s.sim_compress_two_stage.argtypes = [ctypes.c_char_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_size_t, ctypes.POINTER(ctypes.c_int)]
+_sim = None
+
+
+def sim():
+    """the simulator build of the product's kernels (tests/test_sim_cpu.py builds it), loaded at first use: make_case is
+    also imported by tests/test_one_match_gpu.py on the GPU box, which needs no simulator"""
+    global _sim
+    if _sim is None:
+        _sim = ctypes.CDLL(ROOT + '/tests/sim/libsq_sim.so')
+        _sim.sim_compress_two_stage.restype = ctypes.c_size_t
+        _sim.sim_compress_two_stage.argtypes = [ctypes.c_char_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_size_t,
+                                                ctypes.POINTER(ctypes.c_int)]
+    return _sim
 
 
 def two(d):
+    s = sim()
     cap = len(d) + (len(d) >> 8) + 1024
     dst = ctypes.create_string_buffer(cap)
     dec = ctypes.c_int(0)
@@ -93,6 +104,7 @@ def run(seed, cases, verbose=True):
     decided = 0
     per = {}
     t0 = time.time()
+    s = sim()
     before = s.sim_one_match_blocks()
     for it in range(cases):
         d, kind = make_case(rng)
