@@ -216,11 +216,13 @@ static uint64_t pack(const std::string& input, const std::string& output, int de
     uint64_t total_bytes = 0;
     for (uint64_t z : sizes) total_bytes += z;
     // batch size: the configured one, but no larger than an eighth of the input (four batches rotate through the
-    // stages, two of them in flight on the GPU: enough batches for the stages to overlap) -- and not below 256 MiB:
-    // the compressor runs one wave per chunk, a compressible 2 MiB chunk takes a wave the better part of a second,
-    // so a small input must reach the GPU in one or two batches for its chunks to be compressed side by side (small inputs should not pay
-    // for page-locking gigabytes they never fill)
-    uint64_t eff_batch = std::max<uint64_t>(std::min<uint64_t>(batch_bytes, std::max<uint64_t>(total_bytes / 8 + SQ_CHUNK_SIZE, 256ull << 20)), 8u << 20);
+    // stages, two of them in flight on the GPU: enough batches for the stages to overlap) -- and not below 1 GiB:
+    // the compressor runs one wave per chunk, a compressible chunk takes a wave the better part of a second (a 256 KiB
+    // text chunk: two), and the compressor launches of two batches do not fit the GPU side by side -- so the GPU stage
+    // of a compressible tree takes (batches) x (its slowest chunk), and a small input must reach the GPU in ONE batch
+    // (256 MiB until the end of round 4: a 388 MiB tree went in two batches and its GPU stage took 3.3 s instead of
+    // one batch's 1.8; profiles/round4h_cli_soak_batch_floor.txt)
+    uint64_t eff_batch = std::max<uint64_t>(std::min<uint64_t>(batch_bytes, std::max<uint64_t>(total_bytes / 8 + SQ_CHUNK_SIZE, 1ull << 30)), 8u << 20);
     {   // ... and the four batches' input + output buffers (2 x 4 x eff_batch) within half of the memory the host has
         // available (MemAvailable): a small machine packs a large tree in more, smaller batches instead of being
         // killed for lack of memory
