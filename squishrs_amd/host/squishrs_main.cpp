@@ -40,6 +40,7 @@
 #include <filesystem>
 #include <condition_variable>
 #include <map>
+#include <memory>
 #include <mutex>
 #include <thread>
 #include <unordered_map>
@@ -222,7 +223,9 @@ static uint64_t pack(const std::string& input, const std::string& output, int de
     // of a compressible tree takes (batches) x (its slowest chunk), and a small input must reach the GPU in ONE batch
     // (256 MiB until the end of round 4: a 388 MiB tree went in two batches and its GPU stage took 3.3 s instead of
     // one batch's 1.8; profiles/round4h_cli_soak_batch_floor.txt)
-    uint64_t eff_batch = std::max<uint64_t>(std::min<uint64_t>(batch_bytes, std::max<uint64_t>(total_bytes / 8 + SQ_CHUNK_SIZE, 1ull << 30)), 8u << 20);
+    uint64_t floor_bytes = 1ull << 30;
+    if (const char* e = getenv("SQUISH_BATCH_FLOOR")) floor_bytes = std::max<uint64_t>(strtoull(e, nullptr, 10), 8u << 20); // (experiments)
+    uint64_t eff_batch = std::max<uint64_t>(std::min<uint64_t>(batch_bytes, std::max<uint64_t>(total_bytes / 8 + SQ_CHUNK_SIZE, floor_bytes)), 8u << 20);
     {   // ... and the four batches' input + output buffers (2 x 4 x eff_batch) within half of the memory the host has
         // available (MemAvailable): a small machine packs a large tree in more, smaller batches instead of being
         // killed for lack of memory
@@ -902,9 +905,36 @@ struct Summary {
     uint64_t archive_size = 0, total_orig = 0, unique_chunks = 0, timestamp = 0;
     std::string version;
     std::vector<std::pair<std::string, uint64_t>> files;
+    bool bad_utf8 = false;
 };
 static void rd(FILE* f, void* p, size_t n) {
     if (fread(p, 1, n, f) != n) throw AppError{"Error reading from squish: failed to fill whole buffer"};
+}
+// String::from_utf8's rule (reader.rs:178,350): well-formed UTF-8, no overlong forms, no surrogates, nothing above U+10FFFF
+static bool valid_utf8(const std::string& s) {
+    size_t i = 0, n = s.size();
+    auto cont = [&](size_t k) { return k < n && ((uint8_t)s[k] & 0xC0) == 0x80; };
+    while (i < n) {
+        uint8_t const c = (uint8_t)s[i];
+        if (c < 0x80) {
+            i += 1;
+        } else if (c >= 0xC2 && c <= 0xDF) {
+            if (!cont(i + 1)) return false;
+            i += 2;
+        } else if (c >= 0xE0 && c <= 0xEF) {
+            if (!cont(i + 1) || !cont(i + 2)) return false;
+            uint8_t const d = (uint8_t)s[i + 1];
+            if ((c == 0xE0 && d < 0xA0) || (c == 0xED && d > 0x9F)) return false;
+            i += 3;
+        } else if (c >= 0xF0 && c <= 0xF4) {
+            if (!cont(i + 1) || !cont(i + 2) || !cont(i + 3)) return false;
+            uint8_t const d = (uint8_t)s[i + 1];
+            if ((c == 0xF0 && d < 0x90) || (c == 0xF4 && d > 0x8F)) return false;
+            i += 4;
+        } else
+            return false;
+    }
+    return true;
 }
 static Summary read_summary(const std::string& path) {
     FILE* f = fopen(path.c_str(), "rb");
@@ -943,6 +973,10 @@ static Summary read_summary(const std::string& path) {
         rd(f, &plen, 4);
         std::string p(plen, '\0');
         rd(f, &p[0], plen);
+        if (!valid_utf8(p)) { // get_summary's String::from_utf8 (reader.rs:178) ends the pass here: `list` reports it,
+            s.bad_utf8 = true; // `unpack` (which only takes the header fields from this summary) at its own pass over the table
+            break;
+        }
         rd(f, &osz, 8);
         rd(f, &cc, 4);
         fseek(f, (long)cc * 16, SEEK_CUR);
@@ -962,6 +996,7 @@ static std::string date_of(uint64_t ts) { // header.rs:87-95 "%H:%M %d/%m/%Y" lo
 }
 static void list_cmd(const std::string& squish, bool simple) {
     Summary s = read_summary(squish);
+    if (s.bad_utf8) throw AppError{"Illegal UTF8 detected"};
     double ratio = s.total_orig ? (double)s.archive_size / (double)s.total_orig * 100.0 : 0.0;
     if (simple) { // lib.rs:67-80
         printf("squish_size(bytes): %" PRIu64 ", original_size(bytes): %" PRIu64
@@ -1021,6 +1056,18 @@ static void list_cmd(const std::string& squish, bool simple) {
 // decoded by zstd_frame_decoder.hpp with the record's original_size as the capacity
 // (zstd::bulk::decompress(&compressed_data, orig_size), reader.rs:302-303).
 static std::string os_error(int e) { return std::string(strerror(e)) + " (os error " + std::to_string(e) + ")"; }
+// Frame_Content_Size of a zstd frame header (RFC 8878 3.1.1.1), if the header carries one.
+static bool frame_content_size(const uint8_t* p, size_t n, uint64_t* fcs) {
+    if (n < 6 || p[0] != 0x28 || p[1] != 0xB5 || p[2] != 0x2F || p[3] != 0xFD) return false;
+    unsigned const fhd = p[4], flag = fhd >> 6, single = (fhd >> 5) & 1, did = fhd & 3;
+    size_t const pos = 5 + (single ? 0 : 1) + (did == 0 ? 0 : did == 1 ? 1 : did == 2 ? 2 : 4);
+    size_t const fsz = flag == 0 ? (single ? 1 : 0) : flag == 1 ? 2 : flag == 2 ? 4 : 8;
+    if (fsz == 0 || pos + fsz > n) return false;
+    uint64_t v = 0;
+    for (size_t k = 0; k < fsz; k++) v |= (uint64_t)p[pos + k] << (8 * k);
+    *fcs = fsz == 2 ? v + 256 : v;
+    return true;
+}
 static void unpack_cmd(const std::string& squish, const std::string& outdir, long threads, int device) {
     Summary hdr = read_summary(squish); // ArchiveReader::new: header / version checks, table offsets
     FILE* f = fopen(squish.c_str(), "rb");
@@ -1029,20 +1076,58 @@ static void unpack_cmd(const std::string& squish, const std::string& outdir, lon
     struct Rec {
         std::string hash;
         uint64_t osz;
+        const uint8_t* fptr = nullptr; // the record's frame: a stretch of the mapped archive, or `frame` (no mapping)
+        size_t flen = 0;
         std::vector<uint8_t> frame, data;
+        const uint8_t* dptr = nullptr; // the decoded bytes: `data`, or a stretch of a GPU batch's output buffer (outs)
+        size_t dlen = 0;
         std::string err;
     };
     std::vector<Rec> recs((size_t)hdr.unique_chunks);
-    for (auto& r : recs) {
-        uint64_t csz;
-        r.hash.resize(16);
-        rd(f, &r.hash[0], 16);
-        rd(f, &r.osz, 8);
-        rd(f, &csz, 8);
-        if (csz > hdr.archive_size) throw AppError{"Error reading from squish: failed to fill whole buffer"};
-        r.frame.resize((size_t)csz);
-        rd(f, r.frame.data(), (size_t)csz);
+    double const t_read0 = now_s();
+    std::vector<std::unique_ptr<uint8_t[]>> outs; // GPU decode: every batch's output buffer stays alive until the files are written
+    // The records (read_chunks, reader.rs:259-314).  The archive is mapped and a record's frame is a view of the mapping (the
+    // reference reads each into a Vec; here 8.6 GB of frames took 2.1 s to copy out of the page cache before anything was
+    // decoded); without a mapping every frame is read into a buffer of its own as before.
+    struct Mapping {
+        const uint8_t* p = nullptr;
+        size_t n = 0;
+        ~Mapping() { if (p) munmap((void*)p, n); }
+    } map;
+    if (hdr.archive_size > 0 && !getenv("SQUISH_NO_MMAP")) {
+        void* m = mmap(nullptr, (size_t)hdr.archive_size, PROT_READ, MAP_PRIVATE | MAP_POPULATE, fileno(f), 0);
+        if (m != MAP_FAILED) map.p = (const uint8_t*)m, map.n = (size_t)hdr.archive_size;
     }
+    if (map.p) {
+        uint64_t pos = 27;
+        for (auto& r : recs) {
+            if (pos + 32 > map.n) throw AppError{"Error reading from squish: failed to fill whole buffer"};
+            uint64_t csz;
+            r.hash.assign((const char*)map.p + pos, 16);
+            memcpy(&r.osz, map.p + pos + 16, 8);
+            memcpy(&csz, map.p + pos + 24, 8);
+            if (csz > hdr.archive_size || pos + 32 + csz > map.n) throw AppError{"Error reading from squish: failed to fill whole buffer"};
+            r.fptr = map.p + pos + 32;
+            r.flen = (size_t)csz;
+            pos += 32 + csz;
+        }
+        if (fseek(f, (long)pos, SEEK_SET)) throw AppError{"Error reading from squish: seek"};
+    } else {
+        for (auto& r : recs) {
+            uint64_t csz;
+            r.hash.resize(16);
+            rd(f, &r.hash[0], 16);
+            rd(f, &r.osz, 8);
+            rd(f, &csz, 8);
+            if (csz > hdr.archive_size) throw AppError{"Error reading from squish: failed to fill whole buffer"};
+            r.frame.resize((size_t)csz);
+            rd(f, r.frame.data(), (size_t)csz);
+            r.fptr = r.frame.data();
+            r.flen = r.frame.size();
+        }
+    }
+    if (getenv("SQUISH_TIMING"))
+        fprintf(stderr, "[squishrs timing] unpack: %zu records %s in %.3f s\n", recs.size(), map.p ? "mapped" : "read", now_s() - t_read0);
     // Where the frames are decoded: on the GPU (sq_decompress_batch: one wavefront per record, batches of records whose
     // outputs fit 4 GiB) when a gfx950 device is there and the archive is large, on host threads (zstd_frame_decoder.hpp,
     // the same statement of RFC 8878) otherwise -- `unpack` and `list` must work on a machine without a GPU, as the
@@ -1074,23 +1159,36 @@ static void unpack_cmd(const std::string& squish, const std::string& outdir, lon
         double const t0 = now_s();
         if (ctx) {
             on_gpu = true;
+            // A record's output needs no more room than its frame says it holds: the recorded original size is the
+            // capacity zstd::bulk::decompress gets (reader.rs:302-303) and the pack path records 2 MiB for EVERY chunk
+            // (writer.rs:255), so 32,768 chunks of 256 KiB used to travel back as 16 batches of 4 GiB, an eighth of
+            // it data.  With min(recorded size, Frame_Content_Size) the batches' buffers hold the data back to back
+            // (to 16 bytes) and are kept as they are: the files are rebuilt from them without another copy.
             uint64_t const out_budget = 4ull << 30;
             size_t i0 = 0;
-            std::vector<uint8_t> in, out;
-            std::vector<uint64_t> off, ooff;
+            std::unique_ptr<uint8_t[]> in;
+            size_t in_cap = 0;
+            double t_alloc = 0, t_fill = 0, t_call = 0; // (t_fill includes t_alloc)
+            int n_batches = 0;
+            std::vector<uint64_t> off, ooff, want(recs.size());
             std::vector<uint32_t> len, ocap, olen, stat;
+            for (size_t i = 0; i < recs.size(); i++) {
+                uint64_t fcs = 0;
+                want[i] = recs[i].osz;
+                if (frame_content_size(recs[i].fptr, recs[i].flen, &fcs) && fcs < want[i]) want[i] = fcs;
+            }
             while (i0 < recs.size()) {
                 size_t i1 = i0;
                 uint64_t in_bytes = 0, out_bytes = 0;
-                while (i1 < recs.size() && (i1 == i0 || (out_bytes + recs[i1].osz <= out_budget && in_bytes + recs[i1].frame.size() <= out_budget))) {
-                    if (recs[i1].osz > 0xFFFFFFFFull || recs[i1].frame.size() > 0xFFFFFFFFull) break;
-                    in_bytes += (recs[i1].frame.size() + 15) & ~(uint64_t)15;
-                    out_bytes += (recs[i1].osz + 15) & ~(uint64_t)15;
+                while (i1 < recs.size() && (i1 == i0 || (out_bytes + want[i1] <= out_budget && in_bytes + recs[i1].flen <= out_budget))) {
+                    if (want[i1] > 0xFFFFFFFFull || recs[i1].flen > 0xFFFFFFFFull) break;
+                    in_bytes += (recs[i1].flen + 15) & ~(uint64_t)15;
+                    out_bytes += (want[i1] + 15) & ~(uint64_t)15;
                     i1++;
                 }
                 if (i1 == i0) { // a record no batch can take (> 4 GiB): the host decoder's business
                     try {
-                        recs[i0].data = zfd::decompress(recs[i0].frame.data(), recs[i0].frame.size(), (size_t)recs[i0].osz);
+                        recs[i0].data = zfd::decompress(recs[i0].fptr, recs[i0].flen, (size_t)recs[i0].osz);
                     } catch (const zfd::DecodeError& e) {
                         recs[i0].err = e.msg;
                     }
@@ -1098,22 +1196,55 @@ static void unpack_cmd(const std::string& squish, const std::string& outdir, lon
                     continue;
                 }
                 size_t const n = i1 - i0;
-                in.resize((size_t)in_bytes + 16);
-                out.resize((size_t)out_bytes + 16);
+                double const ta = now_s();
+                if ((size_t)in_bytes + 16 > in_cap) {
+                    in.reset();
+                    in.reset(new uint8_t[(size_t)in_bytes + 16]); // (not zero-filled: every byte the decoder reads is written below)
+                    in_cap = (size_t)in_bytes + 16;
+                }
+                outs.emplace_back(new uint8_t[(size_t)out_bytes + 16]);
+                uint8_t* const out = outs.back().get();
+                t_alloc += now_s() - ta;
                 off.resize(n), ooff.resize(n), len.resize(n), ocap.resize(n), olen.assign(n, 0), stat.assign(n, 0);
                 uint64_t a = 0, b = 0;
                 for (size_t k = 0; k < n; k++) {
                     Rec& r = recs[i0 + k];
                     off[k] = a;
-                    len[k] = (uint32_t)r.frame.size();
-                    if (!r.frame.empty()) memcpy(in.data() + a, r.frame.data(), r.frame.size());
-                    a += (r.frame.size() + 15) & ~(uint64_t)15;
+                    len[k] = (uint32_t)r.flen;
+                    a += (r.flen + 15) & ~(uint64_t)15;
                     ooff[k] = b;
-                    ocap[k] = (uint32_t)r.osz;
-                    b += (r.osz + 15) & ~(uint64_t)15;
+                    ocap[k] = (uint32_t)want[i0 + k];
+                    b += (want[i0 + k] + 15) & ~(uint64_t)15;
                 }
-                int const rc = sq_decompress_batch(ctx, in.data(), off.data(), len.data(), (uint32_t)n, out.data(), ooff.data(), ocap.data(),
+                memset(in.get() + a, 0, 16);
+                {   // the frames into the batch buffer, on up to -j threads (8.6 GB out of the page cache: 0.9 s on one)
+                    uint8_t* const dst = in.get();
+                    std::atomic<size_t> nextk{0};
+                    auto copy = [&]() {
+                        for (;;) {
+                            size_t const k0 = nextk.fetch_add(64);
+                            if (k0 >= n) return;
+                            for (size_t k = k0; k < std::min(n, k0 + 64); k++) {
+                                const Rec& r = recs[i0 + k];
+                                if (r.flen) memcpy(dst + off[k], r.fptr, r.flen);
+                                size_t const pad = (size_t)(((r.flen + 15) & ~(uint64_t)15) - r.flen);
+                                if (pad) memset(dst + off[k] + r.flen, 0, pad);
+                            }
+                        }
+                    };
+                    unsigned const hw = std::thread::hardware_concurrency();
+                    size_t const nt = std::min<size_t>((size_t)std::max(1L, std::min<long>(threads, hw ? (long)hw : 1L)), (n + 63) / 64);
+                    std::vector<std::thread> pool;
+                    for (size_t t = 1; t < nt; t++) pool.emplace_back(copy);
+                    copy();
+                    for (auto& t : pool) t.join();
+                }
+                double const tb = now_s();
+                t_fill += tb - ta;
+                int const rc = sq_decompress_batch(ctx, in.get(), off.data(), len.data(), (uint32_t)n, out, ooff.data(), ocap.data(),
                                                    olen.data(), stat.data());
+                t_call += now_s() - tb;
+                n_batches++;
                 if (rc != SQ_OK && rc != SQ_E_DECOMPRESS) {
                     sq_ctx_destroy(ctx);
                     throw AppError{std::string("sq_decompress_batch: ") + sq_strerror(rc)};
@@ -1123,12 +1254,16 @@ static void unpack_cmd(const std::string& squish, const std::string& outdir, lon
                     if (stat[k])
                         r.err = sq_decompress_strerror(stat[k]);
                     else
-                        r.data.assign(out.data() + ooff[k], out.data() + ooff[k] + olen[k]);
+                        r.dptr = out + ooff[k], r.dlen = olen[k]; // (no copy: the batch's buffer is kept)
                     std::vector<uint8_t>().swap(r.frame);
                 }
                 i0 = i1;
             }
+            double const td = now_s();
             sq_ctx_destroy(ctx);
+            if (getenv("SQUISH_TIMING"))
+                fprintf(stderr, "[squishrs timing] unpack: %d GPU batches: buffers %.3f s, frames into the batch buffer %.3f s, sq_decompress_batch %.3f s, ctx_destroy %.3f s\n",
+                        n_batches, t_alloc, t_fill - t_alloc, t_call, now_s() - td);
         } else {
             std::atomic<size_t> next{0};
             auto work = [&]() {
@@ -1136,7 +1271,7 @@ static void unpack_cmd(const std::string& squish, const std::string& outdir, lon
                     size_t const i = next.fetch_add(1);
                     if (i >= recs.size()) return;
                     try {
-                        recs[i].data = zfd::decompress(recs[i].frame.data(), recs[i].frame.size(), (size_t)recs[i].osz);
+                        recs[i].data = zfd::decompress(recs[i].fptr, recs[i].flen, (size_t)recs[i].osz);
                     } catch (const zfd::DecodeError& e) {
                         recs[i].err = e.msg;
                     }
@@ -1154,51 +1289,99 @@ static void unpack_cmd(const std::string& squish, const std::string& outdir, lon
         if (getenv("SQUISH_TIMING"))
             fprintf(stderr, "[squishrs timing] unpack: %zu records decoded on the %s in %.3f s\n", recs.size(), on_gpu ? "GPU" : "host", now_s() - t0);
     }
-    std::unordered_map<std::string, const std::vector<uint8_t>*> chunk_map;
+    struct View {
+        const uint8_t* p;
+        size_t n;
+    };
+    std::unordered_map<std::string, View> chunk_map;
     for (auto& r : recs) {
         if (!r.err.empty()) throw AppError{"Error reading from squish: " + r.err};
-        chunk_map[r.hash] = &r.data;
+        chunk_map[r.hash] = r.dptr ? View{r.dptr, r.dlen} : View{r.data.data(), r.data.size()};
     }
-    // file table
+    // file table: ALL entries are read first (rebuild_files, reader.rs:337-375: a damaged table is an error before any
+    // file is created), then the files are rebuilt in parallel (reader.rs:378-407, entries.par_iter() on the -j pool)
+    struct Entry {
+        std::string rel;
+        std::vector<std::string> hashes;
+        std::string err;
+    };
     uint32_t nfiles;
     rd(f, &nfiles, 4);
-    namespace fs = std::filesystem;
+    std::vector<Entry> entries;
     for (uint32_t i = 0; i < nfiles; i++) {
         uint32_t plen, cc;
         uint64_t osz;
         rd(f, &plen, 4);
         if (plen > hdr.archive_size) throw AppError{"Error reading from squish: failed to fill whole buffer"};
-        std::string rel(plen, '\0');
-        rd(f, &rel[0], plen);
+        Entry e;
+        e.rel.assign(plen, '\0');
+        rd(f, &e.rel[0], plen);
+        if (!valid_utf8(e.rel)) throw AppError{"Illegal UTF8 detected"}; // reader.rs:350
         rd(f, &osz, 8);
         rd(f, &cc, 4);
         if ((uint64_t)cc * 16 > hdr.archive_size) throw AppError{"Error reading from squish: failed to fill whole buffer"};
-        std::vector<std::string> hashes(cc, std::string(16, '\0'));
-        for (auto& h : hashes) rd(f, &h[0], 16);
-        fs::path const full = fs::path(outdir) / fs::path(rel); // Path::join: an absolute `rel` replaces outdir
-        if (full.has_parent_path()) {
-            std::error_code ec;
-            fs::create_directories(full.parent_path(), ec);
-            if (ec) throw AppError{"Error creating directory `" + full.parent_path().string() + "`: " + os_error(ec.value())};
-        }
-        FILE* o = fopen(full.c_str(), "wb");
-        if (!o) throw AppError{"Error creating file `" + full.string() + "`: " + os_error(errno)};
-        for (auto& h : hashes) {
-            auto it = chunk_map.find(h);
-            if (it == chunk_map.end()) {
-                fclose(o);
-                throw AppError{"Missing Chunk for File: `" + rel + "`"};
-            }
-            const std::vector<uint8_t>& d = *it->second;
-            if (!d.empty() && fwrite(d.data(), 1, d.size(), o) != d.size()) {
-                int const e = errno;
-                fclose(o);
-                throw AppError{"Error creating directory `" + rel + "`: " + os_error(e)}; // (sic) reader.rs:392-394
-            }
-        }
-        if (fclose(o)) throw AppError{"Error creating directory `" + rel + "`: " + os_error(errno)};
+        e.hashes.assign(cc, std::string(16, '\0'));
+        for (auto& h : e.hashes) rd(f, &h[0], 16);
+        entries.push_back(std::move(e));
     }
     fclose(f);
+    namespace fs = std::filesystem;
+    std::atomic<size_t> next_file{0};
+    std::atomic<bool> failed{false};
+    auto rebuild = [&]() {
+        for (;;) {
+            size_t const i = next_file.fetch_add(1);
+            if (i >= entries.size() || failed.load()) return; // (try_for_each: nobody starts a new file after a failure)
+            Entry& e = entries[i];
+            fs::path const full = fs::path(outdir) / fs::path(e.rel); // Path::join: an absolute `rel` replaces outdir
+            if (full.has_parent_path()) {
+                std::error_code ec;
+                fs::create_directories(full.parent_path(), ec);
+                if (ec && !fs::is_directory(full.parent_path())) { // (another thread may have been creating the same directory)
+                    e.err = "Error creating directory `" + full.parent_path().string() + "`: " + os_error(ec.value());
+                    failed.store(true);
+                    return;
+                }
+            }
+            FILE* o = fopen(full.c_str(), "wb");
+            if (!o) {
+                e.err = "Error creating file `" + full.string() + "`: " + os_error(errno);
+                failed.store(true);
+                return;
+            }
+            for (auto& h : e.hashes) {
+                auto it = chunk_map.find(h);
+                if (it == chunk_map.end()) {
+                    e.err = "Missing Chunk for File: `" + e.rel + "`";
+                    break;
+                }
+                View const d = it->second;
+                if (d.n && fwrite(d.p, 1, d.n, o) != d.n) {
+                    e.err = "Error creating directory `" + e.rel + "`: " + os_error(errno); // (sic) reader.rs:392-394
+                    break;
+                }
+            }
+            if (fclose(o) && e.err.empty()) e.err = "Error creating directory `" + e.rel + "`: " + os_error(errno);
+            if (!e.err.empty()) {
+                failed.store(true);
+                return;
+            }
+        }
+    };
+    {
+        unsigned const hw = std::thread::hardware_concurrency();
+        size_t nt = (size_t)std::max(1L, std::min<long>(threads, hw ? (long)hw : 1L));
+        nt = std::min(nt, std::max<size_t>(1, entries.size()));
+        double const t0 = now_s();
+        std::vector<std::thread> pool;
+        for (size_t t = 1; t < nt; t++) pool.emplace_back(rebuild);
+        rebuild();
+        for (auto& t : pool) t.join();
+        if (getenv("SQUISH_TIMING"))
+            fprintf(stderr, "[squishrs timing] unpack: %zu files rebuilt by %zu threads in %.3f s\n", entries.size(), nt, now_s() - t0);
+    }
+    for (auto& e : entries) // the first failure in table order
+        if (!e.err.empty()) throw AppError{e.err};
 }
 
 // clap's behaviour for `squishrs` (cmd/mod.rs:11-58): -h/--help prints the help on stdout and exits 0; an unknown

@@ -220,3 +220,75 @@ def test_cli_clap_behaviour_and_list_tables(tmp_path, oracle):
     assert lines[i + 5].startswith("| small ") and lines[i + 6].startswith("+-")
     r = _run("list", str(arch), "--simple")
     assert r.returncode == 0 and "number_of_files: 1234" in r.stdout
+
+
+def _archive_raw(records, files, ts=0):
+    """as _archive, but the paths are bytes (any bytes)"""
+    b = bytearray(b"squish1.2.0") + struct.pack("<QQ", ts, len(records))
+    for h, osz, fr in records:
+        b += h + struct.pack("<QQ", osz, len(fr)) + fr
+    b += struct.pack("<I", len(files))
+    for p, size, hashes in files:
+        b += struct.pack("<I", len(p)) + p + struct.pack("<QI", size, len(hashes)) + b"".join(hashes)
+    return bytes(b)
+
+
+def test_illegal_utf8_paths_and_table_read_before_any_file(tmp_path, oracle):
+    """reader.rs:178,350: a path that is not UTF-8 is AppError::IllegalUTF8 for `list` and `unpack`; rebuild_files reads the WHOLE
+    file table before it creates a file (reader.rs:337-375), so a table damaged at its end leaves the output directory empty."""
+    h0 = b"\x07" * 16
+    data = b"squish " * 40
+    fr = oracle.compress_chunk(data)
+    for bad in (b"a\xffb.txt", b"\xc0\xaf.txt", b"\xed\xa0\x80.txt", b"\xf4\x90\x80\x80", b"trunc\xe2\x82"):
+        a = tmp_path / "u.squish"
+        a.write_bytes(_archive_raw([(h0, 2 << 20, fr)], [(b"ok.txt", len(data), [h0]), (bad, len(data), [h0])]))
+        out = tmp_path / ("o_" + bad.hex())
+        r = _run("unpack", str(a), "-o", str(out))
+        assert r.returncode == 1 and "Illegal UTF8 detected" in r.stderr, (bad, r.stderr)
+        assert not out.exists() or _tree(out) == {}, "a file was created before the table had been read"
+        r = _run("list", str(a), "--simple")
+        assert r.returncode == 1 and "Illegal UTF8 detected" in r.stderr, (bad, r.stderr)
+    # well-formed multi-byte paths pass
+    a = tmp_path / "v.squish"
+    name = "déjà/文件-\U0001F600.txt"
+    a.write_bytes(_archive([(h0, 2 << 20, fr)], [(name, len(data), [h0])]))
+    r = _run("unpack", str(a), "-o", str(tmp_path / "ov"))
+    assert r.returncode == 0, r.stderr
+    assert _tree(tmp_path / "ov") == {name: data}
+    # table cut short after its first (good) entry: nothing is written
+    whole = _archive([(h0, 2 << 20, fr)], [("first.txt", len(data), [h0]), ("second.txt", len(data), [h0])])
+    a.write_bytes(whole[:-7])
+    r = _run("unpack", str(a), "-o", str(tmp_path / "ot"))
+    assert r.returncode == 1 and "Error reading from squish" in r.stderr
+    assert not (tmp_path / "ot").exists() or _tree(tmp_path / "ot") == {}
+
+
+def test_unpack_rebuilds_many_files_in_parallel(tmp_path, oracle):
+    """rebuild_files' par_iter (reader.rs:378-407): 600 files in 40 directories over 30 records, -j 8 and -j 1 give the same tree; a
+    missing chunk in one of them is reported whatever the thread count."""
+    import random
+    rng = random.Random(5)
+    recs, blobs = [], []
+    for i in range(30):
+        d = bytes(rng.getrandbits(8) for _ in range(rng.choice([0, 1, 300, 5000]))) + (b"abc%d " % i) * rng.randrange(1, 400)
+        h = oracle.hash_chunk(d)
+        recs.append((h, 2 << 20, oracle.compress_chunk(d)))
+        blobs.append((h, d))
+    files, want = [], {}
+    for i in range(600):
+        picks = [rng.choice(blobs) for _ in range(rng.randrange(0, 4))]
+        rel = "d%02d/sub/f%03d.bin" % (i % 40, i)
+        files.append((rel, sum(len(d) for _, d in picks), [h for h, _ in picks]))
+        want[rel] = b"".join(d for _, d in picks)
+    a = tmp_path / "many.squish"
+    a.write_bytes(_archive(recs, files))
+    for j in ("8", "1"):
+        out = tmp_path / ("o" + j)
+        r = _run("-j", j, "unpack", str(a), "-o", str(out))
+        assert r.returncode == 0, r.stderr
+        assert _tree(out) == want
+    files[333] = (files[333][0], 1, [b"\xee" * 16])
+    a.write_bytes(_archive(recs, files))
+    for j in ("8", "1"):
+        r = _run("-j", j, "unpack", str(a), "-o", str(tmp_path / ("m" + j)))
+        assert r.returncode == 1 and "Missing Chunk for File: `%s`" % files[333][0] in r.stderr, r.stderr
