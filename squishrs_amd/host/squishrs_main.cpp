@@ -138,6 +138,7 @@ static std::string strip_prefix(const std::string& path, const std::string& pref
 }
 
 static uint64_t pack(const std::string& input, const std::string& output, int device, uint64_t batch_bytes, long max_threads) {
+    double const t_wall0 = now_s();
     std::string trimmed = input;
     while (!trimmed.empty() && (trimmed.back() == '/' || trimmed.back() == '\\')) trimmed.pop_back();
     std::vector<std::string> files = walk_dir(trimmed); // lib.rs:36
@@ -166,7 +167,7 @@ static uint64_t pack(const std::string& input, const std::string& output, int de
     }
     cfg.dedup_capacity = total_chunks + 1024;
     sq_ctx* ctx = nullptr;
-    double const t_ctx0 = now_s();
+    double const t_ctx0 = now_s(), t_walk = t_ctx0 - t_wall0;
     check(sq_ctx_create(&cfg, &ctx), "sq_ctx_create");
     double t_ctx = now_s() - t_ctx0, t_read = 0, t_gpu = 0, t_write = 0; // SQUISH_TIMING=1 prints them
 
@@ -503,6 +504,7 @@ static uint64_t pack(const std::string& input, const std::string& output, int de
     }
     reader.join();
     writer.join();
+    double const t_stages_end = now_s();
     if (!err.empty()) {
         fclose(out);
         sq_ctx_destroy(ctx);
@@ -539,7 +541,11 @@ static uint64_t pack(const std::string& input, const std::string& output, int de
     fflush(out);
     uint64_t total = (uint64_t)ftell(out);
     fclose(out);
+    double const t_fin = now_s();
     sq_ctx_destroy(ctx);
+    if (getenv("SQUISH_TIMING"))
+        fprintf(stderr, "[squishrs timing] wall inside pack(): walk + stat %.3f s, ctx_create %.3f s, the three stages %.3f s, count + manifest %.3f s, ctx_destroy %.3f s "
+                        "(the batch buffers are released after this line)\n", t_walk, t_ctx, t_stages_end - (t_wall0 + t_walk + t_ctx), t_fin - t_stages_end, now_s() - t_fin);
     return total;
 }
 
