@@ -256,6 +256,9 @@ def _run_cli(cli, *args, env=None):
             if m:
                 stages = {"ctx_create_s": float(m.group(1)), "file_reads_busy_s": float(m.group(2)), "gpu_stage_busy_s": float(m.group(3)),
                           "record_writes_busy_s": float(m.group(4))}
+            w = re.search(r"wall inside pack\(\): walk \+ stat ([0-9.]+) s, ctx_create ([0-9.]+) s, the three stages ([0-9.]+) s", line)
+            if w and stages is not None:   # (the rest of pack_seconds is the process's start and its teardown)
+                stages["wall_inside_pack_s"] = {"walk_and_stat": float(w.group(1)), "ctx_create": float(w.group(2)), "three_stages": float(w.group(3))}
     return dt, stages, r.stdout
 
 
