@@ -1,5 +1,6 @@
 """Differential fuzz on the GPU box: many chunks of random kinds / sizes / compositions through the compress stage,
-EVERY frame compared with the oracle (oracle calls on host threads; ctypes releases the GIL).
+EVERY frame compared with the oracle (oracle calls on host threads; ctypes releases the GIL), then every frame decoded on the
+GPU and compared with its chunk.
 usage: python tools/gpu_fuzz.py [chunks] [seed]"""
 import os
 import sys
@@ -88,5 +89,13 @@ for i, (c, r) in enumerate(zip(chunks, res)):
         if r.compressed_data != want[i] or r.hash != o.hash_chunk(c):
             bad2.append(i)
 print(f"insert_batch path: mismatches {len(bad2)} {bad2[:10]}; unique {st.len()} == {len(seen)}", flush=True)
+# the unpack side: every frame back through sq_decompress_batch with the capacity the reader gives it (the chunk's recorded size,
+# reader.rs:302-303); the output must be the chunk
+t0 = time.time()
+bad3 = []
+for b0 in range(0, n, 512):
+    got = st.decompress_batch(frames[b0:b0 + 512], [len(c) for c in chunks[b0:b0 + 512]])
+    bad3 += [b0 + j for j, g in enumerate(got) if g != chunks[b0 + j]]
+print(f"sq_decompress_batch of the {n} frames: {time.time() - t0:.1f} s; outputs that differ from their chunk: {len(bad3)} {bad3[:10]}", flush=True)
 st.close()
-assert not bad and not bad2 and st is not None
+assert not bad and not bad2 and not bad3 and st is not None
