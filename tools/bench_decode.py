@@ -23,8 +23,11 @@ def one(seed):
 
 
 if __name__ == "__main__":
-    with mp.get_context("fork").Pool(min(32, len(os.sched_getaffinity(0)))) as pool:
-        chunks = pool.map(one, range(41000, 41000 + k))
+    if os.environ.get("SQ_NO_FORK"):   # under rocprofv3 --pmc the GPU is initialised before main(): no fork then
+        chunks = [one(s) for s in range(41000, 41000 + k)]
+    else:
+        with mp.get_context("fork").Pool(min(32, len(os.sched_getaffinity(0)))) as pool:
+            chunks = pool.map(one, range(41000, 41000 + k))
     import torch
     import squishrs_amd
     base = torch.frombuffer(bytearray(b"".join(chunks)), dtype=torch.uint8).cuda()
